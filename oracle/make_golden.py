@@ -1,0 +1,68 @@
+"""Generate tests/golden/*.npz from the oracle (run here, committed with its outputs).
+
+There are no upstream vectors (parity unpinned, SPEC.md); these fixtures pin the
+oracle itself against drift and give the GPU box fixed inputs -> expected outputs.
+
+    python oracle/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from coivo_amd import synth  # noqa: E402
+from oracle import colvo_spec as S  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def loss_case(name, B, H, W, seed, jitter=True):
+    """Inputs + loss + gradients of the fused path (a3..a7) at the synthetic GT-ish operating point."""
+    b = synth.make_batch(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    depth = (b["gt_depth"] * (1 + 0.05 * torch.randn(B, 1, H, W, generator=g))).clamp(0.2, 9.0) if jitter else b["gt_depth"]
+    pose = b["gt_pose"] + (0.005 * torch.randn(B, 6, generator=g) if jitter else 0)
+    a, bb = b["gt_a"].clone(), b["gt_b"].clone()
+    leaves = [t.clone().requires_grad_(True) for t in (depth, pose, a, bb)]
+    loss = S.photometric_loss(b["tgt"], b["ref"], leaves[0], leaves[1], b["K"], leaves[2], leaves[3])
+    grads = torch.autograd.grad(loss, leaves)
+    warped, valid = S.inverse_warp(b["ref"], depth, pose, b["K"])
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        tgt=b["tgt"].numpy(), ref=b["ref"].numpy(), K=b["K"].numpy(),
+        depth=depth.numpy(), pose=pose.numpy(), lcc_a=a.numpy(), lcc_b=bb.numpy(),
+        loss=np.float32(loss.item()), valid_frac=np.float32(valid.mean().item()),
+        warped_sum=np.float64(warped.double().sum().item()),
+        d_depth=grads[0].numpy(), d_pose=grads[1].numpy(), d_a=grads[2].numpy(), d_b=grads[3].numpy())
+    print(name, "loss", loss.item(), "valid", valid.mean().item())
+
+
+def net_case(name, B, H, W, seed):
+    """Seeds + expected network outputs (weights are regenerated from the seed, not stored)."""
+    b = synth.make_batch(B, H, W, seed=seed)
+    dn, pn = S.make_models(seed=seed)
+    loss, d_t, d_r, pose, a, bb = S.dcdp_forward(dn, pn, b["tgt"], b["ref"], b["K"])
+    loss.backward()
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        B=B, H=H, W=W, seed=seed,
+        loss=np.float32(loss.item()), depth_t=d_t.detach().numpy(), depth_r=d_r.detach().numpy(),
+        pose=pose.detach().numpy(), lcc_a=a.detach().numpy(), lcc_b=bb.detach().numpy(),
+        g_head_w=dn.head.weight.grad.numpy(), g_enc1a_w=dn.enc1a.weight.grad.numpy(),
+        g_pred_w=pn.pred.weight.grad.numpy(), g_conv1_b=pn.conv1.bias.grad.numpy())
+    print(name, "loss", loss.item())
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)  # one thread: bit-stable reductions
+    loss_case("loss_b2_32x40", 2, 32, 40, seed=11)
+    loss_case("loss_b2_64x96", 2, 64, 96, seed=12)
+    loss_case("loss_b1_256x320", 1, 256, 320, seed=13)
+    loss_case("loss_b2_33x47_ragged", 2, 33, 47, seed=14)   # not tile-aligned
+    net_case("net_b2_64x96", 2, 64, 96, seed=21)
+    net_case("net_b1_32x64", 1, 32, 64, seed=22)
