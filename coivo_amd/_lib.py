@@ -1,0 +1,91 @@
+"""ctypes binding of libcolvo.so -- the C-ABI declared in include/colvo.h.
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcolvo.so")
+
+F32, BF16 = 0, 1
+ABI_VERSION = 1
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "dtype", "B", "Ho", "Wo", "Cout", "ksize", "stride", "relu",
+        "C0", "up0", "C1", "up1", "Hi", "Wi")]
+
+
+# name -> (restype, argtypes); lists every symbol include/colvo.h declares
+SIGNATURES = {
+    "colvo_abi_version": (_i, []),
+    "colvo_last_error": (C.c_char_p, []),
+    "colvo_warp_loss_workspace_floats": (_sz, [_i, _i, _i]),
+    "colvo_warp_loss_fwd": (_i, [_vp] * 7 + [_i, _i, _i, _f, _vp, _vp, _vp]),
+    "colvo_warp_loss_bwd": (_i, [_vp] * 7 + [_i, _i, _i, _f] + [_vp] * 8),
+    "colvo_inverse_warp": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 3),
+    "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
+    "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
+    "colvo_relu_bwd_inplace": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "colvo_pack_weights": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "colvo_pack_nchw": (_i, [_i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _vp, _vp]),
+    "colvo_unpack_nhwc_grad": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "colvo_depth_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
+    "colvo_depth_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "colvo_pose_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
+    "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libcolvo.so (built by `python -m coivo_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python -m coivo_amd.build`). "
+            "coivo_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing and not os.environ.get("COLVO_PARTIAL_LIB"):  # bring-up switch, removed once all symbols exist
+        raise RuntimeError(f"{LIB_PATH} does not export {missing}: stale build? run `python -m coivo_amd.build --force`")
+    v = lib.colvo_abi_version()
+    if v != ABI_VERSION:
+        raise RuntimeError(f"libcolvo ABI version {v} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().colvo_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

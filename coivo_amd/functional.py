@@ -1,0 +1,89 @@
+"""Loss-side operators of the hot path with the signatures of the frozen spec
+(oracle/colvo_spec.py: photometric_loss, inverse_warp), backed by the fused HIP kernels.
+
+Concepts: /root/reference/README.md:1 (photometric consistency), :7 (geometric projection between
+consecutive frames), :5/:7 (LCC).  The reference ships no code, so the signatures are
+the spec's.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+SSIM_WEIGHT = 0.85
+
+
+def _chk(t: torch.Tensor, name: str, shape) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: coivo_amd ops run on the GPU only (got a {t.device} tensor); "
+                           "there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+class _WarpLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight):
+        lib = _lib.load()
+        B, C, H, W = tgt.shape
+        if C != 3:
+            raise ValueError("photometric_loss: images must have 3 channels")
+        tgt = _chk(tgt, "tgt", (B, 3, H, W))
+        ref = _chk(ref, "ref", (B, 3, H, W))
+        depth = _chk(depth, "depth", (B, 1, H, W))
+        pose = _chk(pose, "pose", (B, 6))
+        K = _chk(K, "K", (B, 3, 3))
+        lcc_a = _chk(lcc_a, "lcc_a", (B, 1))
+        lcc_b = _chk(lcc_b, "lcc_b", (B, 1))
+        nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
+        ws = torch.empty(nws, device=tgt.device, dtype=torch.float32)
+        state = torch.empty(4, device=tgt.device, dtype=torch.float32)
+        _lib.check(lib.colvo_warp_loss_fwd(_lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K),
+                                           _lib.ptr(lcc_a), _lib.ptr(lcc_b), B, H, W, float(ssim_weight),
+                                           _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr()), "colvo_warp_loss_fwd")
+        ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
+        ctx.ssim_weight = float(ssim_weight)
+        return state[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        tgt, ref, depth, pose, K, lcc_a, lcc_b, state = ctx.saved_tensors
+        B, _, H, W = tgt.shape
+        g = grad_loss.to(torch.float32).contiguous().reshape(1)
+        nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
+        ws = torch.empty(nws, device=tgt.device, dtype=torch.float32)
+        d_depth = torch.empty_like(depth)
+        d_pose = torch.empty_like(pose)
+        d_a = torch.empty_like(lcc_a)
+        d_b = torch.empty_like(lcc_b)
+        _lib.check(lib.colvo_warp_loss_bwd(_lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K),
+                                           _lib.ptr(lcc_a), _lib.ptr(lcc_b), B, H, W, ctx.ssim_weight,
+                                           _lib.ptr(state), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(d_depth),
+                                           _lib.ptr(d_pose), _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr()),
+                   "colvo_warp_loss_bwd")
+        return None, None, d_depth, d_pose, None, d_a, d_b, None
+
+
+def photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
+    """Masked mean of alpha*(1-SSIM)/2 + (1-alpha)*|I_t - (a*warp(I_r)+b)| -> scalar (spec: photometric_loss)."""
+    return _WarpLoss.apply(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight)
+
+
+def inverse_warp(ref, depth, pose, K):
+    """Un-fused debugging entry (spec: inverse_warp) -> (warped [B,C,H,W], valid [B,1,H,W]); no autograd."""
+    lib = _lib.load()
+    B, C, H, W = ref.shape
+    ref = _chk(ref, "ref", (B, C, H, W))
+    depth = _chk(depth, "depth", (B, 1, H, W))
+    pose = _chk(pose, "pose", (B, 6))
+    K = _chk(K, "K", (B, 3, 3))
+    warped = torch.empty_like(ref)
+    valid = torch.empty_like(depth)
+    _lib.check(lib.colvo_inverse_warp(_lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), B, C, H, W,
+                                      _lib.ptr(warped), _lib.ptr(valid), _lib.stream_ptr()), "colvo_inverse_warp")
+    return warped, valid

@@ -1,0 +1,153 @@
+/* colvo.h -- C-ABI of the MI355X-native ColVO DCDP+LCC training hot path (libcolvo.so).
+ *
+ * The upstream reference (HNUicda/CoIVO, /root/reference) defines NO plugin, operator or FFI
+ * interface -- it ships README.md and three figures only.  Each entry point
+ * below therefore cites the README sentence that names the concept it implements and the function
+ * of the frozen specification (oracle/colvo_spec.py) whose results it must reproduce; there is no
+ * reference file:line to replace.
+ *
+ * Conventions
+ *   - plain C types only: device pointers + sizes; `stream` is a hipStream_t passed as void*.
+ *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
+ *     frees or keeps a pointer after return.
+ *   - every call only ENQUEUES work on `stream` and returns; no internal synchronisation, no
+ *     global mutable state -> safe under one-process-per-GPU data parallel and under hipGraph
+ *     capture.
+ *   - return 0 on success, a non-zero hipError_t-style code otherwise; the message is available
+ *     from colvo_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - images / depth at the boundary: NCHW, contiguous, fp32.  Feature maps inside the conv stack:
+ *     NHWC, fp32 (COLVO_F32) or bf16 (COLVO_BF16).
+ */
+#ifndef COLVO_H_
+#define COLVO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COLVO_ABI_VERSION 1
+
+typedef void* colvo_stream_t; /* hipStream_t */
+
+enum { COLVO_F32 = 0, COLVO_BF16 = 1 };
+
+int colvo_abi_version(void);
+const char* colvo_last_error(void);
+
+/* ------------------------------------------------------------------------------------------- *
+ * a3..a7  fused  project -> bilinear-sample -> LCC-recalibrate -> SSIM/L1       *
+ *   concept: README.md:1 "Photometric Consistency", README.md:7 "alignment of geometric       *
+ *   projections between consecutive frames", README.md:5,7 LCC "recalibrating the luminosity  *
+ *   values of adjacent frames".   spec: oracle/colvo_spec.py photometric_loss().               *
+ * ------------------------------------------------------------------------------------------- */
+
+/* Number of floats of scratch the fwd / bwd calls need for a [B,3,H,W] problem. */
+size_t colvo_warp_loss_workspace_floats(int B, int H, int W);
+
+/* Forward.  tgt, ref [B,3,H,W]; depth [B,1,H,W]; pose [B,6]; K [B,3,3]; lcc_a, lcc_b [B].
+ * loss_state[4] (device) receives { loss, 1/max(3*n_valid,1), n_valid, 0 }.  H, W >= 2. */
+int colvo_warp_loss_fwd(const float* tgt, const float* ref, const float* depth, const float* pose,
+                        const float* K, const float* lcc_a, const float* lcc_b,
+                        int B, int H, int W, float ssim_weight,
+                        float* workspace, float* loss_state, colvo_stream_t stream);
+
+/* Backward (recomputes the warp; nothing but loss_state is saved by the forward).
+ * grad_loss: device scalar dL/dloss.  Outputs: d_depth [B,1,H,W], d_pose [B,6], d_a [B], d_b [B]. */
+int colvo_warp_loss_bwd(const float* tgt, const float* ref, const float* depth, const float* pose,
+                        const float* K, const float* lcc_a, const float* lcc_b,
+                        int B, int H, int W, float ssim_weight,
+                        const float* loss_state, const float* grad_loss,
+                        float* workspace, float* d_depth, float* d_pose, float* d_a, float* d_b,
+                        colvo_stream_t stream);
+
+/* Un-fused debugging entry (spec: inverse_warp()).  ref [B,C,H,W] -> warped [B,C,H,W], valid [B,1,H,W]. */
+int colvo_inverse_warp(const float* ref, const float* depth, const float* pose, const float* K,
+                       int B, int C, int H, int W, float* warped, float* valid, colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * a1, a2  conv blocks of DepthNet / PoseNet (README.md:5,7 DCDP "depth and pose estimation")  *
+ *   spec: oracle/colvo_spec.py DepthNet / PoseNet (F.conv2d + F.relu + nearest up + concat).   *
+ *   One implicit-GEMM convolution on NHWC feature maps, MFMA on gfx950; the decoder's nearest  *
+ *   2x up-sample and the skip concat are folded into the input gather.                         *
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ColvoConvDesc {
+    int32_t dtype;      /* COLVO_F32 | COLVO_BF16: type of x0, x1, y, dy, dx and of the packed weights */
+    int32_t B;          /* images */
+    int32_t Ho, Wo;     /* output spatial size */
+    int32_t Cout;       /* multiple of 8 */
+    int32_t ksize;      /* 3 or 1 (pad = ksize/2) */
+    int32_t stride;     /* 1 or 2 */
+    int32_t relu;       /* 1: y = max(conv + bias, 0) */
+    /* source 0 (and optional source 1, channel-concatenated after source 0) */
+    int32_t C0;         /* channels of x0, multiple of 8 */
+    int32_t up0;        /* 1: x0 is stored at half resolution and read through nearest 2x up-sampling */
+    int32_t C1;         /* channels of x1 (0 = none), multiple of 8 */
+    int32_t up1;
+    int32_t Hi, Wi;     /* spatial size of the (virtual, i.e. after up-sampling) conv input */
+} ColvoConvDesc;
+
+/* y[B,Ho,Wo,Cout] = act(conv(cat(x0,x1)) + bias).  w_fwd: weights packed [Cout][ksize*ksize][C0+C1]
+ * in `dtype`; bias fp32 [Cout]. */
+int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void* x1, const void* w_fwd,
+                   const float* bias, void* y, colvo_stream_t stream);
+
+/* Input gradient of source `src` (0 or 1).  dy[B,Ho,Wo,Cout] must already be the gradient w.r.t. the
+ * pre-activation (see relu_mask below).  w_bwd: weights packed [C0+C1][ksize*ksize][Cout].
+ * dx has the STORED shape of the source (half resolution when up-sampled).
+ * relu_mask (may be NULL): the stored output of the layer that produced this source; when given, dx is
+ * multiplied by (relu_mask > 0), i.e. dx becomes that producer's pre-activation gradient.
+ * accumulate: 0 = overwrite dx, 1 = dx += (fan-out of skip connections). */
+int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy, const void* w_bwd,
+                     const void* relu_mask, void* dx, int accumulate, colvo_stream_t stream);
+
+/* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
+ * (the caller zeroes them once per step). */
+int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
+                     float* dw, float* db, colvo_stream_t stream);
+
+/* dy <- dy * (y > 0) in place (first consumer of a ReLU output's gradient when no dgrad produced it). */
+int colvo_relu_bwd_inplace(int dtype, const void* y, void* dy, size_t n, colvo_stream_t stream);
+
+/* Master fp32 weights [Cout][kk][Cin] -> the two packed operand layouts in `dtype`:
+ * w_fwd [Cout][kk][Cin] and w_bwd [Cin][kk][Cout]. */
+int colvo_pack_weights(int dtype, const float* w_master, int Cout, int kk, int Cin,
+                       void* w_fwd, void* w_bwd, colvo_stream_t stream);
+
+/* NCHW fp32 planes -> NHWC feature map of `Cpad` channels (zero padded), and back (gradient, fp32 NCHW).
+ * src[i] points to an [B,c_i,H,W] tensor; up to 4 sources are concatenated along channels. */
+int colvo_pack_nchw(int dtype, const float* const* src, const int32_t* src_channels, int nsrc,
+                    int B, int H, int W, int Cpad, void* dst, colvo_stream_t stream);
+int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H, int W, int Cpad,
+                           int c_begin, int c_count, float* dst_nchw, int accumulate, colvo_stream_t stream);
+
+/* DepthNet head: conv3x3 (C -> 1) + sigmoid + disp_to_depth, output NCHW fp32 [B,1,H,W]; and its
+ * backward (d_depth -> dx NHWC [masked by x>0, the producer's ReLU], dw[9*C] += , db[1] +=). */
+int colvo_depth_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int H, int W, int C,
+                         float min_depth, float max_depth, float* depth, colvo_stream_t stream);
+int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* depth, const float* d_depth,
+                         int B, int H, int W, int C, float min_depth, float max_depth,
+                         void* dx, float* dw, float* db, colvo_stream_t stream);
+
+/* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.
+ * out[B,8] = { pose[6], lcc_a, lcc_b }; backward takes d_out[B,8]. */
+int colvo_pose_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int HW, int C,
+                        float pose_scale, float lcc_scale, float* out, colvo_stream_t stream);
+int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_out, int B, int HW, int C,
+                        float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * a8  Adam over the flat parameter arena (torch.optim.Adam semantics, no weight decay)         *
+ * ------------------------------------------------------------------------------------------- */
+/* step_count: device int32 holding t BEFORE this step (incremented by the kernel, graph-safe).
+ * grad_scale multiplies the gradient first (1/world_size for data-parallel sums). */
+int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, float grad_scale,
+                    int32_t* step_count, colvo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLVO_H_ */
