@@ -1,0 +1,662 @@
+// conv.hip -- a1/a2 of SURVEY.md §8: the 3x3 convolution blocks of DepthNet / PoseNet as
+// patch-staged implicit GEMMs on the gfx950 matrix cores.
+//
+// Concept: /root/reference/README.md:5,7 (DCDP depth + pose estimation networks).  Results are
+// specified by oracle/colvo_spec.py (F.conv2d(k=3, pad=1, stride 1|2) + bias + ReLU, nearest 2x
+// up-sampling and channel concat in front of decoder convs).
+//
+// Layout: feature maps NHWC, channels a multiple of 8; T = float (exact-f32 MFMA 16x16x4, parity mode)
+// or bf16 (MFMA 16x16x32, throughput mode), fp32 accumulation in both.
+//
+// k_conv3x3 (forward AND input-gradient):  D[pixel][n] = sum_{tap,c} A[pixel@tap][c] * W[n][tap][c]
+//   - one 256-thread workgroup = a tile of <=128 output pixels (toh x tow region of one image) x BN
+//     output channels; wave w owns pixel rows 32w..32w+31 (2 MFMA row fragments) x all BN columns.
+//   - K loop over channel chunks of CK = NG*16 bytes: the input PATCH of the tile (tile + halo, CK
+//     channels) is staged in LDS ONCE and re-read by all 9 taps (9x fewer global reads than a per-tap
+//     gather); the weight slab [BN][9][CK] is staged beside it.  Pixel pitch / weight-row pitch are
+//     padded by one 16-byte granule so the 16 lanes of a ds_read_b128 group fall on distinct banks.
+//   - the gather that fills the patch folds in: zero padding, nearest 2x up-sampling (decoder "up"
+//     convs), channel concat of two sources (skip connections), and zero-insertion (the input gradient
+//     of a stride-2 conv is a stride-1 conv over the zero-dilated output gradient, flipped weights).
+//   - epilogue through LDS: bias, ReLU, 2x2 sum-pooling (input gradient of an up-sampled source),
+//     ReLU-mask of the producer, accumulate (skip fan-out), convert, 16-byte coalesced stores.
+//
+// k_wgrad3x3:  dW[co][tap][c] += sum_pixels dY[pixel][co] * X[pixel@tap][c]   (K = pixels)
+//   - workgroup = (co tile of 16*MT) x (channel chunk CK of one source) x (a range of pixel tiles);
+//     the sums of the whole range stay in MFMA accumulators, then ONE fp32 atomic add per element.
+//   - both operands have the reduction index (pixel) as the slow LDS dimension: bf16 fragments are
+//     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
+#include "common.h"
+
+namespace colvo {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+struct bf16_t { uint16_t v; };
+
+template <typename T> struct TT;
+template <> struct TT<float> { static constexpr int G = 4; static constexpr int ES = 4; };
+template <> struct TT<bf16_t> { static constexpr int G = 8; static constexpr int ES = 2; };
+
+constexpr int NT = 256;
+constexpr int BM = 128;   // output pixels per workgroup (4 waves x 2 fragments x 16 rows)
+
+enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
+
+struct Gather {               // how the (virtual) conv input is read from the stored sources
+    const char* src[2];
+    int C[2];
+    int Hs[2], Ws[2];
+    int mode[2];
+    int Hi, Wi;               // virtual input extent (zero outside)
+    int stride;
+};
+
+struct ConvK {
+    Gather g;
+    int Ho, Wo;               // conv output extent
+    const char* w;            // [N][9][Ctot]
+    int Ctot, N;
+    const float* bias;
+    int relu;
+    char* out;                // [B][Ho(/2)][Wo(/2)][N]
+    const char* mask;         // same shape as out or null
+    int accumulate, pool2;
+    int toh, tow, tiles_x, tiles_y;
+};
+
+struct WgradK {
+    Gather g;
+    int Ho, Wo, B;
+    const char* dy;           // [B][Ho][Wo][Cout]
+    int Cout;
+    float* dw;                // [Cout][9][Ctot]
+    int Ctot;
+    float* db;
+    int toh, tow, tiles_x, tiles_y, ntiles, tiles_per_split;
+};
+
+__device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+// Stage the input patch of one tile / one channel chunk: sP[pix][CK] (pitch PIXP bytes).
+template <typename T, int NG>
+__device__ __forceinline__ void stage_patch(const Gather& g, int s, int c0, int b, int iy0, int ix0, int PH, int PW,
+                                            char* sP) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int PIXP = (NG + 1) * 16;
+    const int total = PH * PW * NG;
+    const char* base = g.src[s];
+    const int C = g.C[s], Hs = g.Hs[s], Ws = g.Ws[s], mode = g.mode[s];
+    for (int i = threadIdx.x; i < total; i += NT) {
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = pix / PW, px = pix - py * PW;
+        const int vy = iy0 + py, vx = ix0 + px;
+        bool inb = (vy >= 0) && (vy < g.Hi) && (vx >= 0) && (vx < g.Wi);
+        int sy = vy, sx = vx;
+        if (mode != MODE_DIRECT) {
+            if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
+            sy = vy >> 1; sx = vx >> 1;
+        }
+        inb = inb && (sy < Hs) && (sx < Ws);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inb) v = ld16(base + ((((size_t)b * Hs + sy) * Ws + sx) * C + c0 + cg * G) * ES);
+        st16(sP + pix * PIXP + cg * 16, v);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// forward / input-gradient kernel                                                                //
+// --------------------------------------------------------------------------------------------- //
+template <typename T, int BN, int NG>
+__global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int CK = NG * G;
+    constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
+    constexpr int STEPS = (NGR + 3) / 4;           // MFMA k-groups (4 granules each) per chunk
+    constexpr int WROW = (STEPS * 4 + 1) * 16;     // weight-row pitch in LDS (bytes)
+    constexpr int PIXP = (NG + 1) * 16;            // patch-pixel pitch in LDS (bytes)
+    constexpr int NF = BN / 16;
+    constexpr int OUTP = BN + 4;                   // epilogue row pitch (floats)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.y * BN;
+    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    const int oy0 = ty * a.toh, ox0 = tx * a.tow;
+    const int S = a.g.stride;
+    const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
+    const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+    const int npix = a.toh * a.tow;
+
+    // the two fragment rows (pixels) of this lane
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = p / a.tow, ox = p - oy * a.tow;
+        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
+    }
+
+    f32x4 acc[2][NF];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int wc0 = 0;   // column of this chunk inside a weight row
+    for (int s = 0; s < 2; ++s) {
+        const int Cs = a.g.C[s];
+        for (int c0 = 0; c0 < Cs; c0 += CK, wc0 += CK) {
+            __syncthreads();
+            // weight slab [BN][STEPS*4 granules], zero beyond the 9*NG real ones / beyond N
+            for (int i = tid; i < BN * STEPS * 4; i += NT) {
+                const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (gi < NGR && n0 + n < a.N) {
+                    const int tap = gi / NG, cg = gi - tap * NG;
+                    v = ld16(a.w + (((size_t)(n0 + n) * 9 + tap) * a.Ctot + wc0 + cg * G) * ES);
+                }
+                st16(sW + n * WROW + gi * 16, v);
+            }
+            stage_patch<T, NG>(a.g, s, c0, b, iy0, ix0, PH, PW, sP);
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < STEPS; ++m) {
+                const int gi = 4 * m + kg;
+                int tap = gi / NG;
+                const int cg = gi - tap * NG;
+                tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+                u32x4 av[2], bv[NF];
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf)
+                                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue through LDS ----
+    __syncthreads();
+    float* sOut = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sOut[(wave * 32 + mf * 16 + 4 * kg + r) * OUTP + nf * 16 + l15] = acc[mf][nf][r];
+    __syncthreads();
+
+    constexpr int GPR = BN / G;   // output granules per pixel row of the tile
+    const int Hout = a.pool2 ? (a.Ho >> 1) : a.Ho, Wout = a.pool2 ? (a.Wo >> 1) : a.Wo;
+    const int eh = a.pool2 ? (a.toh >> 1) : a.toh, ew = a.pool2 ? (a.tow >> 1) : a.tow;
+    const int ey0 = a.pool2 ? (oy0 >> 1) : oy0, ex0 = a.pool2 ? (ox0 >> 1) : ox0;
+    for (int i = tid; i < eh * ew * GPR; i += NT) {
+        const int q = i / GPR, gch = i - q * GPR;
+        const int qy = q / ew, qx = q - qy * ew;
+        const int gy = ey0 + qy, gx = ex0 + qx;
+        const int n = n0 + gch * G;
+        if (gy >= Hout || gx >= Wout || n >= a.N) continue;
+        float v[G];
+        if (a.pool2) {
+            const float* r0 = sOut + ((2 * qy) * a.tow + 2 * qx) * OUTP + gch * G;
+            const float* r1 = r0 + a.tow * OUTP;
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = (r0[k] + r0[OUTP + k]) + (r1[k] + r1[OUTP + k]);
+        } else {
+            const float* r0 = sOut + q * OUTP + gch * G;
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = r0[k];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] += a.bias[n + k];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = fmaxf(v[k], 0.0f);
+        }
+        const size_t off = ((((size_t)b * Hout + gy) * Wout + gx) * a.N + n) * ES;
+        if constexpr (ES == 4) {
+            if (a.mask) {
+                const u32x4 m = ld16(a.mask + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (__uint_as_float(m[k]) > 0.0f) ? v[k] : 0.0f;
+            }
+            if (a.accumulate) {
+                const u32x4 o = ld16(a.out + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += __uint_as_float(o[k]);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(v[k]);
+            st16(a.out + off, o);
+        } else {
+            if (a.mask) {
+                const u32x4 m = ld16(a.mask + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // bf16 > 0  <=>  sign clear and magnitude non-zero
+                    const uint32_t lo = m[k] & 0xFFFFu, hi = m[k] >> 16;
+                    if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
+                    if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+                }
+            }
+            if (a.accumulate) {
+                const u32x4 o = ld16(a.out + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] += bf2f((uint16_t)(o[k] & 0xFFFFu));
+                    v[2 * k + 1] += bf2f((uint16_t)(o[k] >> 16));
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+            st16(a.out + off, o);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// weight-gradient kernel                                                                         //
+// --------------------------------------------------------------------------------------------- //
+template <typename T, int MT, int NG>
+__global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int CK = NG * G;
+    constexpr int NCOL = 9 * CK;                   // (tap, c) columns of this chunk
+    constexpr int NFR = (NCOL + 15) / 16;          // column fragments
+    constexpr int FPW = (NFR + 3) / 4;             // fragments per wave
+    constexpr int PIXP = (NG + 1) * 16;
+    constexpr int DYP = 16 * MT * ES + 16;         // dY row pitch (bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sDY = smem;                              // [BM][16*MT]
+    char* sX = smem + BM * DYP;                    // patch
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int co0 = blockIdx.y * 16 * MT;
+    // chunk -> (source, channel offset)
+    const int chunks0 = a.g.C[0] / CK;
+    const int s = ((int)blockIdx.z < chunks0) ? 0 : 1;
+    const int c0 = (s == 0 ? (int)blockIdx.z : (int)blockIdx.z - chunks0) * CK;
+    const int wc0 = (s == 0 ? 0 : a.g.C[0]) + c0;
+    const int S = a.g.stride;
+    const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
+    const int npix = a.toh * a.tow;
+
+    // per-lane column decode of the owned fragments
+    int boff[FPW];      // LDS byte offset of this lane's (tap, c) inside a patch pixel row-set
+    int ocol[FPW];      // element offset tap*Ctot + c of this lane's OUTPUT column (-1: padding)
+#pragma unroll
+    for (int fi = 0; fi < FPW; ++fi) {
+        const int f = wave + 4 * fi;
+        // address column (tr read: lane supplies the address of columns 4p..4p+3; plain: own column)
+        const int ncol_addr = 16 * f + ((ES == 2) ? 4 * (lane & 3) : l15);
+        int tap = min(ncol_addr / CK, 8);
+        const int c = ncol_addr - (ncol_addr / CK) * CK;
+        boff[fi] = ((tap / 3) * PW + (tap % 3)) * PIXP + c * ES;
+        const int ncol = 16 * f + l15;
+        ocol[fi] = (f < NFR && ncol < NCOL) ? ((ncol / CK) * a.Ctot + (ncol % CK)) : -1;
+    }
+
+    f32x4 acc[MT][FPW];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int fi = 0; fi < FPW; ++fi) acc[mi][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc = 0.0f;
+
+    const int t_begin = blockIdx.x * a.tiles_per_split;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / tiles_per_img;
+        const int tr_ = t - b * tiles_per_img;
+        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
+        const int oy0 = ty * a.toh, ox0 = tx * a.tow;
+        __syncthreads();
+        // dY tile: BM rows (zero for slots outside the region / image)
+        constexpr int DGR = 16 * MT / G;
+        for (int i = tid; i < BM * DGR; i += NT) {
+            const int p = i / DGR, gch = i - p * DGR;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (p < npix) {
+                const int oy = p / a.tow, ox = p - oy * a.tow;
+                const int gy = oy0 + oy, gx = ox0 + ox;
+                if (gy < a.Ho && gx < a.Wo && co0 + gch * G < a.Cout)
+                    v = ld16(a.dy + ((((size_t)b * a.Ho + gy) * a.Wo + gx) * a.Cout + co0 + gch * G) * ES);
+            }
+            st16(sDY + p * DYP + gch * 16, v);
+        }
+        stage_patch<T, NG>(a.g, s, c0, b, oy0 * S - 1, ox0 * S - 1, PH, PW, sX);
+        __syncthreads();
+
+        if (blockIdx.z == 0 && a.db && tid < 16 * MT) {
+            float sacc = 0.0f;
+            for (int p = 0; p < npix; ++p) {
+                if constexpr (ES == 2) sacc += bf2f(*reinterpret_cast<const uint16_t*>(sDY + p * DYP + tid * 2));
+                else sacc += *reinterpret_cast<const float*>(sDY + p * DYP + tid * 4);
+            }
+            dbacc += sacc;
+        }
+
+        if constexpr (ES == 2) {
+            // K = 128 pixels in 4 steps of 32; fragments by hardware-transposed LDS reads
+            const int q = l15 >> 2, pp = lane & 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int xo[2], yo[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int p = 32 * ks + 8 * kg + q + 4 * h;
+                    yo[h] = p * DYP;
+                    if (p >= npix) p = 0;     // its dY row is zero
+                    const int oy = p / a.tow, ox = p - oy * a.tow;
+                    xo[h] = ((oy * S) * PW + ox * S) * PIXP;
+                }
+                s16x8 af[MT];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sDY + yo[0] + (16 * mi + 4 * pp) * 2));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sDY + yo[1] + (16 * mi + 4 * pp) * 2));
+                    af[mi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sX + xo[0] + boff[fi]));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sX + xo[1] + boff[fi]));
+                    const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        acc[mi][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf), acc[mi][fi], 0, 0, 0);
+                }
+            }
+        } else {
+            // K = 128 pixels in 32 steps of 4 (exact f32 MFMA 16x16x4); lane k-slot = kg
+            int p = kg;
+            int oy = p / a.tow, ox = p - oy * a.tow;
+            for (int ks = 0; ks < BM / 4; ++ks) {
+                const bool live = p < npix;
+                const int xo = live ? ((oy * S) * PW + ox * S) * PIXP : 0;
+                float av[MT];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+                    av[mi] = *reinterpret_cast<const float*>(sDY + p * DYP + (16 * mi + l15) * 4);
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi) {
+                    const float bvv = *reinterpret_cast<const float*>(sX + xo + boff[fi]);
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        acc[mi][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bvv, acc[mi][fi], 0, 0, 0);
+                }
+                p += 4; ox += 4;
+                while (ox >= a.tow) { ox -= a.tow; ++oy; }
+            }
+        }
+    }
+
+    // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int fi = 0; fi < FPW; ++fi) {
+            if (ocol[fi] < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + 16 * mi + 4 * kg + r;
+                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
+            }
+        }
+    if (blockIdx.z == 0 && a.db && tid < 16 * MT && co0 + tid < a.Cout) atomicAdd(a.db + co0 + tid, dbacc);
+}
+
+// --------------------------------------------------------------------------------------------- //
+// host side                                                                                      //
+// --------------------------------------------------------------------------------------------- //
+struct Tile { int toh, tow; };
+
+// choose the tile region (<=128 pixels) that wastes the fewest fragment rows; ties: least staged patch
+Tile pick_tile(int Ho, int Wo, int stride, bool even) {
+    Tile best{even ? 2 : 1, even ? 2 : 1};
+    double best_cost = 1e30;
+    const int step = even ? 2 : 1;
+    for (int tow = step; tow <= (Wo + step - 1) / step * step && tow <= BM; tow += step) {
+        int toh = BM / tow;
+        if (even) toh &= ~1;
+        const int hcap = (Ho + step - 1) / step * step;
+        if (toh > hcap) toh = hcap;
+        if (toh < step) continue;
+        const long tiles = (long)((Ho + toh - 1) / toh) * ((Wo + tow - 1) / tow);
+        const long patch = (long)((toh - 1) * stride + 3) * ((tow - 1) * stride + 3);
+        const double cost = (double)tiles * (BM + 0.25 * patch);
+        if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow}; }
+    }
+    return best;
+}
+
+template <typename T, int BN, int NG>
+int launch_conv(const ConvK& k, int B, hipStream_t s) {
+    constexpr int STEPS = (9 * NG + 3) / 4;
+    constexpr int WROW = (STEPS * 4 + 1) * 16, PIXP = (NG + 1) * 16;
+    const int S = k.g.stride;
+    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
+    const size_t eplds = (size_t)BM * (BN + 4) * 4;
+    if (eplds > lds) lds = eplds;
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
+    static size_t configured = 0;   // per instantiation
+    if (lds > 48 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = 160 * 1024;
+    }
+    dim3 grid(k.tiles_x * k.tiles_y, (k.N + BN - 1) / BN, B);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG>), grid, dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_conv3x3");
+    return 0;
+}
+
+template <typename T, int BN>
+int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
+    switch (ng) {
+        case 4: return launch_conv<T, BN, 4>(k, B, s);
+        case 2: return launch_conv<T, BN, 2>(k, B, s);
+        default: return launch_conv<T, BN, 1>(k, B, s);
+    }
+}
+
+template <typename T>
+int launch_conv_t(const ConvK& k, int B, hipStream_t s) {
+    constexpr int G = TT<T>::G;
+    int ng = 4;
+    for (int i = 0; i < 2; ++i)
+        if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
+    for (int i = 0; i < 2; ++i)
+        COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "conv: channel count %d is not a multiple of %d", k.g.C[i], G);
+    if (k.N >= 64) return launch_conv_ng<T, 64>(k, B, ng, s);
+    if (k.N >= 32) return launch_conv_ng<T, 32>(k, B, ng, s);
+    return launch_conv_ng<T, 16>(k, B, ng, s);
+}
+
+template <typename T, int MT, int NG>
+int launch_wgrad(WgradK k, hipStream_t s) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int CK = NG * G, PIXP = (NG + 1) * 16, DYP = 16 * MT * ES + 16;
+    const int S = k.g.stride;
+    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    const size_t lds = (size_t)BM * DYP + (size_t)PH * PW * PIXP + 64;
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: tile needs %zu bytes of LDS", lds);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<T, MT, NG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = 160 * 1024;
+    }
+    const int chunks = (k.g.C[0] + k.g.C[1]) / CK;
+    const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
+    // enough workgroups to fill 256 CUs a few times over, but >= 1 tile each
+    int nsplit = (1024 + chunks * cot - 1) / (chunks * cot);
+    if (nsplit > k.ntiles) nsplit = k.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
+    nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
+    dim3 grid(nsplit, cot, chunks);
+    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG>), grid, dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_wgrad3x3");
+    return 0;
+}
+
+template <typename T, int MT>
+int launch_wgrad_ng(const WgradK& k, int ng, hipStream_t s) {
+    switch (ng) {
+        case 4: return launch_wgrad<T, MT, 4>(k, s);
+        case 2: return launch_wgrad<T, MT, 2>(k, s);
+        default: return launch_wgrad<T, MT, 1>(k, s);
+    }
+}
+
+template <typename T>
+int launch_wgrad_t(const WgradK& k, hipStream_t s) {
+    constexpr int G = TT<T>::G;
+    int ng = 4;
+    for (int i = 0; i < 2; ++i)
+        if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
+    for (int i = 0; i < 2; ++i)
+        COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "wgrad: channel count %d is not a multiple of %d", k.g.C[i], G);
+    if (k.Cout >= 64) return launch_wgrad_ng<T, 4>(k, ng, s);
+    if (k.Cout >= 32) return launch_wgrad_ng<T, 2>(k, ng, s);
+    return launch_wgrad_ng<T, 1>(k, ng, s);
+}
+
+int check_desc(const ColvoConvDesc* d, const char* who) {
+    COLVO_CHECK_ARG(d, "%s: null descriptor", who);
+    COLVO_CHECK_ARG(d->dtype == COLVO_F32 || d->dtype == COLVO_BF16, "%s: bad dtype %d", who, d->dtype);
+    COLVO_CHECK_ARG(d->ksize == 3, "%s: only 3x3 convolutions are on this path (got k=%d)", who, d->ksize);
+    COLVO_CHECK_ARG(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2", who);
+    COLVO_CHECK_ARG(d->B >= 1 && d->B <= 65535 && d->Hi >= 1 && d->Wi >= 1, "%s: bad shape", who);
+    COLVO_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
+                    "%s: output %dx%d does not match input %dx%d / stride %d", who, d->Ho, d->Wo, d->Hi, d->Wi, d->stride);
+    COLVO_CHECK_ARG(d->C0 >= 8 && d->C0 % 8 == 0 && d->C1 >= 0 && d->C1 % 8 == 0 && d->Cout >= 8 && d->Cout % 8 == 0,
+                    "%s: channel counts must be multiples of 8 (C0=%d C1=%d Cout=%d)", who, d->C0, d->C1, d->Cout);
+    COLVO_CHECK_ARG(!(d->up0 && ((d->Hi | d->Wi) & 1)) && !(d->up1 && ((d->Hi | d->Wi) & 1)),
+                    "%s: up-sampled sources need an even input size", who);
+    COLVO_CHECK_ARG(!((d->up0 || d->up1) && d->stride != 1), "%s: up-sampled sources need stride 1", who);
+    return 0;
+}
+
+void fill_gather(const ColvoConvDesc* d, const void* x0, const void* x1, Gather& g) {
+    g.src[0] = (const char*)x0; g.src[1] = (const char*)x1;
+    g.C[0] = d->C0; g.C[1] = x1 ? d->C1 : 0;
+    g.mode[0] = d->up0 ? MODE_UP2 : MODE_DIRECT;
+    g.mode[1] = d->up1 ? MODE_UP2 : MODE_DIRECT;
+    g.Hs[0] = d->up0 ? d->Hi / 2 : d->Hi; g.Ws[0] = d->up0 ? d->Wi / 2 : d->Wi;
+    g.Hs[1] = d->up1 ? d->Hi / 2 : d->Hi; g.Ws[1] = d->up1 ? d->Wi / 2 : d->Wi;
+    g.Hi = d->Hi; g.Wi = d->Wi; g.stride = d->stride;
+}
+
+}  // namespace
+}  // namespace colvo
+
+using namespace colvo;
+
+extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void* x1, const void* w_fwd,
+                              const float* bias, void* y, colvo_stream_t stream) {
+    if (int e = check_desc(d, "colvo_conv_fwd")) return e;
+    COLVO_CHECK_ARG(x0 && w_fwd && y && (d->C1 == 0 || x1), "colvo_conv_fwd: null pointer argument");
+    ConvK k{};
+    fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
+    k.Ho = d->Ho; k.Wo = d->Wo;
+    k.w = (const char*)w_fwd; k.Ctot = d->C0 + d->C1; k.N = d->Cout;
+    k.bias = bias; k.relu = d->relu; k.out = (char*)y; k.mask = nullptr; k.accumulate = 0; k.pool2 = 0;
+    const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
+    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
+                                 : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
+}
+
+extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy, const void* w_bwd,
+                                const void* relu_mask, void* dx, int accumulate, colvo_stream_t stream) {
+    if (int e = check_desc(d, "colvo_conv_dgrad")) return e;
+    COLVO_CHECK_ARG(dy && w_bwd && dx, "colvo_conv_dgrad: null pointer argument");
+    COLVO_CHECK_ARG(src == 0 || (src == 1 && d->C1 > 0), "colvo_conv_dgrad: bad source index %d", src);
+    const int es = d->dtype == COLVO_F32 ? 4 : 2;
+    const int Csrc = src == 0 ? d->C0 : d->C1;
+    const int coff = src == 0 ? 0 : d->C0;
+    const int up = src == 0 ? d->up0 : d->up1;
+    ConvK k{};
+    // the conv input is dy (Cout channels), dilated by zero insertion when the forward stride was 2
+    k.g.src[0] = (const char*)dy; k.g.src[1] = nullptr;
+    k.g.C[0] = d->Cout; k.g.C[1] = 0;
+    k.g.Hs[0] = d->Ho; k.g.Ws[0] = d->Wo; k.g.Hs[1] = k.g.Ws[1] = 0;
+    k.g.mode[0] = d->stride == 2 ? MODE_DILATE : MODE_DIRECT; k.g.mode[1] = MODE_DIRECT;
+    k.g.Hi = d->stride == 2 ? 2 * d->Ho : d->Ho;
+    k.g.Wi = d->stride == 2 ? 2 * d->Wo : d->Wo;
+    k.g.stride = 1;
+    k.Ho = d->Hi; k.Wo = d->Wi;                    // gradient w.r.t. the (virtual) forward input
+    k.w = (const char*)w_bwd + (size_t)coff * 9 * d->Cout * es; k.Ctot = d->Cout; k.N = Csrc;
+    k.bias = nullptr; k.relu = 0; k.out = (char*)dx; k.mask = (const char*)relu_mask;
+    k.accumulate = accumulate; k.pool2 = up;
+    const Tile t = pick_tile(d->Hi, d->Wi, 1, up != 0);
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (d->Wi + t.tow - 1) / t.tow; k.tiles_y = (d->Hi + t.toh - 1) / t.toh;
+    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
+                                 : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
+}
+
+extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
+                                float* db, colvo_stream_t stream) {
+    if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
+    COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
+    WgradK k{};
+    fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
+    k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
+    k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
+    const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
+    k.ntiles = d->B * k.tiles_x * k.tiles_y;
+    return d->dtype == COLVO_F32 ? launch_wgrad_t<float>(k, (hipStream_t)stream)
+                                 : launch_wgrad_t<bf16_t>(k, (hipStream_t)stream);
+}

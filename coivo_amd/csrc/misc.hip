@@ -1,0 +1,400 @@
+// misc.hip -- the memory-bound helpers around the conv stack:
+//   layout packing (NCHW fp32 planes <-> NHWC feature maps, weight operand layouts),
+//   the 1-channel DepthNet head (conv3x3 + sigmoid + disp->depth) and the PoseNet head
+//   (1x1 conv + spatial mean + pose/LCC scaling), ReLU backward, and Adam over the flat arena (a8).
+// Spec: oracle/colvo_spec.py (DepthNet.head / disp_to_depth, PoseNet.pred, ADAM_KW).
+#include "common.h"
+
+namespace colvo {
+namespace {
+
+constexpr int NT = 256;
+
+template <int ES> struct Elem;
+template <> struct Elem<4> {
+    static __device__ __forceinline__ float ld(const void* p, size_t i) { return reinterpret_cast<const float*>(p)[i]; }
+    static __device__ __forceinline__ void st(void* p, size_t i, float v) { reinterpret_cast<float*>(p)[i] = v; }
+};
+template <> struct Elem<2> {
+    static __device__ __forceinline__ float ld(const void* p, size_t i) { return bf2f(reinterpret_cast<const uint16_t*>(p)[i]); }
+    static __device__ __forceinline__ void st(void* p, size_t i, float v) { reinterpret_cast<uint16_t*>(p)[i] = f2bf(v); }
+};
+
+// ---------------------------------------------------------------- weights -------------------- //
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pack_weights(const float* __restrict__ w, int Cout, int kk, int Cin,
+                                                     void* __restrict__ w_fwd, void* __restrict__ w_bwd) {
+    const size_t n = (size_t)Cout * kk * Cin;
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % Cin);
+    const int t = (int)((i / Cin) % kk);
+    const int co = (int)(i / ((size_t)Cin * kk));
+    const float v = w[i];
+    if (w_fwd) Elem<ES>::st(w_fwd, i, v);
+    if (w_bwd) Elem<ES>::st(w_bwd, ((size_t)c * kk + (kk - 1 - t)) * Cout + co, v);   // taps flipped
+}
+
+// ---------------------------------------------------------------- NCHW <-> NHWC -------------- //
+struct Planes {
+    const float* p[4];
+    int c[4];
+    int n;
+};
+
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pack_nchw(Planes src, int HW, int Cpad, void* __restrict__ dst) {
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)HW) return;
+    int ch = 0;
+    const size_t o = ((size_t)b * HW + pix) * Cpad;
+    for (int s = 0; s < src.n; ++s)
+        for (int c = 0; c < src.c[s]; ++c, ++ch)
+            Elem<ES>::st(dst, o + ch, src.p[s][((size_t)b * src.c[s] + c) * HW + pix]);
+    for (; ch < Cpad; ++ch) Elem<ES>::st(dst, o + ch, 0.0f);
+}
+
+template <int ES>
+__global__ __launch_bounds__(NT) void k_unpack_nhwc(const void* __restrict__ src, int HW, int Cpad, int c_begin,
+                                                    int c_count, float* __restrict__ dst, int accumulate) {
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)HW) return;
+    for (int c = 0; c < c_count; ++c) {
+        const float v = Elem<ES>::ld(src, ((size_t)b * HW + pix) * Cpad + c_begin + c);
+        float* d = dst + ((size_t)b * c_count + c) * HW + pix;
+        *d = accumulate ? (*d + v) : v;
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(NT) void k_relu_bwd(const void* __restrict__ y, void* __restrict__ dy, size_t n) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    if (!(Elem<ES>::ld(y, i) > 0.0f)) Elem<ES>::st(dy, i, 0.0f);
+}
+
+// ---------------------------------------------------------------- DepthNet head -------------- //
+// pre = conv3x3(x; w[9][C]) + bias;  depth = 1 / (lo + (hi - lo) * sigmoid(pre))
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_fwd(const void* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, int H, int W, int C, float lo,
+                                                       float hi, float* __restrict__ depth) {
+    extern __shared__ float sw[];   // 9*C
+    for (int i = threadIdx.x; i < 9 * C; i += NT) sw[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)H * W) return;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    float acc = bias[0];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y2 = yy + ky - 1;
+        if (y2 < 0 || y2 >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x2 = xx + kx - 1;
+            if (x2 < 0 || x2 >= W) continue;
+            const size_t o = (((size_t)b * H + y2) * W + x2) * C;
+            const float* wt = sw + (ky * 3 + kx) * C;
+            for (int c = 0; c < C; ++c) acc += Elem<ES>::ld(x, o + c) * wt[c];
+        }
+    }
+    const float sig = 1.0f / (1.0f + expf(-acc));
+    depth[(size_t)b * H * W + pix] = 1.0f / (lo + (hi - lo) * sig);
+}
+
+// d(pre) from the saved depth:  sig = (1/depth - lo)/(hi-lo);  d depth/d pre = -(hi-lo) depth^2 sig (1-sig)
+__device__ __forceinline__ float head_dpre(float depth, float d_depth, float lo, float hi) {
+    const float k = hi - lo;
+    const float sig = (1.0f / depth - lo) / k;
+    return -d_depth * k * depth * depth * sig * (1.0f - sig);
+}
+
+__global__ __launch_bounds__(NT) void k_depth_head_dpre(const float* __restrict__ depth, const float* __restrict__ d_depth,
+                                                        size_t n, float lo, float hi, float* __restrict__ dpre) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) dpre[i] = head_dpre(depth[i], d_depth[i], lo, hi);
+}
+
+// dx[y,x,c] = (x[y,x,c] > 0) * sum_taps dpre[y-ky+1, x-kx+1] * w[ky,kx,c]
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_dgrad(const void* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ dpre, int H, int W, int C,
+                                                         void* __restrict__ dx) {
+    extern __shared__ float sw[];
+    for (int i = threadIdx.x; i < 9 * C; i += NT) sw[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)H * W) return;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    float g[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y2 = yy - ky + 1, x2 = xx - kx + 1;
+            g[ky * 3 + kx] = (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? dpre[((size_t)b * H + y2) * W + x2] : 0.0f;
+        }
+    const size_t o = ((size_t)b * H * W + pix) * C;
+    for (int c = 0; c < C; ++c) {
+        float v = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v += g[t] * sw[t * C + c];
+        Elem<ES>::st(dx, o + c, (Elem<ES>::ld(x, o + c) > 0.0f) ? v : 0.0f);
+    }
+}
+
+// dw[t][c] += sum_pix dpre[pix] * x[pix + tap][c];  db += sum dpre.   One (tap, c) pair per thread,
+// a strip of pixels per workgroup, partial sums by fp32 atomics.
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict__ x, const float* __restrict__ dpre,
+                                                         int H, int W, int C, int rows_per_block, float* __restrict__ dw,
+                                                         float* __restrict__ db) {
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
+    const int tid = threadIdx.x;
+    const int nk = 9 * C;
+    for (int k = tid; k < nk + 1; k += NT) {
+        float acc = 0.0f;
+        if (k < nk) {
+            const int t = k / C, c = k - t * C;
+            const int ky = t / 3, kx = t - 3 * ky;
+            for (int yy = y0; yy < y1; ++yy) {
+                const int y2 = yy + ky - 1;
+                if (y2 < 0 || y2 >= H) continue;
+                for (int xx = 0; xx < W; ++xx) {
+                    const int x2 = xx + kx - 1;
+                    if (x2 < 0 || x2 >= W) continue;
+                    acc += dpre[((size_t)b * H + yy) * W + xx] * Elem<ES>::ld(x, (((size_t)b * H + y2) * W + x2) * C + c);
+                }
+            }
+            atomicAdd(dw + k, acc);
+        } else {
+            for (int yy = y0; yy < y1; ++yy)
+                for (int xx = 0; xx < W; ++xx) acc += dpre[((size_t)b * H + yy) * W + xx];
+            atomicAdd(db, acc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- PoseNet head --------------- //
+// out[b][j] = s_j * (bias_j + mean_p sum_c x[b][p][c] w[j][c]) (+1 for j = 6);  s = pose_scale (j<6) | lcc_scale
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pose_head_fwd(const void* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, int HW, int C, float pose_scale,
+                                                      float lcc_scale, float* __restrict__ out) {
+    __shared__ float red[4][8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+    for (int c = tid; c < C; c += NT) {
+        float sx = 0.0f;
+        for (int p = 0; p < HW; ++p) sx += Elem<ES>::ld(x, ((size_t)b * HW + p) * C + c);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += sx * w[j * C + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = wave_sum(acc[j]);
+        if ((tid & 63) == 0) red[tid >> 6][j] = v;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const float pre = bias[tid] + ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)HW;
+        float o = (tid < 6 ? pose_scale : lcc_scale) * pre;
+        if (tid == 6) o += 1.0f;
+        out[b * 8 + tid] = o;
+    }
+}
+
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pose_head_bwd(const void* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ d_out, int HW, int C, float pose_scale,
+                                                      float lcc_scale, void* __restrict__ dx, float* __restrict__ dw,
+                                                      float* __restrict__ db) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float go[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) go[j] = d_out[b * 8 + j] * (j < 6 ? pose_scale : lcc_scale);
+    const float inv = 1.0f / (float)HW;
+    for (int c = tid; c < C; c += NT) {
+        float g = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g += go[j] * w[j * C + c];
+        g *= inv;
+        float sx = 0.0f;
+        for (int p = 0; p < HW; ++p) {
+            const size_t o = ((size_t)b * HW + p) * C + c;
+            const float xv = Elem<ES>::ld(x, o);
+            sx += xv;
+            Elem<ES>::st(dx, o, xv > 0.0f ? g : 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dw + j * C + c, go[j] * sx * inv);
+    }
+    if (tid < 8) atomicAdd(db + tid, go[tid]);
+}
+
+// ---------------------------------------------------------------- Adam ----------------------- //
+__global__ __launch_bounds__(NT) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                                             float gscale, const int32_t* __restrict__ step_count) {
+    const int t = step_count[0] + 1;
+    const float bc1 = 1.0f - powf(b1, (float)t);
+    const float bc2 = 1.0f - powf(b2, (float)t);
+    const float step_size = lr / bc1;
+    const float rs_bc2 = 1.0f / sqrtf(bc2);
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * rs_bc2 + eps));
+    }
+}
+
+__global__ void k_inc_step(int32_t* step_count) { step_count[0] += 1; }
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + NT - 1) / NT); }
+
+}  // namespace
+}  // namespace colvo
+
+using namespace colvo;
+
+#define DISPATCH_ES(dtype, CALL)                        \
+    do {                                                \
+        if ((dtype) == COLVO_F32) { constexpr int ES = 4; CALL; } \
+        else { constexpr int ES = 2; CALL; }            \
+    } while (0)
+
+extern "C" int colvo_pack_weights(int dtype, const float* w_master, int Cout, int kk, int Cin, void* w_fwd,
+                                  void* w_bwd, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(w_master && (w_fwd || w_bwd), "colvo_pack_weights: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pack_weights: bad dtype");
+    COLVO_CHECK_ARG(Cout > 0 && kk > 0 && Cin > 0, "colvo_pack_weights: bad shape");
+    const size_t n = (size_t)Cout * kk * Cin;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_weights<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream,
+                                          w_master, Cout, kk, Cin, w_fwd, w_bwd));
+    COLVO_CHECK_LAUNCH("k_pack_weights");
+    return 0;
+}
+
+extern "C" int colvo_pack_nchw(int dtype, const float* const* src, const int32_t* src_channels, int nsrc, int B, int H,
+                               int W, int Cpad, void* dst, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(src && src_channels && dst && nsrc >= 1 && nsrc <= 4, "colvo_pack_nchw: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pack_nchw: bad dtype");
+    Planes pl{};
+    int tot = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        COLVO_CHECK_ARG(src[i] && src_channels[i] > 0, "colvo_pack_nchw: null source %d", i);
+        pl.p[i] = src[i]; pl.c[i] = src_channels[i]; tot += src_channels[i];
+    }
+    pl.n = nsrc;
+    COLVO_CHECK_ARG(tot <= Cpad && Cpad % 8 == 0 && B >= 1 && B <= 65535, "colvo_pack_nchw: bad channel padding %d for %d", Cpad, tot);
+    const size_t HW = (size_t)H * W;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_nchw<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, pl,
+                                          (int)HW, Cpad, dst));
+    COLVO_CHECK_LAUNCH("k_pack_nchw");
+    return 0;
+}
+
+extern "C" int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H, int W, int Cpad, int c_begin,
+                                      int c_count, float* dst_nchw, int accumulate, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(dsrc && dst_nchw && c_begin >= 0 && c_count >= 1 && c_begin + c_count <= Cpad && B >= 1 && B <= 65535,
+                    "colvo_unpack_nhwc_grad: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_unpack_nhwc_grad: bad dtype");
+    const size_t HW = (size_t)H * W;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_unpack_nhwc<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, dsrc,
+                                          (int)HW, Cpad, c_begin, c_count, dst_nchw, accumulate));
+    COLVO_CHECK_LAUNCH("k_unpack_nhwc");
+    return 0;
+}
+
+extern "C" int colvo_relu_bwd_inplace(int dtype, const void* y, void* dy, size_t n, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(y && dy, "colvo_relu_bwd_inplace: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_relu_bwd_inplace: bad dtype");
+    if (n == 0) return 0;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_relu_bwd<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream, y, dy, n));
+    COLVO_CHECK_LAUNCH("k_relu_bwd");
+    return 0;
+}
+
+extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int H, int W,
+                                    int C, float min_depth, float max_depth, float* depth, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && bias && depth, "colvo_depth_head_fwd: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_fwd: bad dtype");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
+                    "colvo_depth_head_fwd: bad shape / range");
+    const size_t HW = (size_t)H * W;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float),
+                                          (hipStream_t)stream, x, w, bias, H, W, C, 1.0f / max_depth, 1.0f / min_depth, depth));
+    COLVO_CHECK_LAUNCH("k_depth_head_fwd");
+    return 0;
+}
+
+// scratch: B*H*W floats (the d(pre) plane), caller-provided.
+extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* depth, const float* d_depth,
+                                    int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
+                                    void* dx, float* dw, float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && depth && d_depth && scratch && dx && dw && db, "colvo_depth_head_bwd: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_bwd: bad dtype");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
+                    "colvo_depth_head_bwd: bad shape / range");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W, n = (size_t)B * HW;
+    const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
+    hipLaunchKernelGGL(k_depth_head_dpre, dim3(nblk(n)), dim3(NT), 0, s, depth, d_depth, n, lo, hi, scratch);
+    COLVO_CHECK_LAUNCH("k_depth_head_dpre");
+    const int rows = 4;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES>), dim3((H + rows - 1) / rows, B), dim3(NT), 0, s, x,
+                                          scratch, H, W, C, rows, dw, db));
+    COLVO_CHECK_LAUNCH("k_depth_head_wgrad");
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+                                          x, w, scratch, H, W, C, dx));
+    COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
+    return 0;
+}
+
+extern "C" int colvo_pose_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int HW, int C,
+                                   float pose_scale, float lcc_scale, float* out, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && bias && out && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_fwd: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_fwd: bad dtype");
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_fwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, bias, HW,
+                                          C, pose_scale, lcc_scale, out));
+    COLVO_CHECK_LAUNCH("k_pose_head_fwd");
+    return 0;
+}
+
+extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_out, int B, int HW, int C,
+                                   float pose_scale, float lcc_scale, void* dx, float* dw, float* db,
+                                   colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && d_out && dx && dw && db && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_bwd: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd: bad dtype");
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_out, HW,
+                                          C, pose_scale, lcc_scale, dx, dw, db));
+    COLVO_CHECK_LAUNCH("k_pose_head_bwd");
+    return 0;
+}
+
+extern "C" int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                               float beta1, float beta2, float eps, float grad_scale, int32_t* step_count,
+                               colvo_stream_t stream) {
+    COLVO_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_count, "colvo_adam_step: null pointer argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (n) {
+        unsigned blocks = nblk(n);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                           eps, grad_scale, step_count);
+        COLVO_CHECK_LAUNCH("k_adam");
+    }
+    hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
+    COLVO_CHECK_LAUNCH("k_inc_step");
+    return 0;
+}

@@ -1,0 +1,147 @@
+"""Op-level host wrappers over the C-ABI (include/colvo.h): tensors in, raw pointers + stream out.
+
+Feature maps are NHWC torch tensors (float32 or bfloat16); everything is enqueued on PyTorch's current
+stream.  No op here has a CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc
+
+MIN_DEPTH, MAX_DEPTH = 0.1, 10.0
+POSE_SCALE, LCC_SCALE = 0.01, 0.1
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return _lib.F32
+    if dtype == torch.bfloat16:
+        return _lib.BF16
+    raise TypeError(f"unsupported feature-map dtype {dtype}")
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("coivo_amd ops run on the GPU only; there is no CPU fallback")
+
+
+def conv_desc(dtype: torch.dtype, B: int, Hi: int, Wi: int, C0: int, Cout: int, *, stride: int = 1, relu: bool = True,
+              C1: int = 0, up0: bool = False, up1: bool = False) -> ConvDesc:
+    d = ConvDesc()
+    d.dtype = dt_code(dtype)
+    d.B, d.Hi, d.Wi = B, Hi, Wi
+    d.Ho, d.Wo = (Hi - 1) // stride + 1, (Wi - 1) // stride + 1
+    d.Cout, d.ksize, d.stride, d.relu = Cout, 3, stride, int(relu)
+    d.C0, d.up0, d.C1, d.up1 = C0, int(up0), C1, int(up1)
+    return d
+
+
+def conv_fwd(d: ConvDesc, x0, x1, w_fwd, bias, y) -> None:
+    _need_cuda(x0, x1, w_fwd, bias, y)
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_fwd(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(w_fwd), _lib.ptr(bias),
+                                  _lib.ptr(y), _lib.stream_ptr()), "colvo_conv_fwd")
+
+
+def conv_dgrad(d: ConvDesc, src: int, dy, w_bwd, relu_mask, dx, accumulate: bool) -> None:
+    _need_cuda(dy, w_bwd, relu_mask, dx)
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_dgrad(C.byref(d), src, _lib.ptr(dy), _lib.ptr(w_bwd), _lib.ptr(relu_mask),
+                                    _lib.ptr(dx), int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad")
+
+
+def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db) -> None:
+    _need_cuda(x0, x1, dy, dw, db)
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_wgrad(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw),
+                                    _lib.ptr(db), _lib.stream_ptr()), "colvo_conv_wgrad")
+
+
+def pack_weights(w_master: torch.Tensor, dtype: torch.dtype, w_fwd: Optional[torch.Tensor],
+                 w_bwd: Optional[torch.Tensor]) -> None:
+    """w_master fp32 [Cout, kk, Cin] -> w_fwd [Cout, kk, Cin], w_bwd [Cin, kk(flipped), Cout] in `dtype`."""
+    _need_cuda(w_master, w_fwd, w_bwd)
+    Cout, kk, Cin = w_master.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_pack_weights(dt_code(dtype), _lib.ptr(w_master), Cout, kk, Cin, _lib.ptr(w_fwd),
+                                      _lib.ptr(w_bwd), _lib.stream_ptr()), "colvo_pack_weights")
+
+
+def pack_nchw(srcs: Sequence[torch.Tensor], Cpad: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None
+              ) -> torch.Tensor:
+    """Concatenate NCHW fp32 tensors along channels into one NHWC feature map with Cpad channels."""
+    _need_cuda(*srcs)
+    B, _, H, W = srcs[0].shape
+    srcs = [s.contiguous() for s in srcs]
+    if out is None:
+        out = torch.empty(B, H, W, Cpad, device=srcs[0].device, dtype=dtype)
+    n = len(srcs)
+    ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int32 * n)(*[s.shape[1] for s in srcs])
+    lib = _lib.load()
+    _lib.check(lib.colvo_pack_nchw(dt_code(dtype), ptrs, chans, n, B, H, W, Cpad, _lib.ptr(out), _lib.stream_ptr()),
+               "colvo_pack_nchw")
+    return out
+
+
+def unpack_nhwc_grad(dsrc: torch.Tensor, c_begin: int, c_count: int, dst: torch.Tensor, accumulate: bool) -> None:
+    _need_cuda(dsrc, dst)
+    B, H, W, Cpad = dsrc.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_unpack_nhwc_grad(dt_code(dsrc.dtype), _lib.ptr(dsrc), B, H, W, Cpad, c_begin, c_count,
+                                          _lib.ptr(dst), int(accumulate), _lib.stream_ptr()), "colvo_unpack_nhwc_grad")
+
+
+def relu_bwd_inplace(y: torch.Tensor, dy: torch.Tensor) -> None:
+    _need_cuda(y, dy)
+    lib = _lib.load()
+    _lib.check(lib.colvo_relu_bwd_inplace(dt_code(y.dtype), _lib.ptr(y), _lib.ptr(dy), y.numel(), _lib.stream_ptr()),
+               "colvo_relu_bwd_inplace")
+
+
+def depth_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, depth: torch.Tensor) -> None:
+    _need_cuda(x, w, bias, depth)
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_depth_head_fwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), B, H, W, Cc,
+                                        MIN_DEPTH, MAX_DEPTH, _lib.ptr(depth), _lib.stream_ptr()), "colvo_depth_head_fwd")
+
+
+def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
+    _need_cuda(x, w, depth, d_depth, scratch, dx, dw, db)
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_depth_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(depth), _lib.ptr(d_depth),
+                                        B, H, W, Cc, MIN_DEPTH, MAX_DEPTH, _lib.ptr(scratch), _lib.ptr(dx), _lib.ptr(dw),
+                                        _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_bwd")
+
+
+def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> None:
+    _need_cuda(x, w, bias, out)
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_pose_head_fwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), B, H * W, Cc,
+                                       POSE_SCALE, LCC_SCALE, _lib.ptr(out), _lib.stream_ptr()), "colvo_pose_head_fwd")
+
+
+def pose_head_bwd(x, w, d_out, dx, dw, db) -> None:
+    _need_cuda(x, w, d_out, dx, dw, db)
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+    _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_out), B, H * W, Cc,
+                                       POSE_SCALE, LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
+                                       _lib.stream_ptr()), "colvo_pose_head_bwd")
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:
+    _need_cuda(param, grad, exp_avg, exp_avg_sq, step_count)
+    lib = _lib.load()
+    _lib.check(lib.colvo_adam_step(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                   param.numel(), lr, beta1, beta2, eps, grad_scale, _lib.ptr(step_count),
+                                   _lib.stream_ptr()), "colvo_adam_step")

@@ -124,11 +124,12 @@ int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H, int W, int
                            int c_begin, int c_count, float* dst_nchw, int accumulate, colvo_stream_t stream);
 
 /* DepthNet head: conv3x3 (C -> 1) + sigmoid + disp_to_depth, output NCHW fp32 [B,1,H,W]; and its
- * backward (d_depth -> dx NHWC [masked by x>0, the producer's ReLU], dw[9*C] += , db[1] +=). */
+ * backward (d_depth -> dx NHWC [masked by x>0, the producer's ReLU], dw[9*C] += , db[1] +=).
+ * scratch: B*H*W floats. */
 int colvo_depth_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int H, int W, int C,
                          float min_depth, float max_depth, float* depth, colvo_stream_t stream);
 int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* depth, const float* d_depth,
-                         int B, int H, int W, int C, float min_depth, float max_depth,
+                         int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
                          void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.

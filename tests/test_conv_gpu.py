@@ -1,0 +1,234 @@
+"""-m gpu unit parity of the conv-stack kernels (a1/a2) against torch CPU ops (F.conv2d autograd).
+
+f32 mode uses the exact-f32 MFMA and is held to fp32 round-off; bf16 mode is compared against the same
+torch computation on bf16-rounded operands with a bf16-sized tolerance.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):   # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _ref_conv(x0, x1, up0, up1, w_master, bias, stride, relu):
+    """x0/x1: NCHW fp32 (stored resolution), w_master [Cout, 9, Cin]."""
+    xs = []
+    for x, up in ((x0, up0), (x1, up1)):
+        if x is None:
+            continue
+        xs.append(F.interpolate(x, scale_factor=2, mode="nearest") if up else x)
+    x = torch.cat(xs, dim=1)
+    Cout, _, Cin = w_master.shape
+    w = w_master.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, bias, stride=stride, padding=1)
+    return F.relu(y) if relu else y
+
+
+CASES = [
+    # B, Hi, Wi, C0, C1, up0, up1, Cout, stride
+    (2, 16, 24, 32, 0, False, False, 64, 1),
+    (2, 16, 24, 32, 0, False, False, 32, 2),
+    (1, 13, 21, 8, 0, False, False, 16, 2),       # stem-like: Cin 8, odd size
+    (2, 16, 20, 64, 0, True, False, 32, 1),       # up-sampled source
+    (2, 16, 20, 32, 32, False, False, 32, 1),     # concat
+    (1, 8, 12, 16, 0, False, False, 16, 1),       # Cin = Cout = 16
+    (3, 8, 10, 128, 0, False, False, 128, 1),     # deep small image, 2 N tiles
+    (2, 5, 5, 64, 0, False, False, 64, 2),        # PoseNet tail sizes
+    (1, 32, 40, 16, 16, True, False, 16, 1),      # up + concat, narrow
+    (2, 9, 7, 24, 0, False, False, 40, 1),        # channel counts that are only multiples of 8
+]
+
+
+def _tols(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+def _close(got, ref, rtol, atol_scale, what):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    atol = atol_scale * max(ref.abs().max().item(), 1e-20)
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e} (atol {atol:.3e}), {int(bad.sum())} bad of {bad.numel()}"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd_dgrad_wgrad(case, dtype):
+    from coivo_amd import ops
+    B, Hi, Wi, C0, C1, up0, up1, Cout, stride = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    rt, at = _tols(dtype)
+
+    def rnd(*s):
+        t = torch.randn(*s, generator=g)
+        return t.to(dtype).float()      # values exactly representable in `dtype`
+
+    def stored(C, up):
+        return (B, C, Hi // 2, Wi // 2) if up else (B, C, Hi, Wi)
+
+    x0 = F.relu(rnd(*stored(C0, up0)))             # sources are ReLU outputs (>= 0, many exact zeros)
+    x1 = F.relu(rnd(*stored(C1, up1))) if C1 else None
+    Cin = C0 + C1
+    w = (rnd(Cout, 9, Cin) * (2.0 / (9 * Cin)) ** 0.5).to(dtype).float()
+    bias = torch.randn(Cout, generator=g) * 0.1
+
+    x0r = x0.clone().requires_grad_(True)
+    x1r = x1.clone().requires_grad_(True) if C1 else None
+    wr = w.clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    y_ref = _ref_conv(x0r, x1r, up0, up1, wr, br, stride, True)
+    dy = rnd(*y_ref.shape)
+    dpre = (dy * (y_ref > 0)).to(dtype).float()    # gradient w.r.t. the pre-activation, as the kernels expect
+    pre = _ref_conv(x0r, x1r, up0, up1, wr, br, stride, False)
+    pre.backward(dpre)
+
+    d = dev()
+    desc = ops.conv_desc(dtype, B, Hi, Wi, C0, Cout, stride=stride, relu=True, C1=C1, up0=up0, up1=up1)
+    x0d = _nhwc(x0).to(d, dtype)
+    x1d = _nhwc(x1).to(d, dtype) if C1 else None
+    wm = w.to(d)
+    w_fwd = torch.empty(Cout, 9, Cin, device=d, dtype=dtype)
+    w_bwd = torch.empty(Cin, 9, Cout, device=d, dtype=dtype)
+    ops.pack_weights(wm, dtype, w_fwd, w_bwd)
+    assert torch.equal(w_fwd.float().cpu(), w)
+    yd = torch.empty(B, desc.Ho, desc.Wo, Cout, device=d, dtype=dtype)
+    ops.conv_fwd(desc, x0d, x1d, w_fwd, bias.to(d), yd)
+    _close(_nchw(yd), y_ref, rt, at, "fwd")
+
+    dyd = _nhwc(dpre).to(d, dtype)
+    # dgrad of each source: plain, then with the producer's ReLU mask + accumulate on top of a base
+    for si, (xs, xr, Cs) in enumerate(((x0d, x0r, C0), (x1d, x1r, C1))):
+        if xs is None:
+            continue
+        dx = torch.full_like(xs, 7.0)
+        ops.conv_dgrad(desc, si, dyd, w_bwd, None, dx, False)
+        _close(_nchw(dx), xr.grad, rt, at, f"dgrad src{si}")
+        base = torch.randn(xs.shape, generator=g).to(dtype)
+        dx2 = base.to(d).clone()
+        ops.conv_dgrad(desc, si, dyd, w_bwd, xs, dx2, True)
+        ref2 = _nchw(base.float()) + xr.grad * (xr > 0)
+        _close(_nchw(dx2), ref2, rt, 2 * at, f"dgrad src{si} masked+accumulate")
+
+    dw = torch.zeros(Cout, 9, Cin, device=d)
+    db = torch.zeros(Cout, device=d)
+    ops.conv_wgrad(desc, x0d, x1d, dyd, dw, db)
+    _close(dw, wr.grad, rt * 5, at * 5, "wgrad")
+    _close(db, br.grad, rt * 5, at * 5, "bgrad")
+    # wgrad accumulates
+    ops.conv_wgrad(desc, x0d, x1d, dyd, dw, db)
+    _close(dw, 2 * wr.grad, rt * 5, at * 5, "wgrad accumulate")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_roundtrip_and_relu_bwd(dtype):
+    from coivo_amd import ops
+    d = dev()
+    a = torch.rand(2, 3, 6, 10)
+    b = torch.rand(2, 1, 6, 10)
+    p = ops.pack_nchw([a.to(d), b.to(d)], 8, dtype)
+    assert p.shape == (2, 6, 10, 8)
+    ref = torch.cat([a, b, torch.zeros(2, 4, 6, 10)], 1).to(dtype)
+    assert torch.equal(_nchw(p).cpu(), ref)
+    out = torch.full((2, 1, 6, 10), 5.0, device=d)
+    ops.unpack_nhwc_grad(p, 3, 1, out, False)
+    assert torch.equal(out.cpu(), b.to(dtype).float())
+    ops.unpack_nhwc_grad(p, 3, 1, out, True)
+    assert torch.allclose(out.cpu(), 2 * b.to(dtype).float())
+    y = torch.randn(1000).clamp(min=0).to(d, dtype)
+    dy = torch.randn(1000).to(d, dtype)
+    ref = dy.clone() * (y > 0)
+    ops.relu_bwd_inplace(y, dy)
+    assert torch.equal(dy, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_depth_head(dtype):
+    from coivo_amd import ops
+    from oracle import colvo_spec as S
+    B, H, W, Cc = 2, 12, 20, 16
+    g = torch.Generator().manual_seed(5)
+    x = F.relu(torch.randn(B, Cc, H, W, generator=g)).to(dtype).float()
+    w = torch.randn(1, 9, Cc, generator=g) * 0.2
+    bias = torch.tensor([0.1])
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    pre = F.conv2d(xr, wr.view(1, 3, 3, Cc).permute(0, 3, 1, 2), br, padding=1)
+    depth_ref = S.disp_to_depth(torch.sigmoid(pre))
+    dd = torch.randn(B, 1, H, W, generator=g)
+    depth_ref.backward(dd)
+    d = dev()
+    xd = _nhwc(x).to(d, dtype)
+    depth = torch.empty(B, 1, H, W, device=d)
+    ops.depth_head_fwd(xd, w.to(d), bias.to(d), depth)
+    tol = 1e-5 if dtype == torch.float32 else 1e-5
+    _close(depth, depth_ref, tol, tol, "depth head fwd")
+    dx = torch.empty_like(xd)
+    dw = torch.zeros(1, 9, Cc, device=d)
+    db = torch.zeros(1, device=d)
+    scratch = torch.empty(B * H * W, device=d)
+    ops.depth_head_bwd(xd, w.to(d), depth, dd.to(d), scratch, dx, dw, db)
+    rt = 1e-4 if dtype == torch.float32 else 2e-2
+    _close(_nchw(dx), xr.grad * (x > 0), rt, rt, "depth head dx")
+    _close(dw, wr.grad, 1e-4, 1e-4, "depth head dw")
+    _close(db, br.grad, 1e-4, 1e-4, "depth head db")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pose_head(dtype):
+    from coivo_amd import ops
+    from oracle import colvo_spec as S
+    B, H, W, Cc = 3, 2, 3, 256
+    g = torch.Generator().manual_seed(6)
+    x = F.relu(torch.randn(B, Cc, H, W, generator=g)).to(dtype).float()
+    w = torch.randn(8, 1, Cc, generator=g) * 0.1
+    bias = torch.randn(8, generator=g) * 0.1
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    o = F.conv2d(xr, wr.view(8, Cc, 1, 1), br).mean(dim=(2, 3))
+    out_ref = torch.cat([S.POSE_SCALE * o[:, :6], 1 + S.LCC_SCALE * o[:, 6:7], S.LCC_SCALE * o[:, 7:8]], 1)
+    do = torch.randn(B, 8, generator=g)
+    out_ref.backward(do)
+    d = dev()
+    xd = _nhwc(x).to(d, dtype)
+    out = torch.empty(B, 8, device=d)
+    ops.pose_head_fwd(xd, w.to(d), bias.to(d), out)
+    _close(out, out_ref, 1e-5, 1e-5, "pose head fwd")
+    dx = torch.empty_like(xd)
+    dw = torch.zeros(8, 1, Cc, device=d)
+    db = torch.zeros(8, device=d)
+    ops.pose_head_bwd(xd, w.to(d), do.to(d), dx, dw, db)
+    rt = 1e-4 if dtype == torch.float32 else 2e-2
+    _close(_nchw(dx), xr.grad * (x > 0), rt, rt, "pose head dx")
+    _close(dw, wr.grad, 1e-4, 1e-4, "pose head dw")
+    _close(db, br.grad, 1e-4, 1e-4, "pose head db")
+
+
+def test_adam_matches_torch():
+    from coivo_amd import ops
+    from oracle import colvo_spec as S
+    d = dev()
+    g = torch.Generator().manual_seed(7)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], **S.ADAM_KW)
+    p = p0.to(d)
+    m = torch.zeros(n, device=d)
+    v = torch.zeros(n, device=d)
+    step = torch.zeros(1, dtype=torch.int32, device=d)
+    for it in range(3):
+        gr = torch.randn(n, generator=g) * 10 ** (it - 1)
+        pr.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(d), m, v, step, lr=S.ADAM_KW["lr"], beta1=S.ADAM_KW["betas"][0],
+                      beta2=S.ADAM_KW["betas"][1], eps=S.ADAM_KW["eps"])
+    assert int(step.item()) == 3
+    assert torch.allclose(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
