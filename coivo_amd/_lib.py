@@ -66,7 +66,7 @@ def load() -> C.CDLL:
             continue
         fn.restype = res
         fn.argtypes = args
-    if missing and not os.environ.get("COLVO_PARTIAL_LIB"):  # bring-up switch, removed once all symbols exist
+    if missing:
         raise RuntimeError(f"{LIB_PATH} does not export {missing}: stale build? run `python -m coivo_amd.build --force`")
     v = lib.colvo_abi_version()
     if v != ABI_VERSION:

@@ -1,0 +1,375 @@
+"""HIP-backed DepthNet / PoseNet with the spec's nn.Module signatures and state_dict keys.
+
+Concept: /root/reference/README.md:5,7 (DCDP depth + pose networks, "multimodal fusion" coupling).
+The reference ships no code; the layer stack, names and shapes are the frozen spec's
+(oracle/colvo_spec.py DepthNet / PoseNet, oracle/SPEC.md §3), so `load_state_dict` works both ways.
+
+MI355X-first host design
+  * ParamArena: every parameter of a network is a strided view into ONE flat fp32 buffer (weights in
+    [Cout][kh][kw][Cin] memory order = the forward GEMM operand layout), gradients likewise in one flat
+    buffer -> one fused Adam launch, and data-parallel all-reduce runs in place on bucket slices.
+  * A whole network is ONE autograd node: forward enqueues its kernels back to back on the current
+    stream, backward walks the layers in reverse, writing weight gradients straight into the arena
+    and reporting each finished layer to an optional hook (gradient buckets for data parallel).
+  * Feature maps are NHWC in `compute_dtype` (torch.float32 = exact-f32 MFMA parity mode,
+    torch.bfloat16 = throughput mode, fp32 accumulation in both).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+ENC_CH = (32, 64, 128, 256, 512)
+DEC_CH = (16, 32, 64, 128, 256)
+POSE_CH = (16, 32, 64, 128, 256, 256, 256)
+
+
+class ConvParams(nn.Module):
+    """weight [Cout, Cin, k, k] (logical, OIHW like nn.Conv2d) + bias [Cout]; memory is arena-owned."""
+
+    def __init__(self, cin: int, cout: int, k: int, cin_pad: Optional[int] = None):
+        super().__init__()
+        self.cin, self.cout, self.k = cin, cout, k
+        self.cin_pad = cin_pad or cin
+        self.weight = nn.Parameter(torch.zeros(cout, k, k, cin).permute(0, 3, 1, 2))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        # filled by the arena
+        self.w_master: Optional[torch.Tensor] = None   # [Cout, k*k, cin_pad] fp32 view (arena)
+        self.g_master: Optional[torch.Tensor] = None
+        self.g_bias: Optional[torch.Tensor] = None
+        self.w_fwd: Optional[torch.Tensor] = None      # operand copies in compute dtype
+        self.w_bwd: Optional[torch.Tensor] = None
+        self.span: Tuple[int, int] = (0, 0)            # [begin, end) of this layer inside the arena
+
+
+class _ArenaModule(nn.Module):
+    """Base: owns the flat parameter / gradient arenas of its ConvParams children."""
+
+    def __init__(self, compute_dtype: torch.dtype):
+        super().__init__()
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = compute_dtype
+        self.flat_param: Optional[torch.Tensor] = None
+        self.flat_grad: Optional[torch.Tensor] = None
+        self._packed_version = None
+        self._manual_version = 0
+        self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
+
+    # ---- arena ------------------------------------------------------------------------------- #
+    def _layers(self) -> List[ConvParams]:
+        return [m for m in self.modules() if isinstance(m, ConvParams)]
+
+    def _build_arena(self, device) -> None:
+        layers = self._layers()
+        total = 0
+        for L in layers:
+            total += L.cout * L.k * L.k * L.cin_pad + L.cout
+            total = (total + 63) // 64 * 64         # keep every layer 256-byte aligned
+        flat = torch.zeros(total, device=device, dtype=torch.float32)
+        grad = torch.zeros(total, device=device, dtype=torch.float32)
+        off = 0
+        for L in layers:
+            nw = L.cout * L.k * L.k * L.cin_pad
+            begin = off
+            wv = flat[off:off + nw].view(L.cout, L.k, L.k, L.cin_pad)
+            gv = grad[off:off + nw].view(L.cout, L.k, L.k, L.cin_pad)
+            with torch.no_grad():
+                wv[..., :L.cin].copy_(L.weight.detach().permute(0, 2, 3, 1).to(device))
+            L.weight.data = wv[..., :L.cin].permute(0, 3, 1, 2)
+            L.weight.grad = None
+            L.w_master = flat[off:off + nw].view(L.cout, L.k * L.k, L.cin_pad)
+            L.g_master = grad[off:off + nw].view(L.cout, L.k * L.k, L.cin_pad)
+            L._gw_view = gv[..., :L.cin].permute(0, 3, 1, 2)
+            off += nw
+            with torch.no_grad():
+                flat[off:off + L.cout].copy_(L.bias.detach().to(device))
+            L.bias.data = flat[off:off + L.cout]
+            L.bias.grad = None
+            L.g_bias = grad[off:off + L.cout]
+            off += L.cout
+            off = (off + 63) // 64 * 64
+            L.span = (begin, off)
+            L.w_fwd = L.w_bwd = None
+        self.flat_param, self.flat_grad = flat, grad
+        self._packed_version = None
+
+    def _apply(self, fn, *a, **kw):   # .to() / .cuda(): rebuild the arena on the new device
+        super()._apply(fn, *a, **kw)
+        p = next(self.parameters())
+        self._build_arena(p.device)
+        return self
+
+    def attach_grads(self) -> None:
+        """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
+        layers = self._layers()
+        if any(L.weight.grad is None or L.bias.grad is None for L in layers):
+            self.flat_grad.zero_()
+            for L in layers:
+                L.weight.grad = L._gw_view
+                L.bias.grad = L.g_bias
+
+    def zero_grad(self, set_to_none: bool = False) -> None:   # arena semantics: grads stay attached
+        if self.flat_grad is not None:
+            self.flat_grad.zero_()
+            self.attach_grads()
+
+    def mark_params_changed(self) -> None:
+        self._manual_version += 1
+
+    def _prepare_weights(self) -> None:
+        """Refresh the operand-layout copies of the weights when the master changed."""
+        # in-place updates of the parameters (any optimizer, load_state_dict) bump their version counters
+        ver = (sum(p._version for p in self.parameters()), self._manual_version, self.compute_dtype)
+        if ver == self._packed_version:
+            return
+        dt = self.compute_dtype
+        for L in self._layers():
+            if L.k != 3 or L.cout == 1:
+                continue                               # heads read the fp32 master directly
+            if L.w_bwd is None or L.w_bwd.dtype != dt:
+                L.w_bwd = torch.empty(L.cin_pad, 9, L.cout, device=self.flat_param.device, dtype=dt)
+                L.w_fwd = L.w_master if dt == torch.float32 else torch.empty(
+                    L.cout, 9, L.cin_pad, device=self.flat_param.device, dtype=dt)
+            ops.pack_weights(L.w_master, dt, None if dt == torch.float32 else L.w_fwd, L.w_bwd)
+        self._packed_version = ver
+
+    def _layer_done(self, L: ConvParams) -> None:
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self, L.span[0], L.span[1])
+
+    def _trigger(self) -> torch.Tensor:
+        # a leaf that requires grad so that autograd schedules the network's backward node
+        t = getattr(self, "_trig", None)
+        if t is None or t.device != self.flat_param.device:
+            t = torch.zeros(1, device=self.flat_param.device, requires_grad=True)
+            self._trig = t
+        return t
+
+
+def _conv(x0, L: ConvParams, desc, x1=None):
+    y = torch.empty(desc.B, desc.Ho, desc.Wo, desc.Cout, device=x0.device, dtype=x0.dtype)
+    ops.conv_fwd(desc, x0, x1, L.w_fwd, L.bias.data, y)
+    return y
+
+
+class DepthNet(_ArenaModule):
+    """forward(img [B,3,H,W] fp32) -> depth [B,1,H,W] fp32 in (0.1, 10).  H, W multiples of 32."""
+
+    def __init__(self, compute_dtype: torch.dtype = torch.float32, device="cuda"):
+        super().__init__(compute_dtype)
+        cin = 3
+        for i, c in enumerate(ENC_CH, start=1):
+            setattr(self, f"enc{i}a", ConvParams(cin, c, 3, cin_pad=8 if cin == 3 else cin))
+            setattr(self, f"enc{i}b", ConvParams(c, c, 3))
+            cin = c
+        for i in range(5, 0, -1):
+            d = DEC_CH[i - 1]
+            setattr(self, f"up{i}", ConvParams(cin, d, 3))
+            skip = ENC_CH[i - 2] if i >= 2 else 0
+            setattr(self, f"iconv{i}", ConvParams(d + skip, d, 3))
+            cin = d
+        self.head = ConvParams(cin, 1, 3)
+        self._build_arena(torch.device(device))
+
+    def forward(self, img: torch.Tensor) -> torch.Tensor:
+        return _DepthNetFn.apply(self, img, self._trigger())
+
+    # ---- whole-network forward / backward ---------------------------------------------------- #
+    def _plan(self, B, H, W):
+        dt = self.compute_dtype
+        P = {}
+        h, w, cin = H, W, 8
+        for i, c in enumerate(ENC_CH, start=1):
+            P[f"enc{i}a"] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
+            h, w = h // 2, w // 2
+            P[f"enc{i}b"] = ops.conv_desc(dt, B, h, w, c, c)
+            cin = c
+        for i in range(5, 0, -1):
+            d = DEC_CH[i - 1]
+            h, w = h * 2, w * 2
+            P[f"up{i}"] = ops.conv_desc(dt, B, h, w, cin, d, up0=True)
+            skip = ENC_CH[i - 2] if i >= 2 else 0
+            P[f"iconv{i}"] = ops.conv_desc(dt, B, h, w, d, d, C1=skip)
+            cin = d
+        return P
+
+    def _forward_impl(self, img: torch.Tensor):
+        if img.dim() != 4 or img.shape[1] != 3:
+            raise ValueError(f"DepthNet: expected [B,3,H,W], got {tuple(img.shape)}")
+        B, _, H, W = img.shape
+        if H % 32 or W % 32:
+            raise ValueError("DepthNet: H and W must be multiples of 32")
+        if not img.is_cuda or img.dtype != torch.float32:
+            raise RuntimeError("DepthNet: expects a float32 CUDA tensor (no CPU fallback)")
+        self._prepare_weights()
+        P = self._plan(B, H, W)
+        A: Dict[str, torch.Tensor] = {}
+        x = ops.pack_nchw([img], 8, self.compute_dtype)
+        A["in"] = x
+        for i in range(1, 6):
+            x = _conv(x, getattr(self, f"enc{i}a"), P[f"enc{i}a"]); A[f"enc{i}a"] = x
+            x = _conv(x, getattr(self, f"enc{i}b"), P[f"enc{i}b"]); A[f"enc{i}b"] = x
+        for i in range(5, 0, -1):
+            x = _conv(x, getattr(self, f"up{i}"), P[f"up{i}"]); A[f"up{i}"] = x
+            x = _conv(x, getattr(self, f"iconv{i}"), P[f"iconv{i}"], A[f"enc{i - 1}b"] if i >= 2 else None)
+            A[f"iconv{i}"] = x
+        depth = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
+        ops.depth_head_fwd(x, self.head.w_master, self.head.bias.data, depth)
+        return depth, (A, P)
+
+    def _backward_impl(self, saved, depth: torch.Tensor, d_depth: torch.Tensor) -> None:
+        A, P = saved
+        self.attach_grads()
+        B, _, H, W = depth.shape
+        dev = depth.device
+
+        def wgrad(name, x0, x1, dy):
+            L = getattr(self, name)
+            ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias)
+            self._layer_done(L)
+
+        def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
+            L = getattr(self, name)
+            if dx is None:
+                dx = torch.empty_like(mask_like)
+            ops.conv_dgrad(P[name], src, dy, L.w_bwd, mask_like, dx, accumulate)
+            return dx
+
+        x1 = A["iconv1"]
+        g = torch.empty_like(x1)
+        scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
+        ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth.contiguous(), scratch, g, self.head.g_master,
+                           self.head.g_bias)
+        self._layer_done(self.head)
+        d_skip: Dict[int, torch.Tensor] = {}
+        for i in range(1, 6):                       # decoder, output side first
+            u = A[f"up{i}"]
+            skip = A[f"enc{i - 1}b"] if i >= 2 else None
+            wgrad(f"iconv{i}", u, skip, g)
+            d_u = dgrad(f"iconv{i}", 0, g, u)
+            if skip is not None:
+                d_skip[i - 1] = dgrad(f"iconv{i}", 1, g, skip)
+            below = A[f"iconv{i + 1}"] if i < 5 else A["enc5b"]
+            wgrad(f"up{i}", below, None, d_u)
+            g = dgrad(f"up{i}", 0, d_u, below)
+        for i in range(5, 0, -1):                   # encoder
+            a = A[f"enc{i}a"]
+            wgrad(f"enc{i}b", a, None, g)
+            g_a = dgrad(f"enc{i}b", 0, g, a)
+            src = A["in"] if i == 1 else A[f"enc{i - 1}b"]
+            wgrad(f"enc{i}a", src, None, g_a)
+            if i > 1:
+                g = dgrad(f"enc{i}a", 0, g_a, src, dx=d_skip[i - 1], accumulate=True)
+
+
+class _DepthNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: DepthNet, img, trigger):
+        depth, saved = net._forward_impl(img)
+        ctx.net, ctx.saved = net, saved
+        ctx.save_for_backward(depth)
+        return depth
+
+    @staticmethod
+    def backward(ctx, d_depth):
+        (depth,) = ctx.saved_tensors
+        ctx.net._backward_impl(ctx.saved, depth, d_depth)
+        ctx.saved = None
+        return None, None, None
+
+
+class PoseNet(_ArenaModule):
+    """forward(tgt, ref, tgt_depth=None, ref_depth=None) -> (pose [B,6], lcc_a [B,1], lcc_b [B,1])."""
+
+    def __init__(self, compute_dtype: torch.dtype = torch.float32, device="cuda"):
+        super().__init__(compute_dtype)
+        cin = 8
+        for i, c in enumerate(POSE_CH, start=1):
+            setattr(self, f"conv{i}", ConvParams(cin, c, 3))
+            cin = c
+        self.pred = ConvParams(cin, 8, 1)
+        self._build_arena(torch.device(device))
+
+    def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):
+        out = _PoseNetFn.apply(self, tgt, ref, tgt_depth, ref_depth, self._trigger())
+        return out[:, 0:6], out[:, 6:7], out[:, 7:8]
+
+    def _forward_impl(self, tgt, ref, d_t, d_r):
+        B, _, H, W = tgt.shape
+        for t in (tgt, ref):
+            if tuple(t.shape) != (B, 3, H, W) or not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("PoseNet: expects float32 CUDA images of equal shape [B,3,H,W] (no CPU fallback)")
+        if (d_t is None) != (d_r is None):
+            raise ValueError("PoseNet: pass both depth maps or neither")
+        for t in (d_t, d_r):
+            if t is not None and tuple(t.shape) != (B, 1, H, W):
+                raise ValueError("PoseNet: depth maps must be [B,1,H,W]")
+        self._prepare_weights()
+        dt = self.compute_dtype
+        srcs = [tgt, ref] + ([d_t.contiguous(), d_r.contiguous()] if d_t is not None else [])
+        x = ops.pack_nchw(srcs, 8, dt)
+        A = {"in": x}
+        P = {}
+        h, w, cin = H, W, 8
+        for i, c in enumerate(POSE_CH, start=1):
+            P[i] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
+            x = _conv(x, getattr(self, f"conv{i}"), P[i])
+            A[i] = x
+            h, w, cin = P[i].Ho, P[i].Wo, c
+        out = torch.empty(B, 8, device=tgt.device, dtype=torch.float32)
+        ops.pose_head_fwd(x, self.pred.w_master, self.pred.bias.data, out)
+        return out, (A, P, (B, H, W), d_t is not None)
+
+    def _backward_impl(self, saved, d_out):
+        A, P, (B, H, W), has_depth = saved
+        self.attach_grads()
+        x = A[7]
+        g = torch.empty_like(x)
+        ops.pose_head_bwd(x, self.pred.w_master, d_out.contiguous(), g, self.pred.g_master, self.pred.g_bias)
+        self._layer_done(self.pred)
+        for i in range(7, 0, -1):
+            L = getattr(self, f"conv{i}")
+            src = A["in"] if i == 1 else A[i - 1]
+            ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias)
+            self._layer_done(L)
+            if i > 1 or has_depth:
+                dx = torch.empty_like(src)
+                ops.conv_dgrad(P[i], 0, g, L.w_bwd, src if i > 1 else None, dx, False)
+                g = dx
+        if not has_depth:
+            return None, None
+        d_t = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)
+        d_r = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)
+        ops.unpack_nhwc_grad(g, 6, 1, d_t, False)
+        ops.unpack_nhwc_grad(g, 7, 1, d_r, False)
+        return d_t, d_r
+
+
+class _PoseNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: PoseNet, tgt, ref, d_t, d_r, trigger):
+        out, saved = net._forward_impl(tgt, ref, d_t, d_r)
+        ctx.net, ctx.saved = net, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_t, d_r = ctx.net._backward_impl(ctx.saved, d_out)
+        ctx.saved = None
+        return None, None, None, d_t, d_r, None
+
+
+def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85):
+    """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss."""
+    from .functional import photometric_loss
+    B = tgt.shape[0]
+    d = depth_net(torch.cat([tgt, ref], dim=0))
+    d_t, d_r = d[:B], d[B:]
+    pose, a, b = pose_net(tgt, ref, d_t, d_r)
+    loss = photometric_loss(tgt, ref, d_t, pose, K, a, b, ssim_weight=ssim_weight)
+    return loss, d_t, d_r, pose, a, b
