@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- training frame-pairs/sec of the ColVO DCDP+LCC step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full training step on one batch of synthetic frame pairs already resident in HBM:
+DepthNet (both frames) + PoseNet forward, fused warp/LCC/SSIM/L1 loss, backward through everything,
+gradient all-reduce (N > 1), Adam.  N = 1 runs BASELINE configs[1]: batch 8, 320x256, bf16 conv / fp32 loss.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+LOSS_BYTES_PER_PIXEL = 60.0    # fwd 28 (tgt 12 + ref 12 + depth 4) + bwd 32 (same + d_depth 4)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
+    ap.add_argument("--no-roofline-cfg2", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=16)
+    ap.add_argument("--grad-transport", choices=["f32", "bf16"], default="f32")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: the cgroup quota when there is one (the GPU box exposes all
+    host cores in the affinity mask but grants a 16-CPU share per GPU), else the affinity mask."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    if n > 64:          # no quota visible: do not oversubscribe a shared host
+        n = 16
+    return n
+
+
+def cpu_baseline(B, H, W, budget_s):
+    """The oracle's full train step (fp32, torch CPU) on this box's host cores: a bounded sample."""
+    from coivo_amd import synth
+    from oracle import colvo_spec as S
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    dn, pn = S.make_models(0)
+    opt = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), **S.ADAM_KW)
+    b = synth.make_batch(B, H, W, seed=1234)
+    t0 = time.perf_counter()
+    S.train_step(dn, pn, opt, b["tgt"], b["ref"], b["K"])          # warm-up (allocations, thread pool)
+    warm = time.perf_counter() - t0
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start) < max(budget_s - warm, 0.0) or not times:
+        t1 = time.perf_counter()
+        S.train_step(dn, pn, opt, b["tgt"], b["ref"], b["K"])
+        times.append(time.perf_counter() - t1)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (pure-torch fp32) full train step, B={B} {W}x{H}, 1 warm-up + {len(times)} timed steps, median"}
+
+
+def roofline_cfg2(dev):
+    """Fused warp/loss fwd+bwd alone at BASELINE configs[2] (B=32, 640x512): where SURVEY.md §8d reads the HBM roofline."""
+    from coivo_amd import functional as Fh
+    from coivo_amd import synth
+    B, H, W = 32, 512, 640
+    b = synth.make_batch(4, H, W, seed=77, device=dev)
+    rep = lambda t: t.repeat(B // 4, *([1] * (t.dim() - 1))).contiguous()
+    tgt, ref, K = rep(b["tgt"]), rep(b["ref"]), rep(b["K"])
+    depth = rep(b["gt_depth"]).requires_grad_(True)
+    pose = rep(b["gt_pose"]).requires_grad_(True)
+    a = rep(b["gt_a"]).requires_grad_(True)
+    bb = rep(b["gt_b"]).requires_grad_(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf, tb = [], []
+    for it in range(25):
+        ev[0].record()
+        loss = Fh.photometric_loss(tgt, ref, depth, pose, K, a, bb)
+        ev[1].record()
+        torch.autograd.grad(loss, [depth, pose, a, bb])
+        ev[2].record()
+        torch.cuda.synchronize()
+        if it >= 5:
+            tf.append(ev[0].elapsed_time(ev[1]))
+            tb.append(ev[1].elapsed_time(ev[2]))
+    tf.sort(); tb.sort()
+    f_ms, b_ms = tf[len(tf) // 2], tb[len(tb) // 2]
+    px = B * H * W
+    ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + b_ms) * 1e-3) / 1e9
+    return {"kernel": "k_warp_loss_fwd + k_warp_loss_bwd", "workload": f"B={B} {W}x{H} fp32, 1 warp direction",
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
+            "timing": "hip events around the op on its launch stream (includes the 1-block finalize kernels), median of 20"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from coivo_amd import functional as Fh
+    from coivo_amd import nn as hnn
+    from coivo_amd import synth
+    from coivo_amd.ddp import GradBuckets
+    from coivo_amd.optim import FusedAdam
+
+    B, H, W = args.batch_per_gpu, args.height, args.width
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dn, pn = hnn.DepthNet(compute_dtype=cdt, device=dev), hnn.PoseNet(compute_dtype=cdt, device=dev)
+    # random-init weights of the spec'd architecture, identical on every rank (same seed)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for net in (dn, pn):
+            for name, p in net.named_parameters():
+                if name.endswith("weight"):
+                    fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                    p.copy_((torch.randn(p.shape, generator=g) * (2.0 / fan_in) ** 0.5).to(dev))
+    opt = FusedAdam([dn, pn], lr=1e-4)
+    ddp = None
+    if world > 1:
+        ddp = GradBuckets([dn, pn], bucket_bytes=args.bucket_mb << 20,
+                          transport_dtype=torch.bfloat16 if args.grad_transport == "bf16" else None)
+        opt.grad_scale = ddp.grad_scale
+    batch = synth.make_batch(B, H, W, seed=1234 + rank, device=dev)
+    tgt, ref, K = batch["tgt"], batch["ref"], batch["K"]
+
+    ev_pool = []
+
+    def step(timed: bool):
+        opt.zero_grad()
+        d = dn(torch.cat([tgt, ref], dim=0))
+        d_t, d_r = d[:B], d[B:]
+        pose, a, b = pn(tgt, ref, d_t, d_r)
+        if timed:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            e[0].record()
+        loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
+        if timed:
+            e[1].record()
+            # time the fused backward in isolation: it is the first node autograd runs
+            loss_g = loss.grad_fn
+            hook_s = loss_g.register_prehook(lambda *_: e[2].record())
+            hook_e = loss_g.register_hook(lambda *_: e[3].record())
+        loss.backward()
+        if timed:
+            hook_s.remove(); hook_e.remove()
+            ev_pool.append(e)
+        if ddp is not None:
+            ddp.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        f_us = sorted(e[0].elapsed_time(e[1]) for e in ev_pool)
+        b_us = sorted(e[2].elapsed_time(e[3]) for e in ev_pool)
+        f_ms, b_ms = sum(f_us) / len(f_us), sum(b_us) / len(b_us)
+        px = B * H * W
+        ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + b_ms) * 1e-3) / 1e9
+        roof = {"kernel": "k_warp_loss_fwd + k_warp_loss_bwd (fused project/sample/LCC/SSIM/L1 and its backward)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
+                "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3,
+                "timing": "hip events on the launch stream inside the timed steps, mean over steps; "
+                          "latency-dominated at this size (SURVEY.md §8d) -- see roofline_cfg2"}
+        out = {"metric": "training frame-pairs/sec at 320x256", "value": value, "unit": "frame-pairs/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU {W}x{H} full DCDP+LCC train step "
+                                      f"(DepthNet x2 frames + PoseNet fwd/bwd, fused warp/LCC/SSIM/L1 loss fwd/bwd, Adam), "
+                                      f"{args.dtype} conv / fp32 loss",
+                          "global_batch": world * B, "height": H, "width": W,
+                          "parallelism": f"dp{world}", "grad_transport": args.grad_transport if world > 1 else None},
+               "final_loss": final_loss, "roofline": roof}
+        if not args.no_roofline_cfg2:
+            out["roofline_cfg2"] = roofline_cfg2(dev)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(B, H, W, args.cpu_seconds)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,11 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -m coivo_amd.build`). "
             "coivo_amd has no CPU or PyTorch fallback.")
+    # torch bundles its own HIP/HSA runtime (soname libamdhip64.so.7, same as /opt/rocm's).  It must be
+    # in the process BEFORE libcolvo.so so that our NEEDED entry binds to that copy: the kernels then share
+    # torch's HIP context and streams.  Loading /opt/rocm's runtime first puts two HSA runtimes in one
+    # process and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     missing = []
     for name, (res, args) in SIGNATURES.items():

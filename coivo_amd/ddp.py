@@ -1,0 +1,106 @@
+"""Data-parallel gradient exchange for the DCDP step (a9 of SURVEY.md §8): one process per GPU,
+bucketed all-reduce over RCCL/xGMI overlapped with the rest of backward.
+
+The reference has no distributed code; frame pairs are independent units, so the only
+exchange is the sum of parameter gradients.  Design for xGMI (point-to-point links, per-link bound):
+  * gradients already live in ONE flat fp32 arena per network (coivo_amd.nn), so a bucket is a slice:
+    no flatten / unflatten copies, the all-reduce runs in place;
+  * the networks report each finished layer (reverse arena order); as soon as the finished suffix of an
+    arena crosses a bucket boundary its all-reduce is issued asynchronously (RCCL orders it after the
+    kernels already enqueued on the compute stream) while backward keeps running;
+  * few, large buckets (default 16 MiB ~ 3 buckets for the 38 MB of gradients): each collective pays the
+    ring latency once and the last, non-overlappable one is the small encoder-stem slice;
+  * optional bf16 transport halves the bytes on the links (BASELINE configs[4]).
+`finish()` makes the compute stream wait for all of them; the 1/world_size average is folded into the
+fused Adam kernel (grad_scale) instead of a separate pass.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+class _ArenaState:
+    def __init__(self, module, bucket_elems: int):
+        self.module = module
+        n = module.flat_grad.numel()
+        # bucket boundaries measured from the END of the arena (backward finishes the tail first)
+        bounds = list(range(n, 0, -bucket_elems)) + [0]
+        self.bounds = bounds            # descending: n, n-b, n-2b, ..., 0
+        self.next = 1                   # index of the next boundary to cross
+        self.low = n                    # everything in [low, n) is final
+        self.calls = 0
+
+
+class GradBuckets:
+    """Bucketed, overlapped gradient all-reduce over the flat arenas of `modules`.
+
+    modules: objects with `.flat_grad` (1-D tensor) and a settable `.grad_ready_hook(module, begin, end)`
+    that they call once per finished layer, in reverse arena order, during backward.
+    """
+
+    def __init__(self, modules: Sequence, process_group=None, bucket_bytes: int = 16 << 20,
+                 transport_dtype: Optional[torch.dtype] = None):
+        if not dist.is_initialized():
+            raise RuntimeError("GradBuckets needs an initialised torch.distributed process group")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.transport_dtype = transport_dtype
+        self.states: List[_ArenaState] = []
+        self._pending = []
+        for m in modules:
+            st = _ArenaState(m, max(1, bucket_bytes // 4))
+            self.states.append(st)
+            m.grad_ready_hook = self._make_hook(st)
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    # ---- hook side ----------------------------------------------------------------------------- #
+    def _make_hook(self, st: _ArenaState):
+        def hook(module, begin: int, end: int) -> None:
+            st.calls += 1
+            if end == st.module.flat_grad.numel() and st.next > 1:
+                raise RuntimeError("GradBuckets: a network ran backward twice in one step after its buckets were "
+                                   "already reduced; batch the inputs into one forward (e.g. cat(tgt, ref))")
+            if end < st.low:            # not contiguous with the finished suffix: defer to finish()
+                return
+            st.low = min(st.low, begin)
+            while st.next < len(st.bounds) and st.low <= st.bounds[st.next]:
+                self._launch(st, st.bounds[st.next], st.bounds[st.next - 1])
+                st.next += 1
+        return hook
+
+    def _launch(self, st: _ArenaState, lo: int, hi: int) -> None:
+        if hi <= lo:
+            return
+        sl = st.module.flat_grad[lo:hi]
+        if self.transport_dtype is not None and self.transport_dtype != sl.dtype:
+            buf = sl.to(self.transport_dtype)
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, sl, buf))
+        else:
+            work = dist.all_reduce(sl, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((work, None, None))
+
+    # ---- step side ----------------------------------------------------------------------------- #
+    def finish(self) -> None:
+        """Issue whatever has not been reduced yet and wait (stream-wise) for every bucket."""
+        for st in self.states:
+            while st.next < len(st.bounds):     # layers that reported out of order / never reported
+                self._launch(st, st.bounds[st.next], st.bounds[st.next - 1])
+                st.next += 1
+        for work, sl, buf in self._pending:
+            work.wait()
+            if buf is not None:
+                sl.copy_(buf)
+        self._pending.clear()
+        for st in self.states:
+            st.next, st.low, st.calls = 1, st.module.flat_grad.numel(), 0
+
+    def detach(self) -> None:
+        for st in self.states:
+            st.module.grad_ready_hook = None
