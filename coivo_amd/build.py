@@ -20,7 +20,10 @@ LIB = os.path.join(LIBDIR, "libcolvo.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-DNDEBUG"]
+         "-fno-gpu-rdc", "-DNDEBUG",
+         # CDNA4 executes packed f32 (v_pk_*_f32) at the plain-op rate, so SLP packing only adds the
+         # v_mov pairs that feed it (measured: fused-loss fwd 112 -> 47 VGPRs, -21 % VALU without it)
+         "-fno-slp-vectorize"]
 
 
 def _deps():

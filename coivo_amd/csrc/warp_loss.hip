@@ -32,9 +32,10 @@ struct Geo {
     float r00, r01, r02, r10, r11, r12, r20, r21, r22;
     float tx, ty, tz;
     float fx, fy, cx, cy;
+    float ifx, ify;
     float a, b;
 };
-constexpr int GEO_N = 18;
+constexpr int GEO_N = 20;
 
 // Thread 0 evaluates the per-image rotation exactly in the oracle's operation order
 // (pose_vec2mat: R = Rz Ry Rx, no FMA contraction), everybody picks it up as wave-uniform scalars.
@@ -58,8 +59,9 @@ __device__ __forceinline__ void geo_compute(const float* pose, const float* K, c
     s[8] = cy * cx;
     s[9] = p[0]; s[10] = p[1]; s[11] = p[2];
     s[12] = k[0]; s[13] = k[4]; s[14] = k[2]; s[15] = k[5];
-    s[16] = la ? la[b] : 1.0f;
-    s[17] = lb ? lb[b] : 0.0f;
+    s[16] = 1.0f / k[0]; s[17] = 1.0f / k[4];
+    s[18] = la ? la[b] : 1.0f;
+    s[19] = lb ? lb[b] : 0.0f;
 }
 
 __device__ __forceinline__ Geo geo_load(const float* s) {
@@ -69,8 +71,16 @@ __device__ __forceinline__ Geo geo_load(const float* s) {
     g.r20 = uniform_f(s[6]); g.r21 = uniform_f(s[7]); g.r22 = uniform_f(s[8]);
     g.tx = uniform_f(s[9]); g.ty = uniform_f(s[10]); g.tz = uniform_f(s[11]);
     g.fx = uniform_f(s[12]); g.fy = uniform_f(s[13]); g.cx = uniform_f(s[14]); g.cy = uniform_f(s[15]);
-    g.a = uniform_f(s[16]); g.b = uniform_f(s[17]);
+    g.ifx = uniform_f(s[16]); g.ify = uniform_f(s[17]);
+    g.a = uniform_f(s[18]); g.b = uniform_f(s[19]);
     return g;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// reciprocal refined by one Newton step (~0.5 ulp): for the cancelling gradient sums
+__device__ __forceinline__ float nr_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
 // index of the pixel a (possibly padded / overhanging) coordinate refers to: 1-px reflection pad,
@@ -92,6 +102,25 @@ __device__ __forceinline__ float window_mult(int q, int p, int n) {
     return (float)c;
 }
 
+// One image's planes behind buffer descriptors: loads take a 32-bit per-lane byte offset plus a scalar
+// plane offset (no 64-bit VALU address arithmetic), and are bounds-checked by the hardware.
+struct Img {
+    __amdgpu_buffer_rsrc_t ref, tgt, dep;
+    int plane4;     // bytes per plane
+};
+__device__ __forceinline__ Img img_make(const float* tgt, const float* ref, const float* depth, int b, int H, int W) {
+    Img im;
+    const size_t plane = (size_t)H * W;
+    im.plane4 = (int)(plane * 4);
+    im.ref = __builtin_amdgcn_make_buffer_rsrc((void*)(ref + (size_t)b * 3 * plane), 0, 3 * im.plane4, 0x00020000);
+    im.tgt = __builtin_amdgcn_make_buffer_rsrc((void*)(tgt + (size_t)b * 3 * plane), 0, 3 * im.plane4, 0x00020000);
+    im.dep = __builtin_amdgcn_make_buffer_rsrc((void*)(depth + (size_t)b * plane), 0, im.plane4, 0x00020000);
+    return im;
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
 struct Proj {
     float x, y;        // sample position in ref (pixels)
     float Xh, Yh;      // K^-1 [u v 1] (x, y components)
@@ -99,62 +128,63 @@ struct Proj {
     bool valid;
 };
 
-// a3: back-project, rigid transform, project.  Same operation order as oracle project().
+// a3: back-project, rigid transform, project (oracle project(); reciprocal-multiply and FMA contraction
+// instead of its divisions: <= 2 ulp on x, y, which the fp32 tolerances absorb)
 __device__ __forceinline__ Proj project_px(const Geo& g, float d, int u, int v, int H, int W) {
-#pragma clang fp contract(off)
     Proj o;
-    o.Xh = ((float)u - g.cx) / g.fx;
-    o.Yh = ((float)v - g.cy) / g.fy;
-    const float X = o.Xh * d, Y = o.Yh * d, Z = d;
-    o.Px = g.r00 * X + g.r01 * Y + g.r02 * Z + g.tx;
-    o.Py = g.r10 * X + g.r11 * Y + g.r12 * Z + g.ty;
-    o.Pz = g.r20 * X + g.r21 * Y + g.r22 * Z + g.tz;
+    o.Xh = ((float)u - g.cx) * g.ifx;
+    o.Yh = ((float)v - g.cy) * g.ify;
+    const float X = o.Xh * d, Y = o.Yh * d;
+    o.Px = fmaf(g.r00, X, fmaf(g.r01, Y, fmaf(g.r02, d, g.tx)));
+    o.Py = fmaf(g.r10, X, fmaf(g.r11, Y, fmaf(g.r12, d, g.ty)));
+    o.Pz = fmaf(g.r20, X, fmaf(g.r21, Y, fmaf(g.r22, d, g.tz)));
     const bool front = o.Pz > Z_EPS;
-    const float pzs = front ? o.Pz : 1.0f;
-    o.x = g.fx * o.Px / pzs + g.cx;
-    o.y = g.fy * o.Py / pzs + g.cy;
+    const float rz = front ? fast_rcp(o.Pz) : 1.0f;
+    o.x = fmaf(g.fx * o.Px, rz, g.cx);
+    o.y = fmaf(g.fy * o.Py, rz, g.cy);
     o.valid = front && (o.x >= 0.0f) && (o.x <= (float)(W - 1)) && (o.y >= 0.0f) && (o.y <= (float)(H - 1));
     return o;
 }
 
 struct Taps {
-    int o00, o01, o10, o11;
+    int o00, o01, o10, o11;   // byte offsets inside a plane
     float wx, wy;
 };
 
+// only called for valid points: 0 <= x <= W-1, 0 <= y <= H-1
 __device__ __forceinline__ Taps make_taps(const Proj& p, int H, int W) {
     Taps t;
-    const float xs = fminf(fmaxf(p.x, 0.0f), (float)(W - 1));
-    const float ys = fminf(fmaxf(p.y, 0.0f), (float)(H - 1));
-    const float x0f = floorf(xs), y0f = floorf(ys);
-    t.wx = xs - x0f;
-    t.wy = ys - y0f;
+    const float x0f = floorf(p.x), y0f = floorf(p.y);
+    t.wx = p.x - x0f;
+    t.wy = p.y - y0f;
     const int x0 = (int)x0f, y0 = (int)y0f;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    t.o00 = y0 * W + x0; t.o01 = y0 * W + x1;
-    t.o10 = y1 * W + x0; t.o11 = y1 * W + x1;
+    const int dx = (x0 + 1 < W) ? 4 : 0;
+    const int dy = (y0 + 1 < H) ? 4 * W : 0;
+    t.o00 = (y0 * W + x0) * 4; t.o01 = t.o00 + dx;
+    t.o10 = t.o00 + dy; t.o11 = t.o10 + dx;
     return t;
 }
 
 // a4 + a5 for one pixel: J[c] = a * bilinear(ref_c) + b  (warp = 0 where invalid)
 template <bool WITH_GRAD>
-__device__ __forceinline__ void sample_px(const Geo& g, const float* __restrict__ refb, size_t plane,
-                                          const Proj& p, int H, int W, float J[3], float Wp[3],
-                                          float gx[3], float gy[3]) {
+__device__ __forceinline__ void sample_px(const Geo& g, const Img& im, const Proj& p, int H, int W, float J[3],
+                                          float Wp[3], float gx[3], float gy[3]) {
     if (p.valid) {
         const Taps t = make_taps(p, H, W);
+        const float ux = 1.0f - t.wx, uy = 1.0f - t.wy;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* r = refb + c * plane;
-            const float i00 = r[t.o00], i01 = r[t.o01], i10 = r[t.o10], i11 = r[t.o11];
-            const float top = i00 * (1.0f - t.wx) + i01 * t.wx;
-            const float bot = i10 * (1.0f - t.wx) + i11 * t.wx;
-            const float w = top * (1.0f - t.wy) + bot * t.wy;
+            const int so = c * im.plane4;
+            const float i00 = bload(im.ref, t.o00, so), i01 = bload(im.ref, t.o01, so);
+            const float i10 = bload(im.ref, t.o10, so), i11 = bload(im.ref, t.o11, so);
+            const float top = fmaf(i01, t.wx, i00 * ux);
+            const float bot = fmaf(i11, t.wx, i10 * ux);
+            const float w = fmaf(bot, t.wy, top * uy);
             Wp[c] = w;
-            J[c] = g.a * w + g.b;
+            J[c] = fmaf(g.a, w, g.b);
             if (WITH_GRAD) {
-                gx[c] = (1.0f - t.wy) * (i01 - i00) + t.wy * (i11 - i10);
-                gy[c] = (1.0f - t.wx) * (i10 - i00) + t.wx * (i11 - i01);
+                gx[c] = fmaf(t.wy, i11 - i10, uy * (i01 - i00));
+                gy[c] = fmaf(t.wx, i11 - i01, ux * (i10 - i00));
             }
         }
     } else {
@@ -167,22 +197,21 @@ __device__ __forceinline__ void sample_px(const Geo& g, const float* __restrict_
     }
 }
 
-// SSIM numerator/denominator pieces from the five window sums of one channel (x = target, y = J)
+// SSIM pieces from the five 3x3 window SUMS of one channel (x = target, y = J), everything scaled by
+// 81 = 9^2 so the means never have to be formed:  S = (A1 A2) / (B1 B2) is scale-free.
 struct SsimTerms {
-    float mx, my, A1, A2, B1, B2;
+    float sx, sy, A1, A2, B1, B2;
 };
+constexpr float C1_81 = 81.0f * SSIM_C1, C2_81 = 81.0f * SSIM_C2;
 __device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, float syy, float sxy) {
     SsimTerms s;
-    const float inv9 = 1.0f / 9.0f;
-    s.mx = sx * inv9;
-    s.my = sy * inv9;
-    const float vx = sxx * inv9 - s.mx * s.mx;
-    const float vy = syy * inv9 - s.my * s.my;
-    const float cxy = sxy * inv9 - s.mx * s.my;
-    s.A1 = 2.0f * s.mx * s.my + SSIM_C1;
-    s.A2 = 2.0f * cxy + SSIM_C2;
-    s.B1 = s.mx * s.mx + s.my * s.my + SSIM_C1;
-    s.B2 = vx + vy + SSIM_C2;
+    s.sx = sx; s.sy = sy;
+    const float pxy = sx * sy;
+    const float q = fmaf(sx, sx, sy * sy);
+    s.A1 = fmaf(2.0f, pxy, C1_81);                       // 81 (2 mx my + C1)
+    s.A2 = fmaf(18.0f, sxy, C2_81) - 2.0f * pxy;         // 81 (2 cov + C2)
+    s.B1 = q + C1_81;                                    // 81 (mx^2 + my^2 + C1)
+    s.B2 = fmaf(9.0f, sxx + syy, C2_81) - q;             // 81 (vx + vy + C2)
     return s;
 }
 
@@ -191,7 +220,7 @@ __device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, f
 // --------------------------------------------------------------------------------------------- //
 constexpr int FSW = TW + 2, FSH = TH + 2;   // slots incl. 1-px halo
 
-__global__ __launch_bounds__(NT) void k_warp_loss_fwd(
+__global__ __launch_bounds__(NT, 4) void k_warp_loss_fwd(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
     const float* __restrict__ lcc_b, int H, int W, float alpha, float* __restrict__ partials) {
@@ -207,10 +236,7 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd(
     __syncthreads();
     const Geo g = geo_load(s_geo);
 
-    const size_t plane = (size_t)H * W;
-    const float* tgtb = tgt + (size_t)b * 3 * plane;
-    const float* refb = ref + (size_t)b * 3 * plane;
-    const float* depb = depth + (size_t)b * plane;
+    const Img im = img_make(tgt, ref, depth, b, H, W);
 
     const int col = tid & 63, rg = tid >> 6;
     float maskv[4];
@@ -224,10 +250,10 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd(
         {
             // a slot overhanging the image is the reflection pad of the last row / column
             const int py = reflect_idx(gy_, H), px = reflect_idx(gx_, W);
-            const size_t o = (size_t)py * W + px;
-            const Proj p = project_px(g, depb[o], px, py, H, W);
-            sample_px<false>(g, refb, plane, p, H, W, J, Wp, dumx, dumy);
-            T[0] = tgtb[o]; T[1] = tgtb[plane + o]; T[2] = tgtb[2 * plane + o];
+            const int o4 = (py * W + px) * 4;
+            const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
+            sample_px<false>(g, im, p, H, W, J, Wp, dumx, dumy);
+            T[0] = bload(im.tgt, o4, 0); T[1] = bload(im.tgt, o4, im.plane4); T[2] = bload(im.tgt, o4, 2 * im.plane4);
             maskv[i] = (p.valid && gy_ < H && gx_ < W) ? 1.0f : 0.0f;
         }
 #pragma unroll
@@ -244,56 +270,48 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd(
         else if (tid < 2 * FSW + TH) { sy = 1 + (tid - 2 * FSW); sx = 0; }
         else { sy = 1 + (tid - 2 * FSW - TH); sx = FSW - 1; }
         const int py = reflect_idx(y0 + sy - 1, H), px = reflect_idx(x0 + sx - 1, W);
-        const size_t o = (size_t)py * W + px;
+        const int o4 = (py * W + px) * 4;
         float J[3], Wp[3], dumx[3], dumy[3];
-        const Proj p = project_px(g, depb[o], px, py, H, W);
-        sample_px<false>(g, refb, plane, p, H, W, J, Wp, dumx, dumy);
+        const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
+        sample_px<false>(g, im, p, H, W, J, Wp, dumx, dumy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             sJ[c][sy][sx] = J[c];
-            sT[c][sy][sx] = tgtb[c * plane + o];
+            sT[c][sy][sx] = bload(im.tgt, o4, c * im.plane4);
         }
     }
     __syncthreads();
 
-    // phase 2: sliding 3x3 window down the thread's 4 rows (6 slot rows), horizontal sums kept in
-    // registers for three consecutive slot rows.
-    float acc = 0.0f, cnt = 0.0f;
-    float hx[3][3], hy[3][3], hxx[3][3], hyy[3][3], hxy[3][3];  // [slot-row mod 3][channel]
-    float midJ[2][3], midT[2][3];                                // centre-column values of the last two rows
+    // phase 2: per channel, a sliding 3x3 window down the thread's 4 rows (6 slot rows); the
+    // horizontal sums of three consecutive slot rows stay in registers.
+    float m4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int sr = 4 * rg + j;
-        const int k = j % 3;
+    for (int c = 0; c < 3; ++c) {
+        float hx[3], hy[3], hxx[3], hyy[3], hxy[3], midd[2];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
+        for (int j = 0; j < 6; ++j) {
+            const int sr = 4 * rg + j;
+            const int k = j % 3;
             const float j0 = sJ[c][sr][col], j1 = sJ[c][sr][col + 1], j2 = sJ[c][sr][col + 2];
             const float t0 = sT[c][sr][col], t1 = sT[c][sr][col + 1], t2 = sT[c][sr][col + 2];
-            hx[k][c] = t0 + t1 + t2;
-            hy[k][c] = j0 + j1 + j2;
-            hxx[k][c] = t0 * t0 + t1 * t1 + t2 * t2;
-            hyy[k][c] = j0 * j0 + j1 * j1 + j2 * j2;
-            hxy[k][c] = t0 * j0 + t1 * j1 + t2 * j2;
-            midJ[j & 1][c] = j1;
-            midT[j & 1][c] = t1;
-        }
-        if (j >= 2) {
-            const int i = j - 2;  // output row 4*rg + i, its centre is slot row sr-1
-            float m = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const SsimTerms s = ssim_terms(hx[0][c] + hx[1][c] + hx[2][c], hy[0][c] + hy[1][c] + hy[2][c],
-                                               hxx[0][c] + hxx[1][c] + hxx[2][c], hyy[0][c] + hyy[1][c] + hyy[2][c],
-                                               hxy[0][c] + hxy[1][c] + hxy[2][c]);
-                const float S = (s.A1 * s.A2) / (s.B1 * s.B2);
+            hx[k] = t0 + t1 + t2;
+            hy[k] = j0 + j1 + j2;
+            hxx[k] = t0 * t0 + t1 * t1 + t2 * t2;
+            hyy[k] = j0 * j0 + j1 * j1 + j2 * j2;
+            hxy[k] = t0 * j0 + t1 * j1 + t2 * j2;
+            midd[j & 1] = fabsf(t1 - j1);
+            if (j >= 2) {
+                const SsimTerms s = ssim_terms(hx[0] + hx[1] + hx[2], hy[0] + hy[1] + hy[2], hxx[0] + hxx[1] + hxx[2],
+                                               hyy[0] + hyy[1] + hyy[2], hxy[0] + hxy[1] + hxy[2]);
+                const float S = (s.A1 * s.A2) * fast_rcp(s.B1 * s.B2);
                 const float ss = fminf(fmaxf(0.5f * (1.0f - S), 0.0f), 1.0f);
-                const float l1 = fabsf(midT[(j - 1) & 1][c] - midJ[(j - 1) & 1][c]);
-                m += alpha * ss + (1.0f - alpha) * l1;
+                m4[j - 2] += alpha * ss + (1.0f - alpha) * midd[(j - 1) & 1];   // centre = previous slot row
             }
-            acc += m * maskv[i];
-            cnt += maskv[i];
         }
     }
+    float acc = 0.0f, cnt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc += m4[i] * maskv[i]; cnt += maskv[i]; }
 
     acc = wave_sum(acc);
     cnt = wave_sum(cnt);
@@ -330,11 +348,16 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd_finalize(const float* __re
 // --------------------------------------------------------------------------------------------- //
 // backward                                                                                       //
 // --------------------------------------------------------------------------------------------- //
+// Per tile:  (1) J, T of tile + 2-px halo -> LDS;  per channel: (2) derivative coefficients of every
+// SSIM window (tile + 1-px halo) from sliding sums -> LDS, (3) every pixel gathers, with the reflection
+// multiplicities, from the 9 windows that contain it -> dJ in registers;  (4) the sample is RECOMPUTED
+// (taps are L1/L2 hits) to chain dJ through LCC, the bilinear taps and the projection.  Only dJ[4][3]
+// lives across the phases, which keeps the kernel at <= 128 VGPRs (2 workgroups per SIMD set).
 constexpr int BSW = TW + 4, BSH = TH + 4;   // J/T slots incl. 2-px halo
 constexpr int WSW = TW + 2, WSH = TH + 2;   // window centres incl. 1-px halo
 constexpr int NPART = 14;                   // dt[3], dR[9], da, db
 
-__global__ __launch_bounds__(NT) void k_warp_loss_bwd(
+__global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
     const float* __restrict__ lcc_b, int H, int W, float alpha, const float* __restrict__ loss_state,
@@ -344,7 +367,6 @@ __global__ __launch_bounds__(NT) void k_warp_loss_bwd(
     __shared__ float sM[WSH][WSW];       // validity mask of each window centre (0 outside the image)
     __shared__ float sK[3][WSH][WSW];    // per-window derivative coefficients of the current channel
     __shared__ float s_geo[GEO_N + 2];
-    __shared__ float s_red[4][NPART + 2];
 
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
@@ -354,66 +376,24 @@ __global__ __launch_bounds__(NT) void k_warp_loss_bwd(
     const Geo g = geo_load(s_geo);
     const float gscale = grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
 
+    const Img im = img_make(tgt, ref, depth, b, H, W);
     const size_t plane = (size_t)H * W;
-    const float* tgtb = tgt + (size_t)b * 3 * plane;
-    const float* refb = ref + (size_t)b * 3 * plane;
-    const float* depb = depth + (size_t)b * plane;
 
-    const int col = tid & 63, rg = tid >> 6;
-
-    // per owned pixel, kept in registers across the phases
-    float Wp[4][3], gx[4][3], gy[4][3], dJ[4][3];
-    Proj pj[4];
-    float dval[4];
-    bool inimg[4];
-
-    // phase 1a: owned pixels (slot = pixel + 2)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 4 * rg + i;
-        const int gy_ = y0 + row, gx_ = x0 + col;
-        float J[3], T[3];
-        inimg[i] = (gy_ < H && gx_ < W);
-        float m = 0.0f;
-        {
-            // a slot overhanging the image is the reflection pad of the last row / column: it holds
-            // the reflected pixel's J and T but owns no output (valid = false, dJ = 0)
-            const int py = reflect_idx(gy_, H), px = reflect_idx(gx_, W);
-            const size_t o = (size_t)py * W + px;
-            dval[i] = depb[o];
-            pj[i] = project_px(g, dval[i], px, py, H, W);
-            sample_px<true>(g, refb, plane, pj[i], H, W, J, Wp[i], gx[i], gy[i]);
-            T[0] = tgtb[o]; T[1] = tgtb[plane + o]; T[2] = tgtb[2 * plane + o];
-            if (!inimg[i]) pj[i].valid = false;
-            m = pj[i].valid ? 1.0f : 0.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dJ[i][c] = 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            sJ[c][row + 2][col + 2] = J[c];
-            sT[c][row + 2][col + 2] = T[c];
-        }
-        sM[row + 1][col + 1] = m;
-    }
-    // phase 1b: the 2-px ring: 2*BSW top + 2*BSW bottom + 4*TH sides = 336 slots
-    for (int r = tid; r < 4 * BSW + 4 * TH; r += NT) {
-        int sy, sx;
-        if (r < 2 * BSW) { sy = r / BSW; sx = r % BSW; }
-        else if (r < 4 * BSW) { const int q = r - 2 * BSW; sy = TH + 2 + q / BSW; sx = q % BSW; }
-        else { const int q = r - 4 * BSW; sy = 2 + (q >> 2); const int k = q & 3; sx = (k < 2) ? k : (TW + k); }
+    // phase 1: every slot of tile + 2-px halo (reflected where it leaves the image)
+#pragma unroll 1
+    for (int s = tid; s < BSH * BSW; s += NT) {
+        const int sy = s / BSW, sx = s - sy * BSW;
         const int uy = y0 + sy - 2, ux = x0 + sx - 2;   // unreflected coordinate
         const int py = reflect_idx(uy, H), px = reflect_idx(ux, W);
-        const size_t o = (size_t)py * W + px;
+        const int o4 = (py * W + px) * 4;
         float J[3], W3[3], dumx[3], dumy[3];
-        const Proj p = project_px(g, depb[o], px, py, H, W);
-        sample_px<false>(g, refb, plane, p, H, W, J, W3, dumx, dumy);
+        const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
+        sample_px<false>(g, im, p, H, W, J, W3, dumx, dumy);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             sJ[c][sy][sx] = J[c];
-            sT[c][sy][sx] = tgtb[c * plane + o];
+            sT[c][sy][sx] = bload(im.tgt, o4, c * im.plane4);
         }
-        // window-centre mask for ring slots that are window centres (inner ring of the 2-px halo)
         const int wy = sy - 1, wx = sx - 1;
         if (wy >= 0 && wy < WSH && wx >= 0 && wx < WSW) {
             const bool exists = (uy >= 0 && uy < H && ux >= 0 && ux < W);
@@ -422,7 +402,8 @@ __global__ __launch_bounds__(NT) void k_warp_loss_bwd(
     }
     __syncthreads();
 
-    // window weights of the owned pixels (reflection multiplicities), shared by the 3 channels
+    const int col = tid & 63, rg = tid >> 6;
+    // reflection multiplicities of the owned pixels (shared by the 3 channels)
     float wyv[4][3], wxv[3];
     {
         const int px = x0 + col;
@@ -442,111 +423,154 @@ __global__ __launch_bounds__(NT) void k_warp_loss_bwd(
         }
     }
 
-    const float kss = gscale * alpha * (-0.5f) * (1.0f / 9.0f);
+    const float kss = gscale * alpha * (-0.5f);
     const float kl1 = gscale * (1.0f - alpha);
+    // phase-2 role: 3 groups of 66 threads, each thread a column of 6 windows
+    const int wcol = tid % WSW, wgrp = tid / WSW;
 
-#pragma unroll   // fully unrolled: dJ[i][c] must stay in registers (static index)
+    float dJ[4][3];
+#pragma unroll 1   // rolled: keeps register pressure down; dJ is written through a uniform switch (static index)
     for (int c = 0; c < 3; ++c) {
-        // phase 2: derivative coefficients of every window centre (tile + 1-px halo)
-        for (int w = tid; w < WSH * WSW; w += NT) {
-            const int wy = w / WSW, wx = w - wy * WSW;
-            float A = 0.f, Bc = 0.f, Cc = 0.f;
-            const float m = sM[wy][wx];
-            if (m != 0.0f) {
-                float sx_ = 0.f, sy_ = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float t = sT[c][wy + dy][wx + dx], j = sJ[c][wy + dy][wx + dx];
-                        sx_ += t; sy_ += j; sxx += t * t; syy += j * j; sxy += t * j;
+        // phase 2: derivative coefficients of every window centre (tile + 1-px halo), sliding sums
+        if (wgrp < 3) {
+            float hx0 = 0.f, hx1 = 0.f, hy0 = 0.f, hy1 = 0.f, hxx0 = 0.f, hxx1 = 0.f, hyy0 = 0.f, hyy1 = 0.f,
+                  hxy0 = 0.f, hxy1 = 0.f;
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int sr = 6 * wgrp + j;
+                const float j0 = sJ[c][sr][wcol], j1 = sJ[c][sr][wcol + 1], j2 = sJ[c][sr][wcol + 2];
+                const float t0 = sT[c][sr][wcol], t1 = sT[c][sr][wcol + 1], t2 = sT[c][sr][wcol + 2];
+                const float hx2 = t0 + t1 + t2;
+                const float hy2 = j0 + j1 + j2;
+                const float hxx2 = t0 * t0 + t1 * t1 + t2 * t2;
+                const float hyy2 = j0 * j0 + j1 * j1 + j2 * j2;
+                const float hxy2 = t0 * j0 + t1 * j1 + t2 * j2;
+                if (j >= 2) {
+                    const int wy = sr - 2;
+                    float A = 0.f, Bc = 0.f, Cc = 0.f;
+                    if (sM[wy][wcol] != 0.0f) {
+                        const SsimTerms s = ssim_terms(hx0 + hx1 + hx2, hy0 + hy1 + hy2, hxx0 + hxx1 + hxx2,
+                                                       hyy0 + hyy1 + hyy2, hxy0 + hxy1 + hxy2);
+                        // refined reciprocal: d_a / d_b / d_pose are heavily cancelling sums of these terms
+                        const float inv = nr_rcp(s.B1 * s.B2);
+                        const float S = s.A1 * s.A2 * inv;
+                        const float ss = 0.5f * (1.0f - S);
+                        if (ss > 0.0f && ss < 1.0f) {
+                            // d S / d(sum J), d(sum J^2), d(sum T J) of the window
+                            const float dS_dsy = 2.0f * (s.sx * (s.A2 - s.A1) - S * s.sy * (s.B2 - s.B1)) * inv;
+                            A = kss * dS_dsy;
+                            Bc = kss * -18.0f * S * (inv * s.B1);
+                            Cc = kss * 18.0f * s.A1 * inv;
+                        }
                     }
-                const SsimTerms s = ssim_terms(sx_, sy_, sxx, syy, sxy);
-                const float inv = 1.0f / (s.B1 * s.B2);
-                const float S = s.A1 * s.A2 * inv;
-                const float ss = 0.5f * (1.0f - S);
-                if (ss > 0.0f && ss < 1.0f) {
-                    const float dS_dmy = (2.0f * s.mx * (s.A2 - s.A1) - S * 2.0f * s.my * (s.B2 - s.B1)) * inv;
-                    const float dS_deyy = -S / s.B2;
-                    const float dS_dexy = 2.0f * s.A1 * inv;
-                    A = kss * dS_dmy;
-                    Bc = kss * 2.0f * dS_deyy;
-                    Cc = kss * dS_dexy;
+                    sK[0][wy][wcol] = A; sK[1][wy][wcol] = Bc; sK[2][wy][wcol] = Cc;
                 }
+                hx0 = hx1; hx1 = hx2; hy0 = hy1; hy1 = hy2; hxx0 = hxx1; hxx1 = hxx2;
+                hyy0 = hyy1; hyy1 = hyy2; hxy0 = hxy1; hxy1 = hxy2;
             }
-            sK[0][wy][wx] = A; sK[1][wy][wx] = Bc; sK[2][wy][wx] = Cc;
         }
         __syncthreads();
-        // phase 3: every owned pixel gathers from the 9 windows that contain it
+        // phase 3: every owned pixel gathers from the 9 windows that contain it (rows 4rg..4rg+5 of
+        // the window grid serve the thread's 4 pixels): horizontal weighted sums first, then vertical
+        {
+            float ha[6], hb[6], hc[6], v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * rg + i;
-            float sa = 0.f, sb = 0.f, sc = 0.f;
+            for (int j = 0; j < 6; ++j) {
+                const int wr = 4 * rg + j;
+                ha[j] = wxv[0] * sK[0][wr][col] + wxv[1] * sK[0][wr][col + 1] + wxv[2] * sK[0][wr][col + 2];
+                hb[j] = wxv[0] * sK[1][wr][col] + wxv[1] * sK[1][wr][col + 1] + wxv[2] * sK[1][wr][col + 2];
+                hc[j] = wxv[0] * sK[2][wr][col] + wxv[1] * sK[2][wr][col + 1] + wxv[2] * sK[2][wr][col + 2];
+            }
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int i = 0; i < 4; ++i) {
+                const int row = 4 * rg + i;
+                const float sa = wyv[i][0] * ha[i] + wyv[i][1] * ha[i + 1] + wyv[i][2] * ha[i + 2];
+                const float sb = wyv[i][0] * hb[i] + wyv[i][1] * hb[i + 1] + wyv[i][2] * hb[i + 2];
+                const float sc = wyv[i][0] * hc[i] + wyv[i][1] * hc[i + 1] + wyv[i][2] * hc[i + 2];
+                const float j = sJ[c][row + 2][col + 2], t = sT[c][row + 2][col + 2];
+                const float diff = j - t;
+                const float sgn = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
+                v[i] = sa + sb * j + sc * t + kl1 * sM[row + 1][col + 1] * sgn;
+            }
+            if (c == 0) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float w = wyv[i][dy] * wxv[dx];
-                    sa += w * sK[0][row + dy][col + dx];
-                    sb += w * sK[1][row + dy][col + dx];
-                    sc += w * sK[2][row + dy][col + dx];
-                }
-            const float j = sJ[c][row + 2][col + 2], t = sT[c][row + 2][col + 2];
-            const float diff = j - t;
-            const float sgn = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
-            const float v = sa + sb * j + sc * t + kl1 * sM[row + 1][col + 1] * sgn;
-            dJ[i][c] = inimg[i] ? v : 0.0f;
+                for (int i = 0; i < 4; ++i) dJ[i][0] = v[i];
+            } else if (c == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dJ[i][1] = v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dJ[i][2] = v[i];
+            }
         }
         __syncthreads();
     }
 
-    // phase 4: chain rule through LCC, the bilinear sample and the projection
+    // phase 4: recompute the sample and chain through LCC, the bilinear taps and the projection
     float part[NPART];
 #pragma unroll
     for (int k = 0; k < NPART; ++k) part[k] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gy_ = y0 + 4 * rg + i, gx_ = x0 + col;
+        if (gy_ >= H || gx_ >= W) continue;          // overhanging slot: owns no output
+        const size_t o = (size_t)gy_ * W + gx_;
+        const float dval = bload(im.dep, (int)o * 4, 0);
+        const Proj p = project_px(g, dval, gx_, gy_, H, W);
+        float J[3], Wp[3], gx[3], gy[3];
+        sample_px<true>(g, im, p, H, W, J, Wp, gx, gy);
         float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            da += dJ[i][c] * Wp[i][c];
+            da += dJ[i][c] * Wp[c];
             db += dJ[i][c];
             const float dW = g.a * dJ[i][c];
-            gxs += dW * gx[i][c];
-            gys += dW * gy[i][c];
+            gxs += dW * gx[c];
+            gys += dW * gy[c];
         }
         part[12] += da;
         part[13] += db;
         float dd = 0.0f;
-        if (pj[i].valid) {
-            const Proj& p = pj[i];
-            const float iz = 1.0f / p.Pz;
+        if (p.valid) {
+            const float iz = nr_rcp(p.Pz);
             const float dPx = gxs * g.fx * iz;
             const float dPy = gys * g.fy * iz;
-            const float dPz = -(gxs * g.fx * p.Px + gys * g.fy * p.Py) * iz * iz;
+            const float dPz = -(dPx * p.Px + dPy * p.Py) * iz;
             // P = R (d * [Xh Yh 1]) + t
             const float rx_ = g.r00 * p.Xh + g.r01 * p.Yh + g.r02;
             const float ry_ = g.r10 * p.Xh + g.r11 * p.Yh + g.r12;
             const float rz_ = g.r20 * p.Xh + g.r21 * p.Yh + g.r22;
             dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
-            const float cX = p.Xh * dval[i], cY = p.Yh * dval[i], cZ = dval[i];
+            const float cX = p.Xh * dval, cY = p.Yh * dval, cZ = dval;
             part[0] += dPx; part[1] += dPy; part[2] += dPz;
             part[3] += dPx * cX; part[4] += dPx * cY; part[5] += dPx * cZ;
             part[6] += dPy * cX; part[7] += dPy * cY; part[8] += dPy * cZ;
             part[9] += dPz * cX; part[10] += dPz * cY; part[11] += dPz * cZ;
         }
-        if (inimg[i]) d_depth[(size_t)b * plane + (size_t)gy_ * W + gx_] = dd;
+        d_depth[(size_t)b * plane + o] = dd;
     }
+    // block reduction of the 14 partial sums through LDS (the staging arrays are free now): two fixed-order
+    // stages instead of 14 x 6 cross-lane shuffles per thread
+    float* sRed = &sJ[0][0][0];          // [NPART][NT]
+    float* sRed2 = &sT[0][0][0];         // [NPART][16]
 #pragma unroll
-    for (int k = 0; k < NPART; ++k) {
-        const float v = wave_sum(part[k]);
-        if ((tid & 63) == 0) s_red[tid >> 6][k] = v;
+    for (int k = 0; k < NPART; ++k) sRed[k * NT + tid] = part[k];
+    __syncthreads();
+    if (tid < NPART * 16) {
+        const int k = tid >> 4, seg = tid & 15;
+        const float* r = sRed + k * NT + seg * 16;
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += r[i];
+        sRed2[tid] = a;
     }
     __syncthreads();
     if (tid < NPART) {
+        float a = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += sRed2[tid * 16 + i];
         const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partials[blk * NPART + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+        partials[blk * NPART + tid] = a;
     }
 }
 
@@ -615,9 +639,9 @@ __global__ __launch_bounds__(NT) void k_inverse_warp(const float* __restrict__ r
     if (p.valid) {
         const Taps t = make_taps(p, H, W);
         for (int c = 0; c < C; ++c) {
-            const float* r = refb + c * plane;
-            const float top = r[t.o00] * (1.0f - t.wx) + r[t.o01] * t.wx;
-            const float bot = r[t.o10] * (1.0f - t.wx) + r[t.o11] * t.wx;
+            const char* r = reinterpret_cast<const char*>(refb + c * plane);
+            const float top = *reinterpret_cast<const float*>(r + t.o00) * (1.0f - t.wx) + *reinterpret_cast<const float*>(r + t.o01) * t.wx;
+            const float bot = *reinterpret_cast<const float*>(r + t.o10) * (1.0f - t.wx) + *reinterpret_cast<const float*>(r + t.o11) * t.wx;
             wb[c * plane + o] = top * (1.0f - t.wy) + bot * t.wy;
         }
     } else {
