@@ -16,6 +16,8 @@
 // 3x3 SSIM statistics then come from LDS with a sliding window (forward) or per window centre
 // (backward).  HBM reads are row-contiguous per plane (lanes = consecutive columns); the 4-tap
 // gather of `ref` is served by L1/L2 for smooth flows.
+#include <type_traits>
+
 #include "common.h"
 
 namespace colvo {
@@ -197,6 +199,121 @@ __device__ __forceinline__ void sample_px(const Geo& g, const Img& im, const Pro
     }
 }
 
+// Branch-free variant for batched evaluation: invalid points read tap (0,0) with zero weights.
+__device__ __forceinline__ Taps make_taps_safe(const Proj& p, int H, int W) {
+    Taps t;
+    const float xs = p.valid ? p.x : 0.0f, ys = p.valid ? p.y : 0.0f;
+    const float x0f = floorf(xs), y0f = floorf(ys);
+    t.wx = xs - x0f;
+    t.wy = ys - y0f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int dx = (x0 + 1 < W) ? 4 : 0;
+    const int dy = (y0 + 1 < H) ? 4 * W : 0;
+    t.o00 = (y0 * W + x0) * 4; t.o01 = t.o00 + dx;
+    t.o10 = t.o00 + dy; t.o11 = t.o10 + dx;
+    return t;
+}
+
+// Evaluate N slots with every global load of the batch in flight together: depth + target first (they
+// depend on nothing), then all 12 N reference taps, then the blends.  No branches, so the compiler keeps
+// it one basic block and the two dependent memory round trips are paid once per batch, not once per slot.
+template <int N, bool WITH_GRAD>
+__device__ __forceinline__ void eval_batch(const Geo& g, const Img& im, const int (&px)[N], const int (&py)[N], int H,
+                                           int W, Proj (&p)[N], float (&dv)[N], float (&J)[N][3], float (&T)[N][3],
+                                           float (&Wp)[N][3], float (&gx)[N][3], float (&gy)[N][3]) {
+    int o4[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        o4[n] = (py[n] * W + px[n]) * 4;
+        dv[n] = bload(im.dep, o4[n], 0);
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[n][c] = bload(im.tgt, o4[n], c * im.plane4);
+    Taps t[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        p[n] = project_px(g, dv[n], px[n], py[n], H, W);
+        t[n] = make_taps_safe(p[n], H, W);
+    }
+    float v[N][3][4];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int so = c * im.plane4;
+            v[n][c][0] = bload(im.ref, t[n].o00, so); v[n][c][1] = bload(im.ref, t[n].o01, so);
+            v[n][c][2] = bload(im.ref, t[n].o10, so); v[n][c][3] = bload(im.ref, t[n].o11, so);
+        }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float m = p[n].valid ? 1.0f : 0.0f;
+        const float ux = 1.0f - t[n].wx, uy = 1.0f - t[n].wy;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float i00 = v[n][c][0], i01 = v[n][c][1], i10 = v[n][c][2], i11 = v[n][c][3];
+            const float top = fmaf(i01, t[n].wx, i00 * ux);
+            const float bot = fmaf(i11, t[n].wx, i10 * ux);
+            const float w = m * fmaf(bot, t[n].wy, top * uy);
+            Wp[n][c] = w;
+            J[n][c] = fmaf(g.a, w, g.b);
+            if (WITH_GRAD) {
+                gx[n][c] = m * fmaf(t[n].wy, i11 - i10, uy * (i01 - i00));
+                gy[n][c] = m * fmaf(t[n].wx, i11 - i01, ux * (i10 - i00));
+            }
+        }
+    }
+}
+
+// The same evaluation split into its three dependency stages, so that a persistent kernel can keep the
+// loads of the NEXT tile in flight while it computes on the current one.
+template <int N>
+struct Batch {
+    float dv[N];
+    float T[N][3];
+    float wx[N], wy[N], m[N];
+    float v[N][3][4];
+};
+template <int N>   // stage A: depth + target loads (depend on nothing)
+__device__ __forceinline__ void batch_issue_dt(const Img& im, const int (&px)[N], const int (&py)[N], int W, Batch<N>& B) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) B.dv[n] = bload(im.dep, (py[n] * W + px[n]) * 4, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) B.T[n][c] = bload(im.tgt, (py[n] * W + px[n]) * 4, c * im.plane4);
+}
+template <int N>   // stage B: project (needs depth) and issue the 12 N reference taps
+__device__ __forceinline__ void batch_issue_taps(const Geo& g, const Img& im, const int (&px)[N], const int (&py)[N],
+                                                 int H, int W, Batch<N>& B) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const Proj p = project_px(g, B.dv[n], px[n], py[n], H, W);
+        const Taps t = make_taps_safe(p, H, W);
+        B.wx[n] = t.wx; B.wy[n] = t.wy; B.m[n] = p.valid ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int so = c * im.plane4;
+            B.v[n][c][0] = bload(im.ref, t.o00, so); B.v[n][c][1] = bload(im.ref, t.o01, so);
+            B.v[n][c][2] = bload(im.ref, t.o10, so); B.v[n][c][3] = bload(im.ref, t.o11, so);
+        }
+    }
+}
+template <int N>   // stage C: blend + LCC
+__device__ __forceinline__ void batch_blend(const Geo& g, const Batch<N>& B, float (&J)[N][3]) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float ux = 1.0f - B.wx[n], uy = 1.0f - B.wy[n];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = fmaf(B.v[n][c][1], B.wx[n], B.v[n][c][0] * ux);
+            const float bot = fmaf(B.v[n][c][3], B.wx[n], B.v[n][c][2] * ux);
+            J[n][c] = fmaf(g.a, B.m[n] * fmaf(bot, B.wy[n], top * uy), g.b);
+        }
+    }
+}
+
 // SSIM pieces from the five 3x3 window SUMS of one channel (x = target, y = J), everything scaled by
 // 81 = 9^2 so the means never have to be formed:  S = (A1 A2) / (B1 B2) is scale-free.
 struct SsimTerms {
@@ -220,10 +337,13 @@ __device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, f
 // --------------------------------------------------------------------------------------------- //
 constexpr int FSW = TW + 2, FSH = TH + 2;   // slots incl. 1-px halo
 
+// Persistent over a strip of tiles of ONE image (grid = strips x 1 x B): the masked loss sum is carried in
+// registers across the strip and reduced once per workgroup (one partial per strip, fixed order).
 __global__ __launch_bounds__(NT, 4) void k_warp_loss_fwd(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
-    const float* __restrict__ lcc_b, int H, int W, float alpha, float* __restrict__ partials) {
+    const float* __restrict__ lcc_b, int H, int W, int tiles_x, int tiles_y, float alpha,
+    float* __restrict__ partials) {
     __shared__ float sJ[3][FSH][FSW];
     __shared__ float sT[3][FSH][FSW];
     __shared__ float s_geo[GEO_N + 2];
@@ -231,94 +351,101 @@ __global__ __launch_bounds__(NT, 4) void k_warp_loss_fwd(
 
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int ntiles = tiles_x * tiles_y;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
     if (tid == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo);
     __syncthreads();
     const Geo g = geo_load(s_geo);
-
     const Img im = img_make(tgt, ref, depth, b, H, W);
 
     const int col = tid & 63, rg = tid >> 6;
-    float maskv[4];
+    // slots of this thread inside a tile: 4 owned + one of the 1-px ring (first 164 threads)
+    int rsy = 4 * rg + 1, rsx = col + 1;      // dummy = first owned slot for threads >= 164
+    if (tid < FSW) { rsy = 0; rsx = tid; }
+    else if (tid < 2 * FSW) { rsy = FSH - 1; rsx = tid - FSW; }
+    else if (tid < 2 * FSW + TH) { rsy = 1 + (tid - 2 * FSW); rsx = 0; }
+    else if (tid < 2 * FSW + 2 * TH) { rsy = 1 + (tid - 2 * FSW - TH); rsx = FSW - 1; }
 
-    // phase 1a: the 4 pixels this thread owns
+    float acc = 0.0f, cnt = 0.0f;
+#pragma unroll 1
+    for (int t = t0; t < t1; ++t) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int x0 = tx * TW, y0 = ty * TH;
+        float maskv[4];
+        // phase 1: evaluate the slots (loads batched); slots that leave the image hold the reflected pixel
+        auto phase1 = [&](auto nslots) {
+            constexpr int N = decltype(nslots)::value;
+            int px[N], py[N], ssy[N], ssx[N];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 4 * rg + i;
-        const int gy_ = y0 + row, gx_ = x0 + col;
-        float J[3], T[3], Wp[3], dumx[3], dumy[3];
-        {
-            // a slot overhanging the image is the reflection pad of the last row / column
-            const int py = reflect_idx(gy_, H), px = reflect_idx(gx_, W);
-            const int o4 = (py * W + px) * 4;
-            const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
-            sample_px<false>(g, im, p, H, W, J, Wp, dumx, dumy);
-            T[0] = bload(im.tgt, o4, 0); T[1] = bload(im.tgt, o4, im.plane4); T[2] = bload(im.tgt, o4, 2 * im.plane4);
-            maskv[i] = (p.valid && gy_ < H && gx_ < W) ? 1.0f : 0.0f;
-        }
+            for (int n = 0; n < N; ++n) {
+                ssy[n] = (n < 4) ? 4 * rg + n + 1 : rsy;
+                ssx[n] = (n < 4) ? col + 1 : rsx;
+                py[n] = reflect_idx(y0 + ssy[n] - 1, H);
+                px[n] = reflect_idx(x0 + ssx[n] - 1, W);
+            }
+            Proj p[N];
+            float dv[N], J[N][3], T[N][3], Wp[N][3], dumx[N][3], dumy[N][3];
+            eval_batch<N, false>(g, im, px, py, H, W, p, dv, J, T, Wp, dumx, dumy);
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                if (n < 4) maskv[n] = (p[n].valid && (y0 + ssy[n] - 1) < H && (x0 + ssx[n] - 1) < W) ? 1.0f : 0.0f;
+                if (n < 4 || tid < 2 * FSW + 2 * TH) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        sJ[c][ssy[n]][ssx[n]] = J[n][c];
+                        sT[c][ssy[n]][ssx[n]] = T[n][c];
+                    }
+                }
+            }
+        };
+        if (tid < 192) phase1(std::integral_constant<int, 5>{});   // waves 0..2 carry the ring (wave-uniform)
+        else phase1(std::integral_constant<int, 4>{});
+        __syncthreads();
+
+        // phase 2: per channel, the 6 slot rows x 3 columns this thread's 4 output rows need are read from LDS
+        // up front (one latency per channel), then the sliding 3x3 sums run from registers.
+        float m4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            sJ[c][row + 1][col + 1] = J[c];
-            sT[c][row + 1][col + 1] = T[c];
-        }
-    }
-    // phase 1b: the 1-px ring (reflected where it leaves the image)
-    if (tid < 2 * FSW + 2 * TH) {
-        int sy, sx;
-        if (tid < FSW) { sy = 0; sx = tid; }
-        else if (tid < 2 * FSW) { sy = FSH - 1; sx = tid - FSW; }
-        else if (tid < 2 * FSW + TH) { sy = 1 + (tid - 2 * FSW); sx = 0; }
-        else { sy = 1 + (tid - 2 * FSW - TH); sx = FSW - 1; }
-        const int py = reflect_idx(y0 + sy - 1, H), px = reflect_idx(x0 + sx - 1, W);
-        const int o4 = (py * W + px) * 4;
-        float J[3], Wp[3], dumx[3], dumy[3];
-        const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
-        sample_px<false>(g, im, p, H, W, J, Wp, dumx, dumy);
+            float jv[6][3], tv[6][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            sJ[c][sy][sx] = J[c];
-            sT[c][sy][sx] = bload(im.tgt, o4, c * im.plane4);
-        }
-    }
-    __syncthreads();
-
-    // phase 2: per channel, a sliding 3x3 window down the thread's 4 rows (6 slot rows); the
-    // horizontal sums of three consecutive slot rows stay in registers.
-    float m4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 6; ++j)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float hx[3], hy[3], hxx[3], hyy[3], hxy[3], midd[2];
+                for (int k = 0; k < 3; ++k) {
+                    jv[j][k] = sJ[c][4 * rg + j][col + k];
+                    tv[j][k] = sT[c][4 * rg + j][col + k];
+                }
+            float hx[6], hy[6], hxx[6], hyy[6], hxy[6];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int sr = 4 * rg + j;
-            const int k = j % 3;
-            const float j0 = sJ[c][sr][col], j1 = sJ[c][sr][col + 1], j2 = sJ[c][sr][col + 2];
-            const float t0 = sT[c][sr][col], t1 = sT[c][sr][col + 1], t2 = sT[c][sr][col + 2];
-            hx[k] = t0 + t1 + t2;
-            hy[k] = j0 + j1 + j2;
-            hxx[k] = t0 * t0 + t1 * t1 + t2 * t2;
-            hyy[k] = j0 * j0 + j1 * j1 + j2 * j2;
-            hxy[k] = t0 * j0 + t1 * j1 + t2 * j2;
-            midd[j & 1] = fabsf(t1 - j1);
-            if (j >= 2) {
-                const SsimTerms s = ssim_terms(hx[0] + hx[1] + hx[2], hy[0] + hy[1] + hy[2], hxx[0] + hxx[1] + hxx[2],
-                                               hyy[0] + hyy[1] + hyy[2], hxy[0] + hxy[1] + hxy[2]);
+            for (int j = 0; j < 6; ++j) {
+                hx[j] = tv[j][0] + tv[j][1] + tv[j][2];
+                hy[j] = jv[j][0] + jv[j][1] + jv[j][2];
+                hxx[j] = fmaf(tv[j][0], tv[j][0], fmaf(tv[j][1], tv[j][1], tv[j][2] * tv[j][2]));
+                hyy[j] = fmaf(jv[j][0], jv[j][0], fmaf(jv[j][1], jv[j][1], jv[j][2] * jv[j][2]));
+                hxy[j] = fmaf(tv[j][0], jv[j][0], fmaf(tv[j][1], jv[j][1], tv[j][2] * jv[j][2]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const SsimTerms s = ssim_terms(hx[i] + hx[i + 1] + hx[i + 2], hy[i] + hy[i + 1] + hy[i + 2],
+                                               hxx[i] + hxx[i + 1] + hxx[i + 2], hyy[i] + hyy[i + 1] + hyy[i + 2],
+                                               hxy[i] + hxy[i + 1] + hxy[i + 2]);
                 const float S = (s.A1 * s.A2) * fast_rcp(s.B1 * s.B2);
                 const float ss = fminf(fmaxf(0.5f * (1.0f - S), 0.0f), 1.0f);
-                m4[j - 2] += alpha * ss + (1.0f - alpha) * midd[(j - 1) & 1];   // centre = previous slot row
+                m4[i] += alpha * ss + (1.0f - alpha) * fabsf(tv[i + 1][1] - jv[i + 1][1]);
             }
         }
-    }
-    float acc = 0.0f, cnt = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc += m4[i] * maskv[i]; cnt += maskv[i]; }
+        for (int i = 0; i < 4; ++i) { acc = fmaf(m4[i], maskv[i], acc); cnt += maskv[i]; }
+        __syncthreads();     // LDS is rewritten by the next tile
+    }
 
     acc = wave_sum(acc);
     cnt = wave_sum(cnt);
     if ((tid & 63) == 0) { s_red[2 * (tid >> 6)] = acc; s_red[2 * (tid >> 6) + 1] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
         partials[2 * blk] = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
         partials[2 * blk + 1] = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
     }
@@ -379,25 +506,34 @@ __global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
     const Img im = img_make(tgt, ref, depth, b, H, W);
     const size_t plane = (size_t)H * W;
 
-    // phase 1: every slot of tile + 2-px halo (reflected where it leaves the image)
+    // phase 1: every slot of tile + 2-px halo (reflected where it leaves the image): 1360 slots, each thread
+    // takes 2 batches of 3 (loads of a batch in flight together); slot ids beyond the end are clamped and
+    // simply rewrite the last slot with the same values.
 #pragma unroll 1
-    for (int s = tid; s < BSH * BSW; s += NT) {
-        const int sy = s / BSW, sx = s - sy * BSW;
-        const int uy = y0 + sy - 2, ux = x0 + sx - 2;   // unreflected coordinate
-        const int py = reflect_idx(uy, H), px = reflect_idx(ux, W);
-        const int o4 = (py * W + px) * 4;
-        float J[3], W3[3], dumx[3], dumy[3];
-        const Proj p = project_px(g, bload(im.dep, o4, 0), px, py, H, W);
-        sample_px<false>(g, im, p, H, W, J, W3, dumx, dumy);
+    for (int it = 0; it < 2; ++it) {
+        int px[3], py[3], ssy[3], ssx[3], uy[3], ux[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            sJ[c][sy][sx] = J[c];
-            sT[c][sy][sx] = bload(im.tgt, o4, c * im.plane4);
+        for (int n = 0; n < 3; ++n) {
+            const int sl = min((it * 3 + n) * NT + tid, BSH * BSW - 1);
+            ssy[n] = sl / BSW; ssx[n] = sl - ssy[n] * BSW;
+            uy[n] = y0 + ssy[n] - 2; ux[n] = x0 + ssx[n] - 2;      // unreflected coordinate
+            py[n] = reflect_idx(uy[n], H); px[n] = reflect_idx(ux[n], W);
         }
-        const int wy = sy - 1, wx = sx - 1;
-        if (wy >= 0 && wy < WSH && wx >= 0 && wx < WSW) {
-            const bool exists = (uy >= 0 && uy < H && ux >= 0 && ux < W);
-            sM[wy][wx] = (exists && p.valid) ? 1.0f : 0.0f;
+        Proj p[3];
+        float dv[3], J[3][3], T[3][3], W3[3][3], dumx[3][3], dumy[3][3];
+        eval_batch<3, false>(g, im, px, py, H, W, p, dv, J, T, W3, dumx, dumy);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sJ[c][ssy[n]][ssx[n]] = J[n][c];
+                sT[c][ssy[n]][ssx[n]] = T[n][c];
+            }
+            const int wy = ssy[n] - 1, wx = ssx[n] - 1;
+            if (wy >= 0 && wy < WSH && wx >= 0 && wx < WSW) {
+                const bool exists = (uy[n] >= 0 && uy[n] < H && ux[n] >= 0 && ux[n] < W);
+                sM[wy][wx] = (exists && p[n].valid) ? 1.0f : 0.0f;
+            }
         }
     }
     __syncthreads();
@@ -510,44 +646,51 @@ __global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
     float part[NPART];
 #pragma unroll
     for (int k = 0; k < NPART; ++k) part[k] = 0.0f;
+    {
+        int px[4], py[4];
+        bool own[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gy_ = y0 + 4 * rg + i, gx_ = x0 + col;
-        if (gy_ >= H || gx_ >= W) continue;          // overhanging slot: owns no output
-        const size_t o = (size_t)gy_ * W + gx_;
-        const float dval = bload(im.dep, (int)o * 4, 0);
-        const Proj p = project_px(g, dval, gx_, gy_, H, W);
-        float J[3], Wp[3], gx[3], gy[3];
-        sample_px<true>(g, im, p, H, W, J, Wp, gx, gy);
-        float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int gy_ = y0 + 4 * rg + i, gx_ = x0 + col;
+            own[i] = (gy_ < H && gx_ < W);            // overhanging slots own no output
+            py[i] = min(gy_, H - 1); px[i] = min(gx_, W - 1);
+        }
+        Proj p[4];
+        float dval[4], J[4][3], T[4][3], Wp[4][3], gx[4][3], gy[4][3];
+        eval_batch<4, true>(g, im, px, py, H, W, p, dval, J, T, Wp, gx, gy);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            da += dJ[i][c] * Wp[c];
-            db += dJ[i][c];
-            const float dW = g.a * dJ[i][c];
-            gxs += dW * gx[c];
-            gys += dW * gy[c];
+        for (int i = 0; i < 4; ++i) {
+            if (!own[i]) continue;
+            float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                da += dJ[i][c] * Wp[i][c];
+                db += dJ[i][c];
+                const float dW = g.a * dJ[i][c];
+                gxs += dW * gx[i][c];
+                gys += dW * gy[i][c];
+            }
+            part[12] += da;
+            part[13] += db;
+            float dd = 0.0f;
+            if (p[i].valid) {
+                const float iz = nr_rcp(p[i].Pz);
+                const float dPx = gxs * g.fx * iz;
+                const float dPy = gys * g.fy * iz;
+                const float dPz = -(dPx * p[i].Px + dPy * p[i].Py) * iz;
+                // P = R (d * [Xh Yh 1]) + t
+                const float rx_ = g.r00 * p[i].Xh + g.r01 * p[i].Yh + g.r02;
+                const float ry_ = g.r10 * p[i].Xh + g.r11 * p[i].Yh + g.r12;
+                const float rz_ = g.r20 * p[i].Xh + g.r21 * p[i].Yh + g.r22;
+                dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
+                const float cX = p[i].Xh * dval[i], cY = p[i].Yh * dval[i], cZ = dval[i];
+                part[0] += dPx; part[1] += dPy; part[2] += dPz;
+                part[3] += dPx * cX; part[4] += dPx * cY; part[5] += dPx * cZ;
+                part[6] += dPy * cX; part[7] += dPy * cY; part[8] += dPy * cZ;
+                part[9] += dPz * cX; part[10] += dPz * cY; part[11] += dPz * cZ;
+            }
+            d_depth[(size_t)b * plane + (size_t)py[i] * W + px[i]] = dd;
         }
-        part[12] += da;
-        part[13] += db;
-        float dd = 0.0f;
-        if (p.valid) {
-            const float iz = nr_rcp(p.Pz);
-            const float dPx = gxs * g.fx * iz;
-            const float dPy = gys * g.fy * iz;
-            const float dPz = -(dPx * p.Px + dPy * p.Py) * iz;
-            // P = R (d * [Xh Yh 1]) + t
-            const float rx_ = g.r00 * p.Xh + g.r01 * p.Yh + g.r02;
-            const float ry_ = g.r10 * p.Xh + g.r11 * p.Yh + g.r12;
-            const float rz_ = g.r20 * p.Xh + g.r21 * p.Yh + g.r22;
-            dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
-            const float cX = p.Xh * dval, cY = p.Yh * dval, cZ = dval;
-            part[0] += dPx; part[1] += dPy; part[2] += dPz;
-            part[3] += dPx * cX; part[4] += dPx * cY; part[5] += dPx * cZ;
-            part[6] += dPy * cX; part[7] += dPy * cY; part[8] += dPy * cZ;
-            part[9] += dPz * cX; part[10] += dPz * cY; part[11] += dPz * cZ;
-        }
-        d_depth[(size_t)b * plane + o] = dd;
     }
     // block reduction of the 14 partial sums through LDS (the staging arrays are free now): two fixed-order
     // stages instead of 14 x 6 cross-lane shuffles per thread
@@ -670,12 +813,15 @@ extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65535, "colvo_warp_loss_fwd: bad shape B=%d H=%d W=%d", B, H, W);
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_fwd: image too large");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(tiles_x(W), tiles_y(H), B);
-    COLVO_CHECK_ARG(grid.y <= 65535, "colvo_warp_loss_fwd: H too large");
-    hipLaunchKernelGGL(k_warp_loss_fwd, grid, dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
-                       ssim_weight, workspace);
+    const int tx = tiles_x(W), ty = tiles_y(H);
+    // persistent strips: ~4 workgroups per CU over the whole batch, each a contiguous run of tiles of one image
+    int strips = (4 * 256 + B - 1) / B;
+    if (strips > tx * ty) strips = tx * ty;
+    if (strips < 1) strips = 1;
+    hipLaunchKernelGGL(k_warp_loss_fwd, dim3(strips, 1, B), dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
+                       tx, ty, ssim_weight, workspace);
     COLVO_CHECK_LAUNCH("k_warp_loss_fwd");
-    const int nblk = (int)(grid.x * grid.y * grid.z);
+    const int nblk = strips * B;
     hipLaunchKernelGGL(k_warp_loss_fwd_finalize, dim3(1), dim3(NT), 0, s, workspace, nblk, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fwd_finalize");
     return 0;
