@@ -35,6 +35,7 @@ SIGNATURES = {
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_relu_bwd_inplace": (_i, [_i, _vp, _vp, _sz, _vp]),
     "colvo_pack_weights": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "colvo_pack_weights_multi": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "colvo_pack_nchw": (_i, [_i, C.POINTER(_vp), C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _vp, _vp]),
     "colvo_unpack_nhwc_grad": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "colvo_depth_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),

@@ -535,8 +535,14 @@ int launch_wgrad(WgradK k, hipStream_t s) {
     }
     const int chunks = (k.g.C[0] + k.g.C[1]) / CK;
     const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
-    // enough workgroups to fill 256 CUs a few times over, but >= 1 tile each
-    int nsplit = (1024 + chunks * cot - 1) / (chunks * cot);
+    // Pixel-range splits: every split adds one fp32 atomic per weight (chip-wide ~1.3 TB/s of atomics), so cap
+    // the atomic traffic at ~12 MB per launch, but keep at least ~256 workgroups in flight and at most ~1024.
+    const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
+    const int per_split = chunks * cot;
+    int nsplit = (int)(12.0e6 / wbytes);
+    const int lo = (256 + per_split - 1) / per_split, hi = (1024 + per_split - 1) / per_split;
+    if (nsplit > hi) nsplit = hi;
+    if (nsplit < lo) nsplit = lo;
     if (nsplit > k.ntiles) nsplit = k.ntiles;
     if (nsplit < 1) nsplit = 1;
     k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;

@@ -35,6 +35,31 @@ __global__ __launch_bounds__(NT) void k_pack_weights(const float* __restrict__ w
     if (w_bwd) Elem<ES>::st(w_bwd, ((size_t)c * kk + (kk - 1 - t)) * Cout + co, v);   // taps flipped
 }
 
+// One launch for all layers of a network: `tab` (device) holds, per layer, the element offsets of the master
+// weights in the fp32 arena and of the two operand copies in their flat buffers, plus the first workgroup
+// of the layer; every workgroup finds its layer by a scan of that small table.
+struct PackEntry {
+    long long w_off, fwd_off, bwd_off;
+    int Cout, kk, Cin, blk_begin;
+};
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pack_weights_multi(const float* __restrict__ master, const PackEntry* __restrict__ tab,
+                                                           int nlayers, void* __restrict__ fwd, void* __restrict__ bwd) {
+    int l = 0;
+    for (int i = 1; i < nlayers; ++i)
+        if ((int)blockIdx.x >= tab[i].blk_begin) l = i;
+    const PackEntry e = tab[l];
+    const size_t n = (size_t)e.Cout * e.kk * e.Cin;
+    const size_t i = (size_t)(blockIdx.x - e.blk_begin) * NT + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % e.Cin);
+    const int t = (int)((i / e.Cin) % e.kk);
+    const int co = (int)(i / ((size_t)e.Cin * e.kk));
+    const float v = master[e.w_off + i];
+    if (fwd && e.fwd_off >= 0) Elem<ES>::st(fwd, e.fwd_off + i, v);
+    Elem<ES>::st(bwd, e.bwd_off + ((size_t)c * e.kk + (e.kk - 1 - t)) * e.Cout + co, v);
+}
+
 // ---------------------------------------------------------------- NCHW <-> NHWC -------------- //
 struct Planes {
     const float* p[4];
@@ -146,12 +171,64 @@ __global__ __launch_bounds__(NT) void k_depth_head_dgrad(const void* __restrict_
     }
 }
 
-// dw[t][c] += sum_pix dpre[pix] * x[pix + tap][c];  db += sum dpre.   One (tap, c) pair per thread,
-// a strip of pixels per workgroup, partial sums by fp32 atomics.
-template <int ES>
+// dw[t][c] += sum_pix dpre[pix] * x[pix + tap][c];  db += sum dpre.
+// Written from the input pixel's side: dw[t][c] = sum_q x[q][c] * dpre[q - tap].  Each thread walks a
+// strided set of pixels q, keeps all 9*C products in registers, and the workgroup reduces ONCE at the
+// end (wave shuffle + LDS) before one fp32 atomic per weight.
+template <int ES, int C>
 __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict__ x, const float* __restrict__ dpre,
-                                                         int H, int W, int C, int rows_per_block, float* __restrict__ dw,
+                                                         int H, int W, int px_per_block, float* __restrict__ dw,
                                                          float* __restrict__ db) {
+    __shared__ float red[4][9 * C + 1];
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int p0 = blockIdx.x * px_per_block, p1 = min(HW, p0 + px_per_block);
+    float acc[9][C];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[t][c] = 0.0f;
+    float sb = 0.0f;
+    for (int q = p0 + (int)threadIdx.x; q < p1; q += NT) {
+        const int qy = q / W, qx = q - qy * W;
+        float xv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = Elem<ES>::ld(x, ((size_t)b * HW + q) * C + c);
+        sb += dpre[(size_t)b * HW + q];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                // output pixel whose tap (ky,kx) lands on q
+                const int oy = qy - ky + 1, ox = qx - kx + 1;
+                const float d = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dpre[((size_t)b * H + oy) * W + ox] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[ky * 3 + kx][c] = fmaf(d, xv[c], acc[ky * 3 + kx][c]);
+            }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float v = wave_sum(acc[t][c]);
+            if (lane == 0) red[wave][t * C + c] = v;
+        }
+    sb = wave_sum(sb);
+    if (lane == 0) red[wave][9 * C] = sb;
+    __syncthreads();
+    for (int k = threadIdx.x; k < 9 * C + 1; k += NT) {
+        const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (k < 9 * C) atomicAdd(dw + k, v);
+        else atomicAdd(db, v);
+    }
+}
+
+// generic-C fallback: one (tap, c) pair per thread over a strip of rows
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_wgrad_generic(const void* __restrict__ x, const float* __restrict__ dpre,
+                                                                 int H, int W, int C, int rows_per_block,
+                                                                 float* __restrict__ dw, float* __restrict__ db) {
     const int b = blockIdx.y;
     const int y0 = blockIdx.x * rows_per_block, y1 = min(H, y0 + rows_per_block);
     const int tid = threadIdx.x;
@@ -285,6 +362,16 @@ extern "C" int colvo_pack_weights(int dtype, const float* w_master, int Cout, in
     return 0;
 }
 
+extern "C" int colvo_pack_weights_multi(int dtype, const float* master, const void* table, int nlayers, int nblocks,
+                                        void* fwd, void* bwd, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(master && table && bwd && nlayers >= 1 && nblocks >= 1, "colvo_pack_weights_multi: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pack_weights_multi: bad dtype");
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_weights_multi<ES>), dim3(nblocks), dim3(NT), 0, (hipStream_t)stream, master,
+                                          (const PackEntry*)table, nlayers, fwd, bwd));
+    COLVO_CHECK_LAUNCH("k_pack_weights_multi");
+    return 0;
+}
+
 extern "C" int colvo_pack_nchw(int dtype, const float* const* src, const int32_t* src_channels, int nsrc, int B, int H,
                                int W, int Cpad, void* dst, colvo_stream_t stream) {
     COLVO_CHECK_ARG(src && src_channels && dst && nsrc >= 1 && nsrc <= 4, "colvo_pack_nchw: bad arguments");
@@ -351,9 +438,15 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
     const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
     hipLaunchKernelGGL(k_depth_head_dpre, dim3(nblk(n)), dim3(NT), 0, s, depth, d_depth, n, lo, hi, scratch);
     COLVO_CHECK_LAUNCH("k_depth_head_dpre");
-    const int rows = 4;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES>), dim3((H + rows - 1) / rows, B), dim3(NT), 0, s, x,
-                                          scratch, H, W, C, rows, dw, db));
+    if (C == 16) {
+        const int ppb = 2048;   // pixels per workgroup (8 per thread)
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
+                                              dim3(NT), 0, s, x, scratch, H, W, ppb, dw, db));
+    } else {
+        const int rows = 4;
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
+                                              0, s, x, scratch, H, W, C, rows, dw, db));
+    }
     COLVO_CHECK_LAUNCH("k_depth_head_wgrad");
     DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
                                           x, w, scratch, H, W, C, dx));

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -58,6 +59,10 @@ class _ArenaModule(nn.Module):
         self.flat_grad: Optional[torch.Tensor] = None
         self._packed_version = None
         self._manual_version = 0
+        self._pack_table = None
+        self._pack_dtype = None
+        self._side = None
+        self.overlap_wgrad = True
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
 
     # ---- arena ------------------------------------------------------------------------------- #
@@ -97,6 +102,7 @@ class _ArenaModule(nn.Module):
             L.w_fwd = L.w_bwd = None
         self.flat_param, self.flat_grad = flat, grad
         self._packed_version = None
+        self._pack_table = None
 
     def _apply(self, fn, *a, **kw):   # .to() / .cuda(): rebuild the arena on the new device
         super()._apply(fn, *a, **kw)
@@ -122,21 +128,63 @@ class _ArenaModule(nn.Module):
         self._manual_version += 1
 
     def _prepare_weights(self) -> None:
-        """Refresh the operand-layout copies of the weights when the master changed."""
+        """Refresh the operand-layout copies of the weights when the master changed (one launch per network)."""
         # in-place updates of the parameters (any optimizer, load_state_dict) bump their version counters
         ver = (sum(p._version for p in self.parameters()), self._manual_version, self.compute_dtype)
         if ver == self._packed_version:
             return
         dt = self.compute_dtype
-        for L in self._layers():
-            if L.k != 3 or L.cout == 1:
-                continue                               # heads read the fp32 master directly
-            if L.w_bwd is None or L.w_bwd.dtype != dt:
-                L.w_bwd = torch.empty(L.cin_pad, 9, L.cout, device=self.flat_param.device, dtype=dt)
-                L.w_fwd = L.w_master if dt == torch.float32 else torch.empty(
-                    L.cout, 9, L.cin_pad, device=self.flat_param.device, dtype=dt)
-            ops.pack_weights(L.w_master, dt, None if dt == torch.float32 else L.w_fwd, L.w_bwd)
+        dev = self.flat_param.device
+        if self._pack_table is None or self._pack_dtype != dt:
+            layers = [L for L in self._layers() if L.k == 3 and L.cout > 1]   # heads read the fp32 master directly
+            tab = np.zeros(len(layers), dtype=np.dtype([("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"),
+                                                        ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4")]))
+            total = sum(L.cout * 9 * L.cin_pad for L in layers)
+            self._op_bwd = torch.empty(total, device=dev, dtype=dt)
+            self._op_fwd = None if dt == torch.float32 else torch.empty(total, device=dev, dtype=dt)
+            off = blk = 0
+            for i, L in enumerate(layers):
+                n = L.cout * 9 * L.cin_pad
+                tab[i] = (L.span[0], -1 if self._op_fwd is None else off, off, L.cout, 9, L.cin_pad, blk)
+                L.w_bwd = self._op_bwd[off:off + n].view(L.cin_pad, 9, L.cout)
+                L.w_fwd = L.w_master if self._op_fwd is None else self._op_fwd[off:off + n].view(L.cout, 9, L.cin_pad)
+                off += n
+                blk += (n + 255) // 256
+            self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+            self._pack_n, self._pack_blocks, self._pack_dtype = len(layers), blk, dt
+        ops.pack_weights_multi(self.flat_param, self._pack_table, self._pack_n, self._pack_blocks, dt, self._op_fwd,
+                               self._op_bwd)
         self._packed_version = ver
+
+    # ---- backward scheduling: weight gradients on a side stream, concurrent with the input gradients ------ #
+    def _bwd_begin(self) -> None:
+        self._main = torch.cuda.current_stream()
+        if self.overlap_wgrad and self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_param.device)
+        self._side_used = False
+
+    def _run_wgrad(self, L: ConvParams, fn, *tensors) -> None:
+        """fn() enqueues the weight-gradient kernel(s) of layer L; with overlap it runs on the side stream,
+        ordered after everything already enqueued on the main stream (its inputs), and so does the
+        gradient-ready hook (the data-parallel all-reduce of finished buckets)."""
+        if not self.overlap_wgrad:
+            fn()
+            self._layer_done(L)
+            return
+        ev = torch.cuda.Event()
+        ev.record(self._main)
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            fn()
+            self._layer_done(L)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self._side)
+        self._side_used = True
+
+    def _bwd_end(self) -> None:
+        if self.overlap_wgrad and self._side_used:
+            self._main.wait_stream(self._side)
 
     def _layer_done(self, L: ConvParams) -> None:
         if self.grad_ready_hook is not None:
@@ -228,10 +276,11 @@ class DepthNet(_ArenaModule):
         B, _, H, W = depth.shape
         dev = depth.device
 
+        self._bwd_begin()
+
         def wgrad(name, x0, x1, dy):
             L = getattr(self, name)
-            ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias)
-            self._layer_done(L)
+            self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias), x0, x1, dy)
 
         def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
             L = getattr(self, name)
@@ -265,6 +314,7 @@ class DepthNet(_ArenaModule):
             wgrad(f"enc{i}a", src, None, g_a)
             if i > 1:
                 g = dgrad(f"enc{i}a", 0, g_a, src, dx=d_skip[i - 1], accumulate=True)
+        self._bwd_end()
 
 
 class _DepthNetFn(torch.autograd.Function):
@@ -328,6 +378,7 @@ class PoseNet(_ArenaModule):
     def _backward_impl(self, saved, d_out):
         A, P, (B, H, W), has_depth = saved
         self.attach_grads()
+        self._bwd_begin()
         x = A[7]
         g = torch.empty_like(x)
         ops.pose_head_bwd(x, self.pred.w_master, d_out.contiguous(), g, self.pred.g_master, self.pred.g_bias)
@@ -335,12 +386,13 @@ class PoseNet(_ArenaModule):
         for i in range(7, 0, -1):
             L = getattr(self, f"conv{i}")
             src = A["in"] if i == 1 else A[i - 1]
-            ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias)
-            self._layer_done(L)
+            self._run_wgrad(L, lambda L=L, i=i, src=src, g=g: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias),
+                            src, g)
             if i > 1 or has_depth:
                 dx = torch.empty_like(src)
                 ops.conv_dgrad(P[i], 0, g, L.w_bwd, src if i > 1 else None, dx, False)
                 g = dx
+        self._bwd_end()
         if not has_depth:
             return None, None
         d_t = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)

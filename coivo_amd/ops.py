@@ -73,6 +73,15 @@ def pack_weights(w_master: torch.Tensor, dtype: torch.dtype, w_fwd: Optional[tor
                                       _lib.ptr(w_bwd), _lib.stream_ptr()), "colvo_pack_weights")
 
 
+def pack_weights_multi(master: torch.Tensor, table: torch.Tensor, nlayers: int, nblocks: int, dtype: torch.dtype,
+                       fwd: Optional[torch.Tensor], bwd: torch.Tensor) -> None:
+    """All 3x3 layers of a network in one launch (table layout: include/colvo.h colvo_pack_weights_multi)."""
+    _need_cuda(master, table, fwd, bwd)
+    lib = _lib.load()
+    _lib.check(lib.colvo_pack_weights_multi(dt_code(dtype), _lib.ptr(master), _lib.ptr(table), nlayers, nblocks,
+                                            _lib.ptr(fwd), _lib.ptr(bwd), _lib.stream_ptr()), "colvo_pack_weights_multi")
+
+
 def pack_nchw(srcs: Sequence[torch.Tensor], Cpad: int, dtype: torch.dtype, out: Optional[torch.Tensor] = None
               ) -> torch.Tensor:
     """Concatenate NCHW fp32 tensors along channels into one NHWC feature map with Cpad channels."""

@@ -116,6 +116,14 @@ int colvo_relu_bwd_inplace(int dtype, const void* y, void* dy, size_t n, colvo_s
 int colvo_pack_weights(int dtype, const float* w_master, int Cout, int kk, int Cin,
                        void* w_fwd, void* w_bwd, colvo_stream_t stream);
 
+/* The same for every 3x3 layer of a network in ONE launch.  `table` (device memory) is an array of
+ *   struct { int64 w_off, fwd_off, bwd_off; int32 Cout, kk, Cin, blk_begin; }
+ * with element offsets into `master` (fp32 arena), `fwd` and `bwd` (flat operand buffers in `dtype`; fwd_off < 0
+ * or fwd == NULL skips the forward copy) and the index of the layer's first 256-thread workgroup;
+ * nblocks = sum over layers of ceil(Cout*kk*Cin / 256). */
+int colvo_pack_weights_multi(int dtype, const float* master, const void* table, int nlayers, int nblocks,
+                             void* fwd, void* bwd, colvo_stream_t stream);
+
 /* NCHW fp32 planes -> NHWC feature map of `Cpad` channels (zero padded), and back (gradient, fp32 NCHW).
  * src[i] points to an [B,c_i,H,W] tensor; up to 4 sources are concatenated along channels. */
 int colvo_pack_nchw(int dtype, const float* const* src, const int32_t* src_channels, int nsrc,
