@@ -1,0 +1,89 @@
+"""CPU-side checks of the boundary: the C-ABI library builds, loads next to torch's HIP runtime and exports every
+symbol include/colvo.h declares; argument validation fails loudly without touching a GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from coivo_amd import _lib, build
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "colvo.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(colvo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported_and_bound(lib):
+    from coivo_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"libcolvo.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} is declared in colvo.h but has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_error_string(lib):
+    from coivo_amd import _lib
+    assert lib.colvo_abi_version() == _lib.ABI_VERSION
+    assert isinstance(lib.colvo_last_error(), bytes)
+
+
+def test_workspace_size_formula(lib):
+    # 64x16 tiles, 14 partial sums per tile
+    assert lib.colvo_warp_loss_workspace_floats(8, 256, 320) == 8 * 5 * 16 * 14
+    assert lib.colvo_warp_loss_workspace_floats(2, 33, 47) == 2 * 1 * 3 * 14
+    assert lib.colvo_warp_loss_workspace_floats(0, 10, 10) == 0
+
+
+def test_argument_validation_fails_loudly_without_gpu(lib):
+    # null pointers / bad shapes are rejected before any launch
+    rc = lib.colvo_warp_loss_fwd(0, 0, 0, 0, 0, 0, 0, 1, 8, 8, 0.85, 0, 0, 0)
+    assert rc != 0 and b"null pointer" in lib.colvo_last_error()
+    buf = (C.c_float * 16)()
+    p = C.addressof(buf)
+    rc = lib.colvo_warp_loss_fwd(p, p, p, p, p, p, p, 1, 1, 8, 0.85, p, p, 0)   # H = 1 < 2
+    assert rc != 0 and b"bad shape" in lib.colvo_last_error()
+    from coivo_amd._lib import ConvDesc
+    d = ConvDesc()
+    d.dtype, d.B, d.Hi, d.Wi, d.Ho, d.Wo, d.Cout, d.ksize, d.stride, d.C0 = 0, 1, 8, 8, 8, 8, 16, 5, 1, 16
+    rc = lib.colvo_conv_fwd(C.byref(d), p, 0, p, p, p, 0)
+    assert rc != 0 and b"3x3" in lib.colvo_last_error()
+    d.ksize, d.C0 = 3, 12
+    rc = lib.colvo_conv_fwd(C.byref(d), p, 0, p, p, p, 0)
+    assert rc != 0 and b"multiples of 8" in lib.colvo_last_error()
+
+
+def test_python_ops_refuse_cpu_tensors():
+    from coivo_amd import functional as Fh
+    t = torch.zeros(1, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        Fh.photometric_loss(t, t, torch.ones(1, 1, 8, 8), torch.zeros(1, 6), torch.eye(3)[None], torch.ones(1, 1),
+                            torch.zeros(1, 1))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        Fh.inverse_warp(t, torch.ones(1, 1, 8, 8), torch.zeros(1, 6), torch.eye(3)[None])
+
+
+def test_product_package_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under coivo_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "coivo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "colvo_spec" not in txt or f in ("nn.py", "functional.py", "optim.py", "misc.hip", "conv.hip",
+                                                       "warp_loss.hip"), f   # docstring citations only
+    for f in ("nn.py", "functional.py", "optim.py", "ops.py", "ddp.py", "synth.py", "_lib.py", "build.py"):
+        txt = open(os.path.join(pkg, f)).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M)
