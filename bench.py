@@ -87,6 +87,20 @@ def cpu_baseline(B, H, W, budget_s):
             "sample": f"oracle (pure-torch fp32) full train step, B={B} {W}x{H}, 1 warm-up + {len(times)} timed steps, median"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per fwd+bwd launch pair from the committed PMC summary (profiles/rN_traffic.json), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+        sel = [k for k in ks if k["workload"] == workload]
+        return sum(k["hbm_bytes"] for k in sel) if len(sel) == 2 else None
+    except Exception:
+        return None
+
+
 def roofline_cfg2(dev):
     """Fused warp/loss fwd+bwd alone at BASELINE configs[2] (B=32, 640x512): where SURVEY.md §8d reads the HBM roofline."""
     from coivo_amd import functional as Fh
@@ -99,26 +113,24 @@ def roofline_cfg2(dev):
     pose = rep(b["gt_pose"]).requires_grad_(True)
     a = rep(b["gt_a"]).requires_grad_(True)
     bb = rep(b["gt_b"]).requires_grad_(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tf, tb = [], []
+    Fh.enable_timing(True)
     for it in range(25):
-        ev[0].record()
         loss = Fh.photometric_loss(tgt, ref, depth, pose, K, a, bb)
-        ev[1].record()
         torch.autograd.grad(loss, [depth, pose, a, bb])
-        ev[2].record()
-        torch.cuda.synchronize()
-        if it >= 5:
-            tf.append(ev[0].elapsed_time(ev[1]))
-            tb.append(ev[1].elapsed_time(ev[2]))
-    tf.sort(); tb.sort()
+    torch.cuda.synchronize()
+    ev = Fh.timing_events()
+    tf = sorted(e0.elapsed_time(e1) for e0, e1 in ev["fwd"][5:])
+    tb = sorted(e0.elapsed_time(e1) for e0, e1 in ev["bwd"][5:])
+    Fh.enable_timing(False)
     f_ms, b_ms = tf[len(tf) // 2], tb[len(tb) // 2]
     px = B * H * W
     ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + b_ms) * 1e-3) / 1e9
     return {"kernel": "k_warp_loss_fwd + k_warp_loss_bwd", "workload": f"B={B} {W}x{H} fp32, 1 warp direction",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": pmc_traffic("B=32 640x512 (configs[2])"),
             "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
-            "timing": "hip events around the op on its launch stream (includes the 1-block finalize kernels), median of 20"}
+            "timing": "hip events on the launch stream directly around each C-ABI call (main kernel + its 1-block finalize "
+                      "kernel), median of 20 launches"}
 
 
 def main():
@@ -166,27 +178,13 @@ def main():
     batch = synth.make_batch(B, H, W, seed=1234 + rank, device=dev)
     tgt, ref, K = batch["tgt"], batch["ref"], batch["K"]
 
-    ev_pool = []
-
     def step(timed: bool):
         opt.zero_grad()
         d = dn(torch.cat([tgt, ref], dim=0))
         d_t, d_r = d[:B], d[B:]
         pose, a, b = pn(tgt, ref, d_t, d_r)
-        if timed:
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-            e[0].record()
         loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
-        if timed:
-            e[1].record()
-            # time the fused backward in isolation: it is the first node autograd runs
-            loss_g = loss.grad_fn
-            hook_s = loss_g.register_prehook(lambda *_: e[2].record())
-            hook_e = loss_g.register_hook(lambda *_: e[3].record())
         loss.backward()
-        if timed:
-            hook_s.remove(); hook_e.remove()
-            ev_pool.append(e)
         if ddp is not None:
             ddp.finish()
         opt.step()
@@ -199,6 +197,7 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    Fh.enable_timing(rank == 0)     # HIP events around the fused-op launches inside the timed steps
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -214,17 +213,20 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        f_us = sorted(e[0].elapsed_time(e[1]) for e in ev_pool)
-        b_us = sorted(e[2].elapsed_time(e[3]) for e in ev_pool)
+        ev = Fh.timing_events()
+        f_us = [e0.elapsed_time(e1) for e0, e1 in ev["fwd"]]
+        b_us = [e0.elapsed_time(e1) for e0, e1 in ev["bwd"]]
+        Fh.enable_timing(False)
         f_ms, b_ms = sum(f_us) / len(f_us), sum(b_us) / len(b_us)
         px = B * H * W
         ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + b_ms) * 1e-3) / 1e9
         roof = {"kernel": "k_warp_loss_fwd + k_warp_loss_bwd (fused project/sample/LCC/SSIM/L1 and its backward)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
+                "traffic": pmc_traffic("B=8 320x256 (configs[1])"), "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
                 "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3,
-                "timing": "hip events on the launch stream inside the timed steps, mean over steps; "
-                          "latency-dominated at this size (SURVEY.md §8d) -- see roofline_cfg2"}
+                "timing": "hip events on the launch stream directly around the fused op's C-ABI calls inside the timed "
+                          "steps (main kernel + 1-block finalize), mean over steps; latency-dominated at this size "
+                          "(SURVEY.md §8d) -- the roofline is read at configs[2], see roofline_cfg2"}
         out = {"metric": "training frame-pairs/sec at 320x256", "value": value, "unit": "frame-pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -13,6 +13,30 @@ from . import _lib
 
 SSIM_WEIGHT = 0.85
 
+# Optional kernel timing for bench.py: when enabled, every fused-op call is bracketed by HIP events recorded on
+# the stream the kernels are launched on (PyTorch's current stream), immediately around the C-ABI call.
+_timing = None
+
+
+def enable_timing(on: bool = True) -> None:
+    global _timing
+    _timing = {"fwd": [], "bwd": []} if on else None
+
+
+def timing_events():
+    return _timing
+
+
+def _timed(kind, call):
+    if _timing is None:
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = call()
+    e1.record()
+    _timing[kind].append((e0, e1))
+    return r
+
 
 def _chk(t: torch.Tensor, name: str, shape) -> torch.Tensor:
     if not t.is_cuda:
@@ -42,9 +66,9 @@ class _WarpLoss(torch.autograd.Function):
         nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
         ws = torch.empty(nws, device=tgt.device, dtype=torch.float32)
         state = torch.empty(4, device=tgt.device, dtype=torch.float32)
-        _lib.check(lib.colvo_warp_loss_fwd(_lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K),
-                                           _lib.ptr(lcc_a), _lib.ptr(lcc_b), B, H, W, float(ssim_weight),
-                                           _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr()), "colvo_warp_loss_fwd")
+        _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fwd(
+            _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
+            B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr())), "colvo_warp_loss_fwd")
         ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
         ctx.ssim_weight = float(ssim_weight)
         return state[0].clone()
@@ -61,11 +85,10 @@ class _WarpLoss(torch.autograd.Function):
         d_pose = torch.empty_like(pose)
         d_a = torch.empty_like(lcc_a)
         d_b = torch.empty_like(lcc_b)
-        _lib.check(lib.colvo_warp_loss_bwd(_lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K),
-                                           _lib.ptr(lcc_a), _lib.ptr(lcc_b), B, H, W, ctx.ssim_weight,
-                                           _lib.ptr(state), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(d_depth),
-                                           _lib.ptr(d_pose), _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr()),
-                   "colvo_warp_loss_bwd")
+        _lib.check(_timed("bwd", lambda: lib.colvo_warp_loss_bwd(
+            _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
+            B, H, W, ctx.ssim_weight, _lib.ptr(state), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(d_depth), _lib.ptr(d_pose),
+            _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr())), "colvo_warp_loss_bwd")
         return None, None, d_depth, d_pose, None, d_a, d_b, None
 
 
