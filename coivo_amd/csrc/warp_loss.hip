@@ -9,13 +9,16 @@
 // Roofline: HBM.  Algorithmic bytes (fp32, per pixel): fwd 28 (tgt 12 + ref 12 + depth 4),
 // bwd 32 (same reads + d_depth 4).  DESIGN.md §kernels.
 //
-// Work decomposition: one 256-thread workgroup per 64x16 output tile of one image.  The
-// recalibrated warp J = a*warp(ref)+b and the target T are evaluated once per tile slot (tile +
-// 1-px halo forward, 2-px halo backward; halo slots beyond the image border hold the REFLECTED
-// pixel, which is how the reflection pad of the SSIM window is realised) and staged in LDS; the
-// 3x3 SSIM statistics then come from LDS with a sliding window (forward) or per window centre
-// (backward).  HBM reads are row-contiguous per plane (lanes = consecutive columns); the 4-tap
-// gather of `ref` is served by L1/L2 for smooth flows.
+// Work decomposition.
+//   forward : "marching wave" -- one wave per 62-column strip marches down the rows; horizontal window sums by
+//             DPP wave shifts, vertical by a rolling 3-row register window; no LDS, no barriers; loads of the next
+//             rows fly under the SSIM arithmetic of the current one.
+//   backward: one 256-thread workgroup per 64x16 tile; J = a*warp(ref)+b and T are evaluated once per tile slot
+//             (tile + 2-px halo; slots beyond the image border hold the REFLECTED pixel, which realises the SSIM
+//             reflection pad) and staged in LDS; per-window derivative coefficients and the 9-window gather run
+//             from LDS with sliding sums; the sample is recomputed for the chain rule.
+// HBM reads are row-contiguous per plane (lanes = consecutive columns); the 4-tap gather of `ref` is served by
+// L1/L2 for smooth flows; loads are buffer loads (32-bit lane offset + scalar plane offset).
 #include <type_traits>
 
 #include "common.h"
@@ -121,6 +124,14 @@ __device__ __forceinline__ Img img_make(const float* tgt, const float* ref, cons
 }
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (private L2s): give each XCD a CONTIGUOUS range of the
+// logical work ids so that neighbouring tiles (shared halos, shared tap neighbourhoods) hit the same L2.
+// Bijective for any n (cdna_hip_programming.md T1).  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
 struct Proj {
@@ -266,54 +277,6 @@ __device__ __forceinline__ void eval_batch(const Geo& g, const Img& im, const in
     }
 }
 
-// The same evaluation split into its three dependency stages, so that a persistent kernel can keep the
-// loads of the NEXT tile in flight while it computes on the current one.
-template <int N>
-struct Batch {
-    float dv[N];
-    float T[N][3];
-    float wx[N], wy[N], m[N];
-    float v[N][3][4];
-};
-template <int N>   // stage A: depth + target loads (depend on nothing)
-__device__ __forceinline__ void batch_issue_dt(const Img& im, const int (&px)[N], const int (&py)[N], int W, Batch<N>& B) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) B.dv[n] = bload(im.dep, (py[n] * W + px[n]) * 4, 0);
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) B.T[n][c] = bload(im.tgt, (py[n] * W + px[n]) * 4, c * im.plane4);
-}
-template <int N>   // stage B: project (needs depth) and issue the 12 N reference taps
-__device__ __forceinline__ void batch_issue_taps(const Geo& g, const Img& im, const int (&px)[N], const int (&py)[N],
-                                                 int H, int W, Batch<N>& B) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const Proj p = project_px(g, B.dv[n], px[n], py[n], H, W);
-        const Taps t = make_taps_safe(p, H, W);
-        B.wx[n] = t.wx; B.wy[n] = t.wy; B.m[n] = p.valid ? 1.0f : 0.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int so = c * im.plane4;
-            B.v[n][c][0] = bload(im.ref, t.o00, so); B.v[n][c][1] = bload(im.ref, t.o01, so);
-            B.v[n][c][2] = bload(im.ref, t.o10, so); B.v[n][c][3] = bload(im.ref, t.o11, so);
-        }
-    }
-}
-template <int N>   // stage C: blend + LCC
-__device__ __forceinline__ void batch_blend(const Geo& g, const Batch<N>& B, float (&J)[N][3]) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const float ux = 1.0f - B.wx[n], uy = 1.0f - B.wy[n];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float top = fmaf(B.v[n][c][1], B.wx[n], B.v[n][c][0] * ux);
-            const float bot = fmaf(B.v[n][c][3], B.wx[n], B.v[n][c][2] * ux);
-            J[n][c] = fmaf(g.a, B.m[n] * fmaf(bot, B.wy[n], top * uy), g.b);
-        }
-    }
-}
-
 // SSIM pieces from the five 3x3 window SUMS of one channel (x = target, y = J), everything scaled by
 // 81 = 9^2 so the means never have to be formed:  S = (A1 A2) / (B1 B2) is scale-free.
 struct SsimTerms {
@@ -333,121 +296,187 @@ __device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, f
 }
 
 // --------------------------------------------------------------------------------------------- //
-// forward                                                                                        //
+// forward: "marching wave"                                                                      //
 // --------------------------------------------------------------------------------------------- //
-constexpr int FSW = TW + 2, FSH = TH + 2;   // slots incl. 1-px halo
+// One WAVE owns a strip of 62 output columns x MROWS output rows and marches down it row by row; lane l
+// holds column x0-1+l (lanes 0 and 63 are the halo columns, reflected at the image border).  Per row every
+// lane evaluates its own pixel once; the 3-wide horizontal window sums come from the two neighbouring lanes
+// by DPP wave shifts (one v_add_f32_dpp each), the 3-tall vertical sums from a rolling window of three rows
+// of registers.  No LDS, no barriers, no redundant products; a 3-stage software pipeline keeps the
+// depth/target loads two rows ahead and the 12 tap gathers one row ahead of the arithmetic.
+constexpr int MCOLS = 62;
+constexpr int MROWS_MAX = 64;
 
-// Persistent over a strip of tiles of ONE image (grid = strips x 1 x B): the masked loss sum is carried in
-// registers across the strip and reduced once per workgroup (one partial per strip, fixed order).
-__global__ __launch_bounds__(NT, 4) void k_warp_loss_fwd(
-    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
-    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
-    const float* __restrict__ lcc_b, int H, int W, int tiles_x, int tiles_y, float alpha,
-    float* __restrict__ partials) {
-    __shared__ float sJ[3][FSH][FSW];
-    __shared__ float sT[3][FSH][FSW];
-    __shared__ float s_geo[GEO_N + 2];
-    __shared__ float s_red[8];
+// Rows per segment: the grid should fill the chip's resident-wave slots (256 CUs x 16 waves at 4 waves/SIMD) in
+// whole rounds -- a 1.4-round grid costs 2 rounds -- while keeping the 2 halo rows + pipeline prologue cheap.
+inline int pick_march_rows(int B, int H, int W) {
+    const long strips = (W + MCOLS - 1) / MCOLS;
+    const long cap = 256 * 16;
+    int best = 32;
+    double best_cost = 1e30;
+    for (int r = 4; r <= MROWS_MAX; ++r) {
+        const long waves = (long)B * ((H + r - 1) / r) * strips;
+        const long rounds = (waves + cap - 1) / cap;
+        const double cost = (double)rounds * (r + 2 + 2.0);      // steps per wave + ~2 steps of prologue / epilogue
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
+    }
+    return best;
+}
 
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int ntiles = tiles_x * tiles_y;
-    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int t0 = blockIdx.x * per, t1 = min(ntiles, t0 + per);
-    if (tid == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo);
-    __syncthreads();
-    const Geo g = geo_load(s_geo);
-    const Img im = img_make(tgt, ref, depth, b, H, W);
+__device__ __forceinline__ float dpp_from_left(float v) {    // lane i <- lane i-1 (0 into lane 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_from_right(float v) {   // lane i <- lane i+1 (0 into lane 63)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float hsum3(float v) { return v + dpp_from_left(v) + dpp_from_right(v); }
 
-    const int col = tid & 63, rg = tid >> 6;
-    // slots of this thread inside a tile: 4 owned + one of the 1-px ring (first 164 threads)
-    int rsy = 4 * rg + 1, rsx = col + 1;      // dummy = first owned slot for threads >= 164
-    if (tid < FSW) { rsy = 0; rsx = tid; }
-    else if (tid < 2 * FSW) { rsy = FSH - 1; rsx = tid - FSW; }
-    else if (tid < 2 * FSW + TH) { rsy = 1 + (tid - 2 * FSW); rsx = 0; }
-    else if (tid < 2 * FSW + 2 * TH) { rsy = 1 + (tid - 2 * FSW - TH); rsx = FSW - 1; }
+struct MarchState {
+    float dv[3], T[3][3];                 // stage A: depth + target of rows j, j+1, j+2 (slot = row % 3)
+    float v[3][3][4], wx[3], wy[3], m[3]; // stage B: taps + weights + validity
+    float h[3][15];                       // horizontal window sums of rows j-2, j-1, j
+    float l1prev[3], mprev;               // |T - J| and ownership*validity of the previous row
+    float acc, cnt;
+};
 
-    float acc = 0.0f, cnt = 0.0f;
-#pragma unroll 1
-    for (int t = t0; t < t1; ++t) {
-        const int ty = t / tiles_x, tx = t - ty * tiles_x;
-        const int x0 = tx * TW, y0 = ty * TH;
-        float maskv[4];
-        // phase 1: evaluate the slots (loads batched); slots that leave the image hold the reflected pixel
-        auto phase1 = [&](auto nslots) {
-            constexpr int N = decltype(nslots)::value;
-            int px[N], py[N], ssy[N], ssx[N];
+template <int K>
+__device__ __forceinline__ void march_step(MarchState& st, const Geo& g, const Img& im, int j, int nrows, int y_first,
+                                           int px, bool own_col, int H, int W, float alpha) {
+    constexpr int K1 = (K + 1) % 3, K2 = (K + 2) % 3;
+    if (j >= nrows) return;                              // wave-uniform
+    // (1) consume what the previous step left in flight: blend row j (taps) and project row j+1 (depth).
+    //     Everything outstanding is needed here, so the compiler's vmcnt(0) at this point is exact.
+    const float ux = 1.0f - st.wx[K], uy = 1.0f - st.wy[K];
+    float Jc[3], Tc[3];
 #pragma unroll
-            for (int n = 0; n < N; ++n) {
-                ssy[n] = (n < 4) ? 4 * rg + n + 1 : rsy;
-                ssx[n] = (n < 4) ? col + 1 : rsx;
-                py[n] = reflect_idx(y0 + ssy[n] - 1, H);
-                px[n] = reflect_idx(x0 + ssx[n] - 1, W);
-            }
-            Proj p[N];
-            float dv[N], J[N][3], T[N][3], Wp[N][3], dumx[N][3], dumy[N][3];
-            eval_batch<N, false>(g, im, px, py, H, W, p, dv, J, T, Wp, dumx, dumy);
-#pragma unroll
-            for (int n = 0; n < N; ++n) {
-                if (n < 4) maskv[n] = (p[n].valid && (y0 + ssy[n] - 1) < H && (x0 + ssx[n] - 1) < W) ? 1.0f : 0.0f;
-                if (n < 4 || tid < 2 * FSW + 2 * TH) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        sJ[c][ssy[n]][ssx[n]] = J[n][c];
-                        sT[c][ssy[n]][ssx[n]] = T[n][c];
-                    }
-                }
-            }
-        };
-        if (tid < 192) phase1(std::integral_constant<int, 5>{});   // waves 0..2 carry the ring (wave-uniform)
-        else phase1(std::integral_constant<int, 4>{});
-        __syncthreads();
-
-        // phase 2: per channel, the 6 slot rows x 3 columns this thread's 4 output rows need are read from LDS
-        // up front (one latency per channel), then the sliding 3x3 sums run from registers.
-        float m4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; ++c) {
+        const float top = fmaf(st.v[K][c][1], st.wx[K], st.v[K][c][0] * ux);
+        const float bot = fmaf(st.v[K][c][3], st.wx[K], st.v[K][c][2] * ux);
+        Jc[c] = fmaf(g.a, st.m[K] * fmaf(bot, st.wy[K], top * uy), g.b);
+        Tc[c] = st.T[K][c];
+    }
+    // (2) issue the loads of the next rows; they fly under the arithmetic of (3)
+    if (j + 1 < nrows) {
+        const int py = reflect_idx(y_first + j + 1, H);
+        const Proj p = project_px(g, st.dv[K1], px, py, H, W);
+        const Taps t = make_taps_safe(p, H, W);
+        st.wx[K1] = t.wx; st.wy[K1] = t.wy; st.m[K1] = p.valid ? 1.0f : 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float jv[6][3], tv[6][3];
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    jv[j][k] = sJ[c][4 * rg + j][col + k];
-                    tv[j][k] = sT[c][4 * rg + j][col + k];
-                }
-            float hx[6], hy[6], hxx[6], hyy[6], hxy[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                hx[j] = tv[j][0] + tv[j][1] + tv[j][2];
-                hy[j] = jv[j][0] + jv[j][1] + jv[j][2];
-                hxx[j] = fmaf(tv[j][0], tv[j][0], fmaf(tv[j][1], tv[j][1], tv[j][2] * tv[j][2]));
-                hyy[j] = fmaf(jv[j][0], jv[j][0], fmaf(jv[j][1], jv[j][1], jv[j][2] * jv[j][2]));
-                hxy[j] = fmaf(tv[j][0], jv[j][0], fmaf(tv[j][1], jv[j][1], tv[j][2] * jv[j][2]));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const SsimTerms s = ssim_terms(hx[i] + hx[i + 1] + hx[i + 2], hy[i] + hy[i + 1] + hy[i + 2],
-                                               hxx[i] + hxx[i + 1] + hxx[i + 2], hyy[i] + hyy[i + 1] + hyy[i + 2],
-                                               hxy[i] + hxy[i + 1] + hxy[i + 2]);
-                const float S = (s.A1 * s.A2) * fast_rcp(s.B1 * s.B2);
-                const float ss = fminf(fmaxf(0.5f * (1.0f - S), 0.0f), 1.0f);
-                m4[i] += alpha * ss + (1.0f - alpha) * fabsf(tv[i + 1][1] - jv[i + 1][1]);
-            }
+            const int so = c * im.plane4;
+            st.v[K1][c][0] = bload(im.ref, t.o00, so); st.v[K1][c][1] = bload(im.ref, t.o01, so);
+            st.v[K1][c][2] = bload(im.ref, t.o10, so); st.v[K1][c][3] = bload(im.ref, t.o11, so);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc = fmaf(m4[i], maskv[i], acc); cnt += maskv[i]; }
-        __syncthreads();     // LDS is rewritten by the next tile
     }
+    if (j + 2 < nrows) {
+        const int py = reflect_idx(y_first + j + 2, H);
+        const int o4 = (py * W + px) * 4;
+        st.dv[K2] = bload(im.dep, o4, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.T[K2][c] = bload(im.tgt, o4, c * im.plane4);
+    }
+    // (3) window sums of row j, SSIM of the row above
+    float l1cur[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float J = Jc[c], T = Tc[c];
+        st.h[K][5 * c + 0] = hsum3(T);
+        st.h[K][5 * c + 1] = hsum3(J);
+        st.h[K][5 * c + 2] = hsum3(T * T);
+        st.h[K][5 * c + 3] = hsum3(J * J);
+        st.h[K][5 * c + 4] = hsum3(T * J);
+        l1cur[c] = fabsf(T - J);
+    }
+    if (j >= 2) {                                        // output row = slot row j-1
+        float mrow = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const SsimTerms s = ssim_terms(st.h[K1][5 * c + 0] + st.h[K2][5 * c + 0] + st.h[K][5 * c + 0],
+                                           st.h[K1][5 * c + 1] + st.h[K2][5 * c + 1] + st.h[K][5 * c + 1],
+                                           st.h[K1][5 * c + 2] + st.h[K2][5 * c + 2] + st.h[K][5 * c + 2],
+                                           st.h[K1][5 * c + 3] + st.h[K2][5 * c + 3] + st.h[K][5 * c + 3],
+                                           st.h[K1][5 * c + 4] + st.h[K2][5 * c + 4] + st.h[K][5 * c + 4]);
+            const float S = (s.A1 * s.A2) * fast_rcp(s.B1 * s.B2);
+            const float ss = fminf(fmaxf(0.5f * (1.0f - S), 0.0f), 1.0f);
+            mrow += alpha * ss + (1.0f - alpha) * st.l1prev[c];
+        }
+        st.acc = fmaf(mrow, st.mprev, st.acc);
+        st.cnt += st.mprev;
+    }
+    // this row becomes "the row above": it is an output row iff it is inside the image and inside the segment
+    const int gy = y_first + j;
+    const bool own_row = (j >= 1) && (j <= nrows - 2) && (gy < H);
+    st.mprev = (own_row && own_col) ? st.m[K] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.l1prev[c] = l1cur[c];
+}
 
+__global__ __launch_bounds__(NT) void k_warp_loss_fwd_march(
+    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
+    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
+    const float* __restrict__ lcc_b, int B, int H, int W, int strips_x, int nseg, int seg_rows, float alpha,
+    float* __restrict__ partials) {
+    __shared__ float s_geo[4][GEO_N + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // wave-uniform BY CONSTRUCTION for the compiler (readfirstlane): everything derived from it -- image index,
+    // buffer descriptors -- stays scalar, otherwise every buffer load is wrapped in a waterfall loop
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nitems = B * nseg * strips_x;
+    const int item_raw = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // (image, segment, strip), strip fastest
+    const bool live = item_raw < nitems;
+    const int item = live ? item_raw : nitems - 1;
+    const int b = item / (nseg * strips_x), rem = item - b * (nseg * strips_x);
+    const int seg = rem / strips_x, strip = rem - seg * strips_x;
+    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave]);
+    __syncthreads();
+    const Geo g = geo_load(s_geo[wave]);
+    const Img im = img_make(tgt, ref, depth, b, H, W);
+
+    const int x0 = strip * MCOLS, y0 = seg * seg_rows;
+    const int gx = x0 - 1 + lane;
+    const int px = reflect_idx(gx, W);
+    const bool own_col = (lane >= 1) && (lane <= MCOLS) && (gx < W);
+    const int rows_here = min(seg_rows, H - y0);
+    const int nrows = rows_here + 2;
+    const int y_first = y0 - 1;
+
+    MarchState st;
+    st.acc = 0.0f; st.cnt = 0.0f; st.mprev = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.l1prev[c] = 0.0f;
+    // prologue: A(0), A(1), B(0)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int py = reflect_idx(y_first + r, H);
+        const int o4 = (py * W + px) * 4;
+        st.dv[r] = bload(im.dep, o4, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.T[r][c] = bload(im.tgt, o4, c * im.plane4);
+    }
+    {
+        const int py = reflect_idx(y_first, H);
+        const Proj p = project_px(g, st.dv[0], px, py, H, W);
+        const Taps t = make_taps_safe(p, H, W);
+        st.wx[0] = t.wx; st.wy[0] = t.wy; st.m[0] = p.valid ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int so = c * im.plane4;
+            st.v[0][c][0] = bload(im.ref, t.o00, so); st.v[0][c][1] = bload(im.ref, t.o01, so);
+            st.v[0][c][2] = bload(im.ref, t.o10, so); st.v[0][c][3] = bload(im.ref, t.o11, so);
+        }
+    }
+#pragma unroll 1
+    for (int j = 0; j < nrows; j += 3) {
+        march_step<0>(st, g, im, j, nrows, y_first, px, own_col, H, W, alpha);
+        march_step<1>(st, g, im, j + 1, nrows, y_first, px, own_col, H, W, alpha);
+        march_step<2>(st, g, im, j + 2, nrows, y_first, px, own_col, H, W, alpha);
+    }
+    float acc = live ? st.acc : 0.0f, cnt = live ? st.cnt : 0.0f;
     acc = wave_sum(acc);
     cnt = wave_sum(cnt);
-    if ((tid & 63) == 0) { s_red[2 * (tid >> 6)] = acc; s_red[2 * (tid >> 6) + 1] = cnt; }
-    __syncthreads();
-    if (tid == 0) {
-        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-        partials[2 * blk] = (s_red[0] + s_red[2]) + (s_red[4] + s_red[6]);
-        partials[2 * blk + 1] = (s_red[1] + s_red[3]) + (s_red[5] + s_red[7]);
+    if (lane == 0 && live) {
+        partials[2 * (size_t)item] = acc;
+        partials[2 * (size_t)item + 1] = cnt;
     }
 }
 
@@ -487,8 +516,9 @@ constexpr int NPART = 14;                   // dt[3], dR[9], da, db
 __global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
-    const float* __restrict__ lcc_b, int H, int W, float alpha, const float* __restrict__ loss_state,
-    const float* __restrict__ grad_loss, float* __restrict__ d_depth, float* __restrict__ partials) {
+    const float* __restrict__ lcc_b, int H, int W, int tiles_x, int tiles_y, float alpha,
+    const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
+    float* __restrict__ partials) {
     __shared__ float sJ[3][BSH][BSW];
     __shared__ float sT[3][BSH][BSW];
     __shared__ float sM[WSH][WSW];       // validity mask of each window centre (0 outside the image)
@@ -496,8 +526,11 @@ __global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
     __shared__ float s_geo[GEO_N + 2];
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);      // logical id = (image * tiles_y + ty) * tiles_x + tx
+    const int tpi = tiles_x * tiles_y;
+    const int b = wid / tpi, trem = wid - b * tpi;
+    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
+    const int x0 = txi * TW, y0 = tyi * TH;
     if (tid == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo);
     __syncthreads();
     const Geo g = geo_load(s_geo);
@@ -712,8 +745,7 @@ __global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
         float a = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) a += sRed2[tid * 16 + i];
-        const size_t blk = ((size_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partials[blk * NPART + tid] = a;
+        partials[(size_t)wid * NPART + tid] = a;
     }
 }
 
@@ -802,7 +834,9 @@ using namespace colvo;
 
 extern "C" size_t colvo_warp_loss_workspace_floats(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * tiles_x(W) * tiles_y(H) * NPART;
+    const size_t bwd = (size_t)B * tiles_x(W) * tiles_y(H) * NPART;                                       // 14 per 64x16 tile
+    const size_t fwd = (size_t)B * ((W + MCOLS - 1) / MCOLS) * ((H + 3) / 4) * 2;   // 2 per strip segment (>= 4 rows each)
+    return bwd > fwd ? bwd : fwd;
 }
 
 extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const float* depth, const float* pose,
@@ -813,15 +847,15 @@ extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65535, "colvo_warp_loss_fwd: bad shape B=%d H=%d W=%d", B, H, W);
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_fwd: image too large");
     hipStream_t s = (hipStream_t)stream;
-    const int tx = tiles_x(W), ty = tiles_y(H);
-    // persistent strips: ~4 workgroups per CU over the whole batch, each a contiguous run of tiles of one image
-    int strips = (4 * 256 + B - 1) / B;
-    if (strips > tx * ty) strips = tx * ty;
-    if (strips < 1) strips = 1;
-    hipLaunchKernelGGL(k_warp_loss_fwd, dim3(strips, 1, B), dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
-                       tx, ty, ssim_weight, workspace);
-    COLVO_CHECK_LAUNCH("k_warp_loss_fwd");
-    const int nblk = strips * B;
+    // marching-wave forward: one wave per (image, 32-row segment, 62-column strip)
+    const int seg_rows = pick_march_rows(B, H, W);
+    const int strips_x = (W + MCOLS - 1) / MCOLS, nseg = (H + seg_rows - 1) / seg_rows;
+    const long long nitems = (long long)B * nseg * strips_x;
+    COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fwd: too many strips");
+    const int nblk = (int)nitems;
+    hipLaunchKernelGGL(k_warp_loss_fwd_march, dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
+                       lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, workspace);
+    COLVO_CHECK_LAUNCH("k_warp_loss_fwd_march");
     hipLaunchKernelGGL(k_warp_loss_fwd_finalize, dim3(1), dim3(NT), 0, s, workspace, nblk, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fwd_finalize");
     return 0;
@@ -838,12 +872,12 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65535, "colvo_warp_loss_bwd: bad shape B=%d H=%d W=%d", B, H, W);
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_bwd: image too large");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(tiles_x(W), tiles_y(H), B);
-    COLVO_CHECK_ARG(grid.y <= 65535, "colvo_warp_loss_bwd: H too large");
-    hipLaunchKernelGGL(k_warp_loss_bwd, grid, dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
-                       ssim_weight, loss_state, grad_loss, d_depth, workspace);
+    const int tx = tiles_x(W), ty = tiles_y(H);
+    COLVO_CHECK_ARG((long long)tx * ty * B < (1ll << 31), "colvo_warp_loss_bwd: too many tiles");
+    hipLaunchKernelGGL(k_warp_loss_bwd, dim3(tx * ty * B), dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
+                       tx, ty, ssim_weight, loss_state, grad_loss, d_depth, workspace);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd");
-    hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, (int)(grid.x * grid.y), pose,
+    hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, tx * ty, pose,
                        d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_finalize");
     return 0;
