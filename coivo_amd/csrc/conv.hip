@@ -154,53 +154,119 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int wc0 = 0;   // column of this chunk inside a weight row
-    for (int s = 0; s < 2; ++s) {
-        const int Cs = a.g.C[s];
-        for (int c0 = 0; c0 < Cs; c0 += CK, wc0 += CK) {
-            __syncthreads();
-            // weight slab [BN][STEPS*4 granules], zero beyond the 9*NG real ones / beyond N
-            for (int i = tid; i < BN * STEPS * 4; i += NT) {
-                const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (gi < NGR && n0 + n < a.N) {
-                    const int tap = gi / NG, cg = gi - tap * NG;
-                    v = ld16(a.w + (((size_t)(n0 + n) * 9 + tap) * a.Ctot + wc0 + cg * G) * ES);
-                }
-                st16(sW + n * WROW + gi * 16, v);
+    // ---- software-pipelined K loop over channel chunks ----
+    // Staging goes global -> registers -> LDS.  The registers of chunk k+1 are loaded (all loads of a thread
+    // issued back to back) BEFORE the MFMAs of chunk k and written to LDS after them, so global latency hides
+    // under the matrix work instead of being paid once per 16-byte granule.
+    constexpr int WTOT = BN * STEPS * 4;                   // weight granules per chunk (incl. zero padding)
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = 3;                                 // patch granules per thread that are prefetched
+    const int ptotal = PH * PW * NG;
+    const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
+    u32x4 wv[WIT], pv[PPF];
+
+    auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
+    auto load_w = [&](int k) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * NT + tid;
+            const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (i < WTOT && gi < NGR && n0 + n < a.N) {
+                const int tap = gi / NG, cg = gi - tap * NG;
+                v = ld16(a.w + (((size_t)(n0 + n) * 9 + tap) * a.Ctot + k * CK + cg * G) * ES);
             }
-            stage_patch<T, NG>(a.g, s, c0, b, iy0, ix0, PH, PW, sP);
-            __syncthreads();
+            wv[it] = v;
+        }
+    };
+    auto store_w = [&]() {
 #pragma unroll
-            for (int m = 0; m < STEPS; ++m) {
-                const int gi = 4 * m + kg;
-                int tap = gi / NG;
-                const int cg = gi - tap * NG;
-                tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
-                const int ky = tap / 3, kx = tap - 3 * ky;
-                const int aoff = (ky * PW + kx) * PIXP + cg * 16;
-                u32x4 av[2], bv[NF];
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * NT + tid;
+            if (i < WTOT) { const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4); st16(sW + n * WROW + gi * 16, wv[it]); }
+        }
+    };
+    auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = pix / PW, px = pix - py * PW;
+        const int vy = iy0 + py, vx = ix0 + px;
+        bool inb = (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
+        int sy = vy, sx = vx;
+        const int mode = a.g.mode[sidx];
+        if (mode != MODE_DIRECT) {
+            if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
+            sy = vy >> 1; sx = vx >> 1;
+        }
+        const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx];
+        inb = inb && (sy < Hs) && (sx < Ws);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inb) v = ld16(a.g.src[sidx] + ((((size_t)b * Hs + sy) * Ws + sx) * a.g.C[sidx] + c0 + cg * G) * ES);
+        return v;
+    };
+    auto load_p = [&](int k) {
+        int sidx, c0;
+        chunk_src(k, sidx, c0);
 #pragma unroll
-                for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
+        for (int it = 0; it < PPF; ++it) pv[it] = patch_granule(sidx, c0, it * NT + tid);
+    };
+    auto store_p = [&](int k) {
 #pragma unroll
-                for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
-                if constexpr (ES == 2) {
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pv[it]); }
+        }
+        // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
+        int sidx, c0;
+        chunk_src(k, sidx, c0);
+        for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
+            u32x4 t[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) t[u] = patch_granule(sidx, c0, base + u * NT + tid);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, t[u]); }
+            }
+        }
+    };
+
+    load_w(0);
+    load_p(0);
+    for (int k = 0; k < nch; ++k) {
+        __syncthreads();                  // the MFMAs of chunk k-1 have finished reading LDS
+        store_w();
+        store_p(k);
+        __syncthreads();
+        if (k + 1 < nch) { load_w(k + 1); load_p(k + 1); }    // in flight during the MFMAs below
+#pragma unroll
+        for (int m = 0; m < STEPS; ++m) {
+            const int gi = 4 * m + kg;
+            int tap = gi / NG;
+            const int cg = gi - tap * NG;
+            tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+            u32x4 av[2], bv[NF];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
-                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                            for (int nf = 0; nf < NF; ++nf)
-                                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
-                }
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
             }
         }
     }
