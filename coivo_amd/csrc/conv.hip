@@ -409,27 +409,88 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
     const int tiles_per_img = a.tiles_x * a.tiles_y;
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int b = t / tiles_per_img;
+    // software pipeline over pixel tiles: the dY tile and the input patch of tile t+1 are loaded into registers
+    // before the MFMAs of tile t and written to LDS after them
+    constexpr int DGR = 16 * MT / G;                       // dY granules per pixel row
+    constexpr int DIT = (BM * DGR + NT - 1) / NT;
+    constexpr int PPF = 3;
+    const int ptotal = PH * PW * NG;
+    u32x4 dyv[DIT], pv[PPF];
+
+    auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+        b = t / tiles_per_img;
         const int tr_ = t - b * tiles_per_img;
         const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
-        const int oy0 = ty * a.toh, ox0 = tx * a.tow;
-        __syncthreads();
-        // dY tile: BM rows (zero for slots outside the region / image)
-        constexpr int DGR = 16 * MT / G;
-        for (int i = tid; i < BM * DGR; i += NT) {
+        oy0 = ty * a.toh; ox0 = tx * a.tow;
+    };
+    auto load_dy = [&](int t) {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int i = it * NT + tid;
             const int p = i / DGR, gch = i - p * DGR;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (p < npix) {
+            if (i < BM * DGR && p < npix) {
                 const int oy = p / a.tow, ox = p - oy * a.tow;
                 const int gy = oy0 + oy, gx = ox0 + ox;
                 if (gy < a.Ho && gx < a.Wo && co0 + gch * G < a.Cout)
                     v = ld16(a.dy + ((((size_t)b * a.Ho + gy) * a.Wo + gx) * a.Cout + co0 + gch * G) * ES);
             }
-            st16(sDY + p * DYP + gch * 16, v);
+            dyv[it] = v;
         }
-        stage_patch<T, NG>(a.g, s, c0, b, oy0 * S - 1, ox0 * S - 1, PH, PW, sX);
+    };
+    auto store_dy = [&]() {
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            const int i = it * NT + tid;
+            if (i < BM * DGR) { const int p = i / DGR, gch = i - p * DGR; st16(sDY + p * DYP + gch * 16, dyv[it]); }
+        }
+    };
+    auto patch_granule = [&](int t, int i) -> u32x4 {
+        int b, oy0, ox0;
+        tile_origin(t, b, oy0, ox0);
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = pix / PW, px = pix - py * PW;
+        const int vy = oy0 * S - 1 + py, vx = ox0 * S - 1 + px;
+        bool inb = (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
+        int sy = vy, sx = vx;
+        if (a.g.mode[s] != MODE_DIRECT) { sy = vy >> 1; sx = vx >> 1; }
+        const int Hs = a.g.Hs[s], Ws = a.g.Ws[s];
+        inb = inb && (sy < Hs) && (sx < Ws);
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inb) v = ld16(a.g.src[s] + ((((size_t)b * Hs + sy) * Ws + sx) * a.g.C[s] + c0 + cg * G) * ES);
+        return v;
+    };
+    auto load_p = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) pv[it] = patch_granule(t, it * NT + tid);
+    };
+    auto store_p = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
+        }
+        for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
+            u32x4 tt[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) tt[u] = patch_granule(t, base + u * NT + tid);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = base + u * NT + tid;
+                if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, tt[u]); }
+            }
+        }
+    };
+
+    if (t_begin < t_end) { load_dy(t_begin); load_p(t_begin); }
+    for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();
+        store_dy();
+        store_p(t);
+        __syncthreads();
+        if (t + 1 < t_end) { load_dy(t + 1); load_p(t + 1); }      // in flight during the MFMAs below
 
         if (blockIdx.z == 0 && a.db && tid < 16 * MT) {
             float sacc = 0.0f;
