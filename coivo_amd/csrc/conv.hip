@@ -46,6 +46,13 @@ template <> struct TT<bf16_t> { static constexpr int G = 8; static constexpr int
 constexpr int NT = 256;
 constexpr int BM = 128;   // output pixels per workgroup (4 waves x 2 fragments x 16 rows)
 
+// LDS pitches.  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (not in
+// contiguous 16-lane groups): 8 lanes of one k-group plus 8 lanes of the next one (+16 B).  With a pitch of r
+// 16-byte slots per fragment row the group is conflict-free iff {r*l mod 16} are distinct EVEN slots for the 8 rows
+// of a half: r = 6 (96 B) for 64-byte payloads, r = 2 (32 B, no padding) for 32-byte payloads.
+constexpr int pitch_bytes(int payload) { return payload == 64 ? 96 : (payload == 32 ? 32 : payload + 16); }
+constexpr int wrow_bytes(int granules) { return ((granules * 16) % 256 == 64) ? granules * 16 + 32 : granules * 16 + 16; }
+
 enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
 
 struct Gather {               // how the (virtual) conv input is read from the stored sources
@@ -89,7 +96,7 @@ template <typename T, int NG>
 __device__ __forceinline__ void stage_patch(const Gather& g, int s, int c0, int b, int iy0, int ix0, int PH, int PW,
                                             char* sP) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int PIXP = (NG + 1) * 16;
+    constexpr int PIXP = pitch_bytes(NG * 16);
     const int total = PH * PW * NG;
     const char* base = g.src[s];
     const int C = g.C[s], Hs = g.Hs[s], Ws = g.Ws[s], mode = g.mode[s];
@@ -119,8 +126,8 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     constexpr int CK = NG * G;
     constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
     constexpr int STEPS = (NGR + 3) / 4;           // MFMA k-groups (4 granules each) per chunk
-    constexpr int WROW = (STEPS * 4 + 1) * 16;     // weight-row pitch in LDS (bytes)
-    constexpr int PIXP = (NG + 1) * 16;            // patch-pixel pitch in LDS (bytes)
+    constexpr int WROW = wrow_bytes(STEPS * 4);     // weight-row pitch in LDS (bytes)
+    constexpr int PIXP = pitch_bytes(NG * 16);     // patch-pixel pitch in LDS (bytes)
     constexpr int NF = BN / 16;
     constexpr int OUTP = BN + 4;                   // epilogue row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,17 +172,50 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
     u32x4 wv[WIT], pv[PPF];
 
+    // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread:
+    // byte offsets of this thread's weight granules (inside a.w, chunk 0) and of its patch granules inside the
+    // image of each source (-1 = zero fill).  Per chunk only `+ k*CK*ES` (weights) / `+ c0*ES` (patch) remains.
+    int woff[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NT + tid;
+        const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
+        woff[it] = -1;
+        if (i < WTOT && gi < NGR && n0 + n < a.N) {
+            const int tap = gi / NG, cg = gi - tap * NG;
+            woff[it] = (((n0 + n) * 9 + tap) * a.Ctot + cg * G) * ES;
+        }
+    }
+    const char* img[2];
+    int poff[2][PPF];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
+        img[sidx] = a.g.src[sidx] + (size_t)b * Hs * Ws * Cs * ES;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            const int pix = i / NG, cg = i - pix * NG;
+            const int py = pix / PW, px = pix - py * PW;
+            const int vy = iy0 + py, vx = ix0 + px;
+            bool inb = (Cs > 0) && (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
+            int sy = vy, sx = vx;
+            if (mode != MODE_DIRECT) {
+                if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
+                sy = vy >> 1; sx = vx >> 1;
+            }
+            inb = inb && (sy < Hs) && (sx < Ws);
+            poff[sidx][it] = inb ? ((sy * Ws + sx) * Cs + cg * G) * ES : -1;
+        }
+    }
+
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
     auto load_w = [&](int k) {
+        const char* wk = a.w + (size_t)k * CK * ES;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
-            const int i = it * NT + tid;
-            const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (i < WTOT && gi < NGR && n0 + n < a.N) {
-                const int tap = gi / NG, cg = gi - tap * NG;
-                v = ld16(a.w + (((size_t)(n0 + n) * 9 + tap) * a.Ctot + k * CK + cg * G) * ES);
-            }
+            if (woff[it] >= 0) v = ld16(wk + woff[it]);
             wv[it] = v;
         }
     };
@@ -186,7 +226,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
             if (i < WTOT) { const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4); st16(sW + n * WROW + gi * 16, wv[it]); }
         }
     };
-    auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {
+    auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
         const int pix = i / NG, cg = i - pix * NG;
         const int py = pix / PW, px = pix - py * PW;
         const int vy = iy0 + py, vx = ix0 + px;
@@ -200,14 +240,20 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
         const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx];
         inb = inb && (sy < Hs) && (sx < Ws);
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (inb) v = ld16(a.g.src[sidx] + ((((size_t)b * Hs + sy) * Ws + sx) * a.g.C[sidx] + c0 + cg * G) * ES);
+        if (inb) v = ld16(img[sidx] + ((size_t)(sy * Ws + sx) * a.g.C[sidx] + c0 + cg * G) * ES);
         return v;
     };
     auto load_p = [&](int k) {
         int sidx, c0;
         chunk_src(k, sidx, c0);
+        const char* base = img[sidx] + c0 * ES;
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) pv[it] = patch_granule(sidx, c0, it * NT + tid);
+        for (int it = 0; it < PPF; ++it) {
+            const int o = sidx ? poff[1][it] : poff[0][it];
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (o >= 0) v = ld16(base + o);
+            pv[it] = v;
+        }
     };
     auto store_p = [&](int k) {
 #pragma unroll
@@ -238,35 +284,45 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
         store_p(k);
         __syncthreads();
         if (k + 1 < nch) { load_w(k + 1); load_p(k + 1); }    // in flight during the MFMAs below
+        // MFMA phase: the fragments of k-group m+1 are read from LDS BEFORE the MFMAs of k-group m are issued
+        // (two register sets), so the ~150-cycle LDS latency hides under the matrix pipe even at one wave per SIMD.
+        {
+            u32x4 av[2][2], bv[2][NF];
+            auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
+                const int gi = 4 * m + kg;
+                int tap = gi / NG;
+                const int cg = gi - tap * NG;
+                tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
+                const int ky = tap / 3, kx = tap - 3 * ky;
+                const int aoff = (ky * PW + kx) * PIXP + cg * 16;
 #pragma unroll
-        for (int m = 0; m < STEPS; ++m) {
-            const int gi = 4 * m + kg;
-            int tap = gi / NG;
-            const int cg = gi - tap * NG;
-            tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int aoff = (ky * PW + kx) * PIXP + cg * 16;
-            u32x4 av[2], bv[NF];
+                for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
+                for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+            };
+            read_frags(0, av[0], bv[0]);
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
-            if constexpr (ES == 2) {
-#pragma unroll
-                for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                    for (int nf = 0; nf < NF; ++nf)
-                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int m = 0; m < STEPS; ++m) {
+                const int cur = m & 1;
+                if (m + 1 < STEPS) read_frags(m + 1, av[cur ^ 1], bv[cur ^ 1]);
+                if constexpr (ES == 2) {
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
-                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, av[cur][mf]), __builtin_bit_cast(bf16x8, bv[cur][nf]),
+                                acc[mf][nf], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf)
+                                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    __uint_as_float(av[cur][mf][j]), __uint_as_float(bv[cur][nf][j]), acc[mf][nf], 0, 0, 0);
+                }
             }
         }
     }
@@ -365,7 +421,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     constexpr int NCOL = 9 * CK;                   // (tap, c) columns of this chunk
     constexpr int NFR = (NCOL + 15) / 16;          // column fragments
     constexpr int FPW = (NFR + 3) / 4;             // fragments per wave
-    constexpr int PIXP = (NG + 1) * 16;
+    constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int DYP = 16 * MT * ES + 16;         // dY row pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sDY = smem;                              // [BM][16*MT]
@@ -603,7 +659,7 @@ Tile pick_tile(int Ho, int Wo, int stride, bool even) {
 template <typename T, int BN, int NG>
 int launch_conv(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
-    constexpr int WROW = (STEPS * 4 + 1) * 16, PIXP = (NG + 1) * 16;
+    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
     size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
@@ -648,7 +704,7 @@ int launch_conv_t(const ConvK& k, int B, hipStream_t s) {
 template <typename T, int MT, int NG>
 int launch_wgrad(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G, PIXP = (NG + 1) * 16, DYP = 16 * MT * ES + 16;
+    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
     const size_t lds = (size_t)BM * DYP + (size_t)PH * PW * PIXP + 64;

@@ -1,0 +1,86 @@
+"""hipGraph-captured DCDP training step (BASELINE configs[4]: "hipGraph-captured train step").
+
+At B=8 the step is ~170 kernel launches of 5-50 us each; the Python / launch path (~2.5 ms) is then longer than
+the GPU work.  Every entry point of libcolvo only enqueues on the given stream (no allocation, no sync, step counter
+and loss state on the device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused loss, backward with
+its weight-gradient side stream (fork/join by events), optional RCCL buckets, fused Adam -- is captured once into a
+hipGraph (torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch.
+
+Inputs live in static device buffers (`frames` = [2B,3,H,W]: target frames then reference frames, `K`); the caller
+writes the next batch into them (or passes tensors to __call__, which copies) and replays.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .functional import photometric_loss
+
+
+class GraphedTrainStep:
+    def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
+                 warmup: int = 2):
+        dev = depth_net.flat_param.device
+        self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
+        self.B, self.ssim_weight = B, ssim_weight
+        self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
+        self.K = torch.zeros(B, 3, 3, device=dev)
+        self.loss = torch.zeros((), device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._warmup = warmup
+
+    # one eager step on the static buffers
+    def _step(self) -> torch.Tensor:
+        B = self.B
+        self.opt.zero_grad()
+        d = self.depth_net(self.frames)
+        d_t, d_r = d[:B], d[B:]
+        tgt, ref = self.frames[:B], self.frames[B:]
+        pose, a, b = self.pose_net(tgt, ref, d_t, d_r)
+        loss = photometric_loss(tgt, ref, d_t, pose, self.K, a, b, ssim_weight=self.ssim_weight)
+        loss.backward()
+        if self.ddp is not None:
+            self.ddp.finish()
+        self.opt.step()
+        return loss.detach()
+
+    def capture(self) -> None:
+        """Warm up (kernel attribute setup, side streams, allocator pools) without side effects, then capture."""
+        nets = (self.depth_net, self.pose_net)
+        snap_p = [n.flat_param.clone() for n in nets]
+        snap_o = [{k: v.clone() for k, v in st.items()} for st in self.opt.state]
+        side = torch.cuda.Stream(device=self.frames.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self._warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        def restore():
+            with torch.no_grad():
+                for n, p in zip(nets, snap_p):
+                    n.flat_param.copy_(p)
+                    n.mark_params_changed()
+                for st, src in zip(self.opt.state, snap_o):
+                    for k in st:
+                        st[k].copy_(src[k])
+        restore()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._step()
+            self.loss.copy_(out)
+        self.graph = g
+        restore()          # capture itself does not execute, but keep the state exactly as the caller left it
+        torch.cuda.synchronize()
+
+    def __call__(self, frames: Optional[torch.Tensor] = None, K: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.graph is None:
+            self.capture()
+        if frames is not None:
+            self.frames.copy_(frames, non_blocking=True)
+        if K is not None:
+            self.K.copy_(K, non_blocking=True)
+        self.graph.replay()
+        return self.loss

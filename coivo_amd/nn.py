@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -62,7 +64,7 @@ class _ArenaModule(nn.Module):
         self._pack_table = None
         self._pack_dtype = None
         self._side = None
-        self.overlap_wgrad = True
+        self.overlap_wgrad = os.environ.get("COLVO_NO_OVERLAP") is None
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
 
     # ---- arena ------------------------------------------------------------------------------- #
