@@ -32,10 +32,20 @@ __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+// Sum over the 64 lanes, result in every lane.  Row rotations by DPP (row_ror: VALU only, no LDS crossbar
+// round trip as with ds_bpermute-based shuffles), then the four 16-lane row totals through scalar registers.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+#define COLVO_ROR(x, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (n), 0xf, 0xf, false))
+    v += COLVO_ROR(v, 8);
+    v += COLVO_ROR(v, 4);
+    v += COLVO_ROR(v, 2);
+    v += COLVO_ROR(v, 1);
+#undef COLVO_ROR
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // bf16 <-> f32 on raw 16-bit storage

@@ -129,6 +129,54 @@ __global__ __launch_bounds__(NT) void k_depth_head_fwd(const void* __restrict__ 
     depth[(size_t)b * H * W + pix] = 1.0f / (lo + (hi - lo) * sig);
 }
 
+// C = 16 specialisation: one 16-channel pixel is 32 B (bf16) / 64 B (f32) -> 16-byte vector loads, weights in LDS
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_fwd16(const void* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int H, int W, float lo, float hi,
+                                                         float* __restrict__ depth) {
+    constexpr int C = 16;
+    __shared__ float sw[9 * C];
+    if (threadIdx.x < 9 * C) sw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)H * W) return;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    float acc = bias[0];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y2 = yy + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int x2 = xx + kx - 1;
+            if (y2 < 0 || y2 >= H || x2 < 0 || x2 >= W) continue;
+            const char* p = reinterpret_cast<const char*>(x) + ((((size_t)b * H + y2) * W + x2) * C) * ES;
+            const float* wt = sw + (ky * 3 + kx) * C;
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(p + 16 * v);
+                    const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc = fmaf(__uint_as_float(u[k] << 16), wt[8 * v + 2 * k], acc);
+                        acc = fmaf(__uint_as_float(u[k] & 0xFFFF0000u), wt[8 * v + 2 * k + 1], acc);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(p + 16 * v);
+                    acc = fmaf(q.x, wt[4 * v], acc); acc = fmaf(q.y, wt[4 * v + 1], acc);
+                    acc = fmaf(q.z, wt[4 * v + 2], acc); acc = fmaf(q.w, wt[4 * v + 3], acc);
+                }
+            }
+        }
+    }
+    const float sig = 1.0f / (1.0f + expf(-acc));
+    depth[(size_t)b * H * W + pix] = 1.0f / (lo + (hi - lo) * sig);
+}
+
 // d(pre) from the saved depth:  sig = (1/depth - lo)/(hi-lo);  d depth/d pre = -(hi-lo) depth^2 sig (1-sig)
 __device__ __forceinline__ float head_dpre(float depth, float d_depth, float lo, float hi) {
     const float k = hi - lo;
@@ -257,7 +305,8 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad_generic(const void* __r
 }
 
 // ---------------------------------------------------------------- PoseNet head --------------- //
-// out[b][j] = s_j * (bias_j + mean_p sum_c x[b][p][c] w[j][c]) (+1 for j = 6);  s = pose_scale (j<6) | lcc_scale
+// o_j = s_j * (bias_j + mean_p sum_c x[b][p][c] w[j][c]) (+1 for j = 6);  s = pose_scale (j<6) | lcc_scale.
+// Output is PLANAR: out = [ pose B x 6 | lcc_a B | lcc_b B ], so the three results are contiguous views.
 template <int ES>
 __global__ __launch_bounds__(NT) void k_pose_head_fwd(const void* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bias, int HW, int C, float pose_scale,
@@ -283,19 +332,24 @@ __global__ __launch_bounds__(NT) void k_pose_head_fwd(const void* __restrict__ x
         const float pre = bias[tid] + ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) / (float)HW;
         float o = (tid < 6 ? pose_scale : lcc_scale) * pre;
         if (tid == 6) o += 1.0f;
-        out[b * 8 + tid] = o;
+        const int B = gridDim.x;
+        if (tid < 6) out[b * 6 + tid] = o;
+        else out[6 * B + (tid - 6) * B + b] = o;
     }
 }
 
 template <int ES>
 __global__ __launch_bounds__(NT) void k_pose_head_bwd(const void* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ d_out, int HW, int C, float pose_scale,
+                                                      const float* __restrict__ d_pose, const float* __restrict__ d_a,
+                                                      const float* __restrict__ d_b, int HW, int C, float pose_scale,
                                                       float lcc_scale, void* __restrict__ dx, float* __restrict__ dw,
                                                       float* __restrict__ db) {
     const int b = blockIdx.x, tid = threadIdx.x;
     float go[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) go[j] = d_out[b * 8 + j] * (j < 6 ? pose_scale : lcc_scale);
+    for (int j = 0; j < 6; ++j) go[j] = d_pose ? d_pose[b * 6 + j] * pose_scale : 0.0f;
+    go[6] = d_a ? d_a[b] * lcc_scale : 0.0f;
+    go[7] = d_b ? d_b[b] * lcc_scale : 0.0f;
     const float inv = 1.0f / (float)HW;
     for (int c = tid; c < C; c += NT) {
         float g = 0.0f;
@@ -419,8 +473,13 @@ extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, co
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
                     "colvo_depth_head_fwd: bad shape / range");
     const size_t HW = (size_t)H * W;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float),
-                                          (hipStream_t)stream, x, w, bias, H, W, C, 1.0f / max_depth, 1.0f / min_depth, depth));
+    if (C == 16) {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd16<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, x,
+                                              w, bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth));
+    } else {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float),
+                                              (hipStream_t)stream, x, w, bias, H, W, C, 1.0f / max_depth, 1.0f / min_depth, depth));
+    }
     COLVO_CHECK_LAUNCH("k_depth_head_fwd");
     return 0;
 }
@@ -464,13 +523,13 @@ extern "C" int colvo_pose_head_fwd(int dtype, const void* x, const float* w, con
     return 0;
 }
 
-extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_out, int B, int HW, int C,
-                                   float pose_scale, float lcc_scale, void* dx, float* dw, float* db,
-                                   colvo_stream_t stream) {
-    COLVO_CHECK_ARG(x && w && d_out && dx && dw && db && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_bwd: bad arguments");
+extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a,
+                                   const float* d_b, int B, int HW, int C, float pose_scale, float lcc_scale, void* dx,
+                                   float* dw, float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && dx && dw && db && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_bwd: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd: bad dtype");
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_out, HW,
-                                          C, pose_scale, lcc_scale, dx, dw, db));
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_pose, d_a,
+                                          d_b, HW, C, pose_scale, lcc_scale, dx, dw, db));
     COLVO_CHECK_LAUNCH("k_pose_head_bwd");
     return 0;
 }

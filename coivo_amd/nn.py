@@ -64,6 +64,7 @@ class _ArenaModule(nn.Module):
         self._pack_table = None
         self._pack_dtype = None
         self._side = None
+        self._plans = {}
         self.overlap_wgrad = os.environ.get("COLVO_NO_OVERLAP") is None
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
 
@@ -232,7 +233,10 @@ class DepthNet(_ArenaModule):
     # ---- whole-network forward / backward ---------------------------------------------------- #
     def _plan(self, B, H, W):
         dt = self.compute_dtype
-        P = {}
+        key = (B, H, W, dt)
+        if key in self._plans:
+            return self._plans[key]
+        P = self._plans[key] = {}
         h, w, cin = H, W, 8
         for i, c in enumerate(ENC_CH, start=1):
             P[f"enc{i}a"] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
@@ -345,11 +349,11 @@ class PoseNet(_ArenaModule):
             setattr(self, f"conv{i}", ConvParams(cin, c, 3))
             cin = c
         self.pred = ConvParams(cin, 8, 1)
+        self.overlap_wgrad = False      # 7 tiny layers: the fork/join bookkeeping costs more than it hides
         self._build_arena(torch.device(device))
 
     def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):
-        out = _PoseNetFn.apply(self, tgt, ref, tgt_depth, ref_depth, self._trigger())
-        return out[:, 0:6], out[:, 6:7], out[:, 7:8]
+        return _PoseNetFn.apply(self, tgt, ref, tgt_depth, ref_depth, self._trigger())
 
     def _forward_impl(self, tgt, ref, d_t, d_r):
         B, _, H, W = tgt.shape
@@ -366,24 +370,30 @@ class PoseNet(_ArenaModule):
         srcs = [tgt, ref] + ([d_t.contiguous(), d_r.contiguous()] if d_t is not None else [])
         x = ops.pack_nchw(srcs, 8, dt)
         A = {"in": x}
-        P = {}
-        h, w, cin = H, W, 8
-        for i, c in enumerate(POSE_CH, start=1):
-            P[i] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
+        key = (B, H, W, dt)
+        P = self._plans.get(key)
+        if P is None:
+            P = self._plans[key] = {}
+            h, w, cin = H, W, 8
+            for i, c in enumerate(POSE_CH, start=1):
+                P[i] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
+                h, w, cin = P[i].Ho, P[i].Wo, c
+        for i in range(1, 8):
             x = _conv(x, getattr(self, f"conv{i}"), P[i])
             A[i] = x
-            h, w, cin = P[i].Ho, P[i].Wo, c
-        out = torch.empty(B, 8, device=tgt.device, dtype=torch.float32)
+        out = torch.empty(8 * B, device=tgt.device, dtype=torch.float32)     # planar: [pose Bx6 | a B | b B]
         ops.pose_head_fwd(x, self.pred.w_master, self.pred.bias.data, out)
         return out, (A, P, (B, H, W), d_t is not None)
 
-    def _backward_impl(self, saved, d_out):
+    def _backward_impl(self, saved, d_pose, d_a, d_b):
         A, P, (B, H, W), has_depth = saved
         self.attach_grads()
         self._bwd_begin()
         x = A[7]
         g = torch.empty_like(x)
-        ops.pose_head_bwd(x, self.pred.w_master, d_out.contiguous(), g, self.pred.g_master, self.pred.g_bias)
+        ops.pose_head_bwd(x, self.pred.w_master, None if d_pose is None else d_pose.contiguous(),
+                          None if d_a is None else d_a.contiguous(), None if d_b is None else d_b.contiguous(),
+                          g, self.pred.g_master, self.pred.g_bias)
         self._layer_done(self.pred)
         for i in range(7, 0, -1):
             L = getattr(self, f"conv{i}")
@@ -409,11 +419,13 @@ class _PoseNetFn(torch.autograd.Function):
     def forward(ctx, net: PoseNet, tgt, ref, d_t, d_r, trigger):
         out, saved = net._forward_impl(tgt, ref, d_t, d_r)
         ctx.net, ctx.saved = net, saved
-        return out
+        B = tgt.shape[0]
+        # three contiguous views of the planar head output: no slicing kernels forward or backward
+        return out[:6 * B].view(B, 6), out[6 * B:7 * B].view(B, 1), out[7 * B:].view(B, 1)
 
     @staticmethod
-    def backward(ctx, d_out):
-        d_t, d_r = ctx.net._backward_impl(ctx.saved, d_out)
+    def backward(ctx, d_pose, d_a, d_b):
+        d_t, d_r = ctx.net._backward_impl(ctx.saved, d_pose, d_a, d_b)
         ctx.saved = None
         return None, None, None, d_t, d_r, None
 

@@ -132,6 +132,7 @@ def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
 
 
 def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> None:
+    """out: 8*B floats, planar [pose Bx6 | lcc_a B | lcc_b B]."""
     _need_cuda(x, w, bias, out)
     B, H, W, Cc = x.shape
     lib = _lib.load()
@@ -139,13 +140,14 @@ def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: tor
                                        POSE_SCALE, LCC_SCALE, _lib.ptr(out), _lib.stream_ptr()), "colvo_pose_head_fwd")
 
 
-def pose_head_bwd(x, w, d_out, dx, dw, db) -> None:
-    _need_cuda(x, w, d_out, dx, dw, db)
+def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db) -> None:
+    """d_pose [B,6] / d_a [B,1] / d_b [B,1] contiguous or None (= zero)."""
+    _need_cuda(x, w, d_pose, d_a, d_b, dx, dw, db)
     B, H, W, Cc = x.shape
     lib = _lib.load()
-    _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_out), B, H * W, Cc,
-                                       POSE_SCALE, LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db),
-                                       _lib.stream_ptr()), "colvo_pose_head_bwd")
+    _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_pose), _lib.ptr(d_a),
+                                       _lib.ptr(d_b), B, H * W, Cc, POSE_SCALE, LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw),
+                                       _lib.ptr(db), _lib.stream_ptr()), "colvo_pose_head_bwd")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:

@@ -141,11 +141,13 @@ int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* 
                          void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.
- * out[B,8] = { pose[6], lcc_a, lcc_b }; backward takes d_out[B,8]. */
+ * out (8*B floats) is PLANAR: [ pose B x 6 | lcc_a B | lcc_b B ] so the three results are contiguous views;
+ * backward takes the three gradients separately (each may be NULL = zero). */
 int colvo_pose_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int HW, int C,
                         float pose_scale, float lcc_scale, float* out, colvo_stream_t stream);
-int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_out, int B, int HW, int C,
-                        float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream);
+int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a,
+                        const float* d_b, int B, int HW, int C, float pose_scale, float lcc_scale,
+                        void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * a8  Adam over the flat parameter arena (torch.optim.Adam semantics, no weight decay)         *

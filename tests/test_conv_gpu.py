@@ -198,13 +198,15 @@ def test_pose_head(dtype):
     out_ref.backward(do)
     d = dev()
     xd = _nhwc(x).to(d, dtype)
-    out = torch.empty(B, 8, device=d)
+    out = torch.empty(8 * B, device=d)
     ops.pose_head_fwd(xd, w.to(d), bias.to(d), out)
-    _close(out, out_ref, 1e-5, 1e-5, "pose head fwd")
+    got = torch.cat([out[:6 * B].view(B, 6), out[6 * B:7 * B].view(B, 1), out[7 * B:].view(B, 1)], 1)   # planar -> [B,8]
+    _close(got, out_ref, 1e-5, 1e-5, "pose head fwd")
     dx = torch.empty_like(xd)
     dw = torch.zeros(8, 1, Cc, device=d)
     db = torch.zeros(8, device=d)
-    ops.pose_head_bwd(xd, w.to(d), do.to(d), dx, dw, db)
+    dod = do.to(d)
+    ops.pose_head_bwd(xd, w.to(d), dod[:, :6].contiguous(), dod[:, 6:7].contiguous(), dod[:, 7:8].contiguous(), dx, dw, db)
     rt = 1e-4 if dtype == torch.float32 else 2e-2
     _close(_nchw(dx), xr.grad * (x > 0), rt, rt, "pose head dx")
     _close(dw, wr.grad, 1e-4, 1e-4, "pose head dw")
