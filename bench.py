@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-roofline-cfg2", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=16)
     ap.add_argument("--grad-transport", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="test hook: all ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks on one device)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from one captured hipGraph; auto = off: measured 2.94 ms replayed vs 2.69 ms eager at "
                          "B=8 (the step is bound by per-kernel latency, not by the host, and replay loses part of the "
@@ -148,13 +150,18 @@ def main():
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from coivo_amd import functional as Fh
     from coivo_amd import nn as hnn

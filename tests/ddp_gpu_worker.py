@@ -1,0 +1,78 @@
+"""Worker for tests/test_ddp_gpu.py: launched by torch.distributed.run with 2 ranks that SHARE cuda:0 (the test box has one
+GPU; RCCL cannot put two ranks on one device, so the rehearsal carries the CUDA tensors over gloo).  Exercises the real
+HIP networks: backward hooks in true layer order, weight gradients on the side stream, bucketed async all-reduce,
+finish(), grad_scale in the fused Adam."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from coivo_amd import nn as hnn
+    from coivo_amd import synth
+    from coivo_amd.ddp import GradBuckets
+    from coivo_amd.optim import FusedAdam
+    from oracle import colvo_spec as S
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    B, H, W, seed = 1, 64, 96, 71
+    dn_o, pn_o = S.make_models(seed)
+
+    def fresh():
+        dn, pn = hnn.DepthNet(device=dev), hnn.PoseNet(device=dev)
+        dn.load_state_dict(dn_o.state_dict())
+        pn.load_state_dict(pn_o.state_dict())
+        return dn, pn
+
+    full = synth.make_batch(world * B, H, W, seed=seed, device=dev)
+    sl = slice(rank * B, (rank + 1) * B)
+    dn, pn = fresh()
+    opt = FusedAdam([dn, pn], lr=1e-4)
+    ddp = GradBuckets([dn, pn], bucket_bytes=2 << 20)          # several buckets per arena
+    opt.grad_scale = ddp.grad_scale
+    opt.zero_grad()
+    loss = hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl])[0]
+    loss.backward()
+    ddp.finish()
+    torch.cuda.synchronize()
+    g_dn, g_pn = dn.flat_grad.clone(), pn.flat_grad.clone()       # summed over ranks, in place in the arena
+    opt.step()
+    torch.cuda.synchronize()
+    # every rank must hold identical gradients and parameters
+    for t in (g_dn, dn.flat_param):
+        ref = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ref, t)
+        assert all(torch.equal(r, ref[0]) for r in ref), "ranks diverged"
+    if rank == 0:
+        # single-process reference: the per-rank batches accumulated into one arena
+        dn2, pn2 = fresh()
+        opt2 = FusedAdam([dn2, pn2], lr=1e-4)
+        opt2.grad_scale = 1.0 / world
+        opt2.zero_grad()
+        for r in range(world):
+            s2 = slice(r * B, (r + 1) * B)
+            hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2])[0].backward()
+        torch.cuda.synchronize()
+        for a, b, name in ((g_dn, dn2.flat_grad, "DepthNet"), (g_pn, pn2.flat_grad, "PoseNet")):
+            scale = b.abs().max().item()
+            err = (a - b).abs().max().item()
+            assert err < 2e-4 * scale, f"{name}: all-reduced gradient differs from the accumulated reference by {err} (scale {scale})"
+        opt2.step()
+        torch.cuda.synchronize()
+        # Adam's first step is sign-like (+-lr): float-atomic summation order may flip it on ~zero gradients only
+        d = (dn.flat_param - dn2.flat_param).abs()
+        assert d.max().item() <= 2.5e-4 and (d > 1e-6).float().mean().item() < 5e-3
+        print("DDP_OK", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

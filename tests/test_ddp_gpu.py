@@ -1,0 +1,42 @@
+"""-m gpu: 2-rank data-parallel rehearsal of the real HIP networks on the one available GPU (gloo transport), and the
+bench.py multi-process code path."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(args, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port())] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_rank_dp_on_one_gpu_matches_averaged_gradients():
+    r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DDP_OK" in r.stdout
+
+
+def test_bench_multiprocess_path():
+    r = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+              "--no-roofline-cfg2", "--batch-per-gpu", "2", "--height", "64", "--width", "96", "--rehearse-on-one-gpu"])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
