@@ -13,10 +13,10 @@
 //   forward : "marching wave" -- one wave per 62-column strip marches down the rows; horizontal window sums by
 //             DPP wave shifts, vertical by a rolling 3-row register window; no LDS, no barriers; loads of the next
 //             rows fly under the SSIM arithmetic of the current one.
-//   backward: one 256-thread workgroup per 64x16 tile; J = a*warp(ref)+b and T are evaluated once per tile slot
-//             (tile + 2-px halo; slots beyond the image border hold the REFLECTED pixel, which realises the SSIM
-//             reflection pad) and staged in LDS; per-window derivative coefficients and the 9-window gather run
-//             from LDS with sliding sums; the sample is recomputed for the chain rule.
+//   backward: the same marching organisation with two halo lanes / rows per side: three rolling 3-row register
+//             windows (evaluated sample, horizontal window sums, horizontally gathered derivative coefficients);
+//             every pixel is evaluated once, rows / columns beyond the image border hold the REFLECTED pixel,
+//             which realises the SSIM reflection pad.
 // HBM reads are row-contiguous per plane (lanes = consecutive columns); the 4-tap gather of `ref` is served by
 // L1/L2 for smooth flows; loads are buffer loads (32-bit lane offset + scalar plane offset).
 #include <type_traits>
@@ -26,8 +26,6 @@
 namespace colvo {
 namespace {
 
-constexpr int TW = 64;   // tile width  (= wave width: one lane per column)
-constexpr int TH = 16;   // tile height (4 row-groups of 4 rows)
 constexpr int NT = 256;
 constexpr float SSIM_C1 = 0.01f * 0.01f;
 constexpr float SSIM_C2 = 0.03f * 0.03f;
@@ -178,39 +176,7 @@ __device__ __forceinline__ Taps make_taps(const Proj& p, int H, int W) {
     return t;
 }
 
-// a4 + a5 for one pixel: J[c] = a * bilinear(ref_c) + b  (warp = 0 where invalid)
-template <bool WITH_GRAD>
-__device__ __forceinline__ void sample_px(const Geo& g, const Img& im, const Proj& p, int H, int W, float J[3],
-                                          float Wp[3], float gx[3], float gy[3]) {
-    if (p.valid) {
-        const Taps t = make_taps(p, H, W);
-        const float ux = 1.0f - t.wx, uy = 1.0f - t.wy;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int so = c * im.plane4;
-            const float i00 = bload(im.ref, t.o00, so), i01 = bload(im.ref, t.o01, so);
-            const float i10 = bload(im.ref, t.o10, so), i11 = bload(im.ref, t.o11, so);
-            const float top = fmaf(i01, t.wx, i00 * ux);
-            const float bot = fmaf(i11, t.wx, i10 * ux);
-            const float w = fmaf(bot, t.wy, top * uy);
-            Wp[c] = w;
-            J[c] = fmaf(g.a, w, g.b);
-            if (WITH_GRAD) {
-                gx[c] = fmaf(t.wy, i11 - i10, uy * (i01 - i00));
-                gy[c] = fmaf(t.wx, i11 - i01, ux * (i10 - i00));
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            Wp[c] = 0.0f;
-            J[c] = g.b;
-            if (WITH_GRAD) { gx[c] = 0.0f; gy[c] = 0.0f; }
-        }
-    }
-}
-
-// Branch-free variant for batched evaluation: invalid points read tap (0,0) with zero weights.
+// Branch-free taps: invalid points read tap (0,0) with zero weights (the result is masked).
 __device__ __forceinline__ Taps make_taps_safe(const Proj& p, int H, int W) {
     Taps t;
     const float xs = p.valid ? p.x : 0.0f, ys = p.valid ? p.y : 0.0f;
@@ -223,58 +189,6 @@ __device__ __forceinline__ Taps make_taps_safe(const Proj& p, int H, int W) {
     t.o00 = (y0 * W + x0) * 4; t.o01 = t.o00 + dx;
     t.o10 = t.o00 + dy; t.o11 = t.o10 + dx;
     return t;
-}
-
-// Evaluate N slots with every global load of the batch in flight together: depth + target first (they
-// depend on nothing), then all 12 N reference taps, then the blends.  No branches, so the compiler keeps
-// it one basic block and the two dependent memory round trips are paid once per batch, not once per slot.
-template <int N, bool WITH_GRAD>
-__device__ __forceinline__ void eval_batch(const Geo& g, const Img& im, const int (&px)[N], const int (&py)[N], int H,
-                                           int W, Proj (&p)[N], float (&dv)[N], float (&J)[N][3], float (&T)[N][3],
-                                           float (&Wp)[N][3], float (&gx)[N][3], float (&gy)[N][3]) {
-    int o4[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        o4[n] = (py[n] * W + px[n]) * 4;
-        dv[n] = bload(im.dep, o4[n], 0);
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) T[n][c] = bload(im.tgt, o4[n], c * im.plane4);
-    Taps t[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        p[n] = project_px(g, dv[n], px[n], py[n], H, W);
-        t[n] = make_taps_safe(p[n], H, W);
-    }
-    float v[N][3][4];
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int so = c * im.plane4;
-            v[n][c][0] = bload(im.ref, t[n].o00, so); v[n][c][1] = bload(im.ref, t[n].o01, so);
-            v[n][c][2] = bload(im.ref, t[n].o10, so); v[n][c][3] = bload(im.ref, t[n].o11, so);
-        }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const float m = p[n].valid ? 1.0f : 0.0f;
-        const float ux = 1.0f - t[n].wx, uy = 1.0f - t[n].wy;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float i00 = v[n][c][0], i01 = v[n][c][1], i10 = v[n][c][2], i11 = v[n][c][3];
-            const float top = fmaf(i01, t[n].wx, i00 * ux);
-            const float bot = fmaf(i11, t[n].wx, i10 * ux);
-            const float w = m * fmaf(bot, t[n].wy, top * uy);
-            Wp[n][c] = w;
-            J[n][c] = fmaf(g.a, w, g.b);
-            if (WITH_GRAD) {
-                gx[n][c] = m * fmaf(t[n].wy, i11 - i10, uy * (i01 - i00));
-                gy[n][c] = m * fmaf(t[n].wx, i11 - i01, ux * (i10 - i00));
-            }
-        }
-    }
 }
 
 // SSIM pieces from the five 3x3 window SUMS of one channel (x = target, y = J), everything scaled by
@@ -309,15 +223,15 @@ constexpr int MROWS_MAX = 64;
 
 // Rows per segment: the grid should fill the chip's resident-wave slots (256 CUs x 16 waves at 4 waves/SIMD) in
 // whole rounds -- a 1.4-round grid costs 2 rounds -- while keeping the 2 halo rows + pipeline prologue cheap.
-inline int pick_march_rows(int B, int H, int W) {
-    const long strips = (W + MCOLS - 1) / MCOLS;
-    const long cap = 256 * 16;
+inline int pick_march_rows(int B, int H, int W, int cols = MCOLS, int halo_rows = 2, int waves_per_cu = 16) {
+    const long strips = (W + cols - 1) / cols;
+    const long cap = 256L * waves_per_cu;
     int best = 32;
     double best_cost = 1e30;
     for (int r = 4; r <= MROWS_MAX; ++r) {
         const long waves = (long)B * ((H + r - 1) / r) * strips;
         const long rounds = (waves + cap - 1) / cap;
-        const double cost = (double)rounds * (r + 2 + 2.0);      // steps per wave + ~2 steps of prologue / epilogue
+        const double cost = (double)rounds * (r + halo_rows + 2.0);      // steps per wave + ~2 steps of prologue / epilogue
         if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
     }
     return best;
@@ -501,251 +415,257 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd_finalize(const float* __re
     }
 }
 
-// --------------------------------------------------------------------------------------------- //
-// backward                                                                                       //
-// --------------------------------------------------------------------------------------------- //
-// Per tile:  (1) J, T of tile + 2-px halo -> LDS;  per channel: (2) derivative coefficients of every
-// SSIM window (tile + 1-px halo) from sliding sums -> LDS, (3) every pixel gathers, with the reflection
-// multiplicities, from the 9 windows that contain it -> dJ in registers;  (4) the sample is RECOMPUTED
-// (taps are L1/L2 hits) to chain dJ through LCC, the bilinear taps and the projection.  Only dJ[4][3]
-// lives across the phases, which keeps the kernel at <= 128 VGPRs (2 workgroups per SIMD set).
-constexpr int BSW = TW + 4, BSH = TH + 4;   // J/T slots incl. 2-px halo
-constexpr int WSW = TW + 2, WSH = TH + 2;   // window centres incl. 1-px halo
 constexpr int NPART = 14;                   // dt[3], dR[9], da, db
 
-__global__ __launch_bounds__(NT, 3) void k_warp_loss_bwd(
-    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
-    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
-    const float* __restrict__ lcc_b, int H, int W, int tiles_x, int tiles_y, float alpha,
-    const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
-    float* __restrict__ partials) {
-    __shared__ float sJ[3][BSH][BSW];
-    __shared__ float sT[3][BSH][BSW];
-    __shared__ float sM[WSH][WSW];       // validity mask of each window centre (0 outside the image)
-    __shared__ float sK[3][WSH][WSW];    // per-window derivative coefficients of the current channel
-    __shared__ float s_geo[GEO_N + 2];
+// --------------------------------------------------------------------------------------------- //
+// backward: "marching wave"                                                                      //
+// --------------------------------------------------------------------------------------------- //
+// Same organisation as the forward: one wave per strip (60 output columns, lanes 2..61; two halo lanes per side)
+// marching down `seg_rows` output rows (+2 halo rows per side).  Three rolling 3-row register windows carry
+//   E  : the evaluated sample of a row (warp, its x/y derivatives, the projected point, depth, validity),
+//   H  : the horizontal 3-sums of {T, J, T^2, J^2, TJ} per channel (DPP wave shifts),
+//   HK : the horizontally gathered derivative coefficients of the SSIM windows (reflection multiplicities),
+// so that at step j:  row j is evaluated, window row j-1 gets its coefficients, pixel row j-2 gets dJ and is
+// chained through LCC / bilinear taps / projection.  Every pixel is evaluated ONCE (the tile version needed
+// 2.3 evaluations), every window's coefficients are computed once, there is no LDS and no barrier.
+constexpr int BCOLS = 60;
 
-    const int tid = threadIdx.x;
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);      // logical id = (image * tiles_y + ty) * tiles_x + tx
-    const int tpi = tiles_x * tiles_y;
-    const int b = wid / tpi, trem = wid - b * tpi;
-    const int tyi = trem / tiles_x, txi = trem - tyi * tiles_x;
-    const int x0 = txi * TW, y0 = tyi * TH;
-    if (tid == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo);
-    __syncthreads();
-    const Geo g = geo_load(s_geo);
-    const float gscale = grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
+struct BwdState {
+    // in flight / just landed (slot = row % 3)
+    float dv[3], T[3][3];
+    float v[3][3][4], wx[3], wy[3];
+    // evaluated rows (T and depth are copied here when a row is consumed: their load slots are refilled one step
+    // later, but the pixel row needs them two steps later)
+    float Wp[3][3], gx[3][3], gy[3][3], Tk[3][3], dk[3], Px[3], Py[3], Pz[3], m[3];
+    float H[3][15];
+    float HK[3][9];
+    float part[NPART];
+};
 
-    const Img im = img_make(tgt, ref, depth, b, H, W);
-    const size_t plane = (size_t)H * W;
-
-    // phase 1: every slot of tile + 2-px halo (reflected where it leaves the image): 1360 slots, each thread
-    // takes 2 batches of 3 (loads of a batch in flight together); slot ids beyond the end are clamped and
-    // simply rewrite the last slot with the same values.
-#pragma unroll 1
-    for (int it = 0; it < 2; ++it) {
-        int px[3], py[3], ssy[3], ssx[3], uy[3], ux[3];
+template <int K>
+__device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& im, int j, int nrows, int y_first,
+                                         int gxcol, int px, bool own_col, float Xh, const float (&wxw)[3], int H,
+                                         int W, float kss, float kl1, float* __restrict__ d_depth_img) {
+    constexpr int K1 = (K + 1) % 3, K2 = (K + 2) % 3;
+    if (j >= nrows) return;                              // wave-uniform
+    // (1) consume the taps of row j: warp, its spatial derivatives, LCC
+    float Jc[3], Tc[3];
+    {
+        const float ux = 1.0f - st.wx[K], uy = 1.0f - st.wy[K], m = st.m[K];
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const int sl = min((it * 3 + n) * NT + tid, BSH * BSW - 1);
-            ssy[n] = sl / BSW; ssx[n] = sl - ssy[n] * BSW;
-            uy[n] = y0 + ssy[n] - 2; ux[n] = x0 + ssx[n] - 2;      // unreflected coordinate
-            py[n] = reflect_idx(uy[n], H); px[n] = reflect_idx(ux[n], W);
+        for (int c = 0; c < 3; ++c) {
+            const float i00 = st.v[K][c][0], i01 = st.v[K][c][1], i10 = st.v[K][c][2], i11 = st.v[K][c][3];
+            const float top = fmaf(i01, st.wx[K], i00 * ux);
+            const float bot = fmaf(i11, st.wx[K], i10 * ux);
+            const float w = m * fmaf(bot, st.wy[K], top * uy);
+            st.Wp[K][c] = w;
+            st.gx[K][c] = m * fmaf(st.wy[K], i11 - i10, uy * (i01 - i00));
+            st.gy[K][c] = m * fmaf(st.wx[K], i11 - i01, ux * (i10 - i00));
+            Jc[c] = fmaf(g.a, w, g.b);
+            Tc[c] = st.T[K][c];
+            st.Tk[K][c] = Tc[c];
         }
-        Proj p[3];
-        float dv[3], J[3][3], T[3][3], W3[3][3], dumx[3][3], dumy[3][3];
-        eval_batch<3, false>(g, im, px, py, H, W, p, dv, J, T, W3, dumx, dumy);
+        st.dk[K] = st.dv[K];
+    }
+    // rows j-2 and j+1 share a slot: snapshot what the chain rule of pixel row j-2 needs before (2) overwrites it
+    const float mp = st.m[K1], Pxv = st.Px[K1], Pyv = st.Py[K1], Pzv = st.Pz[K1];
+    // (2) issue the loads of the next rows (they fly under the arithmetic below)
+    if (j + 1 < nrows) {
+        const int py = reflect_idx(y_first + j + 1, H);
+        const Proj p = project_px(g, st.dv[K1], px, py, H, W);
+        const Taps t = make_taps_safe(p, H, W);
+        st.wx[K1] = t.wx; st.wy[K1] = t.wy; st.m[K1] = p.valid ? 1.0f : 0.0f;
+        st.Px[K1] = p.Px; st.Py[K1] = p.Py; st.Pz[K1] = p.Pz;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sJ[c][ssy[n]][ssx[n]] = J[n][c];
-                sT[c][ssy[n]][ssx[n]] = T[n][c];
-            }
-            const int wy = ssy[n] - 1, wx = ssx[n] - 1;
-            if (wy >= 0 && wy < WSH && wx >= 0 && wx < WSW) {
-                const bool exists = (uy[n] >= 0 && uy[n] < H && ux[n] >= 0 && ux[n] < W);
-                sM[wy][wx] = (exists && p[n].valid) ? 1.0f : 0.0f;
-            }
+        for (int c = 0; c < 3; ++c) {
+            const int so = c * im.plane4;
+            st.v[K1][c][0] = bload(im.ref, t.o00, so); st.v[K1][c][1] = bload(im.ref, t.o01, so);
+            st.v[K1][c][2] = bload(im.ref, t.o10, so); st.v[K1][c][3] = bload(im.ref, t.o11, so);
         }
     }
-    __syncthreads();
-
-    const int col = tid & 63, rg = tid >> 6;
-    // reflection multiplicities of the owned pixels (shared by the 3 channels)
-    float wyv[4][3], wxv[3];
-    {
-        const int px = x0 + col;
+    if (j + 2 < nrows) {
+        const int py = reflect_idx(y_first + j + 2, H);
+        const int o4 = (py * W + px) * 4;
+        st.dv[K2] = bload(im.dep, o4, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.T[K2][c] = bload(im.tgt, o4, c * im.plane4);
+    }
+    // (3) horizontal window sums of row j
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float J = Jc[c], T = Tc[c];
+        st.H[K][5 * c + 0] = hsum3(T);
+        st.H[K][5 * c + 1] = hsum3(J);
+        st.H[K][5 * c + 2] = hsum3(T * T);
+        st.H[K][5 * c + 3] = hsum3(J * J);
+        st.H[K][5 * c + 4] = hsum3(T * J);
+    }
+    // (4) derivative coefficients of window row j-1 (centre = row j-1, this lane's column), gathered horizontally
+    if (j >= 2) {
+        const int gyw = y_first + j - 1;
+        const bool wexists = (gyw >= 0) && (gyw < H) && (gxcol >= 0) && (gxcol < W);
+        const float wmask = wexists ? st.m[K2] : 0.0f;   // row j-1 = slot (j+2) % 3
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const SsimTerms s = ssim_terms(st.H[K1][5 * c + 0] + st.H[K2][5 * c + 0] + st.H[K][5 * c + 0],
+                                           st.H[K1][5 * c + 1] + st.H[K2][5 * c + 1] + st.H[K][5 * c + 1],
+                                           st.H[K1][5 * c + 2] + st.H[K2][5 * c + 2] + st.H[K][5 * c + 2],
+                                           st.H[K1][5 * c + 3] + st.H[K2][5 * c + 3] + st.H[K][5 * c + 3],
+                                           st.H[K1][5 * c + 4] + st.H[K2][5 * c + 4] + st.H[K][5 * c + 4]);
+            const float inv = nr_rcp(s.B1 * s.B2);
+            const float S = s.A1 * s.A2 * inv;
+            const float ss = 0.5f * (1.0f - S);
+            const float live = (ss > 0.0f && ss < 1.0f) ? wmask * kss : 0.0f;
+            const float A = live * 2.0f * (s.sx * (s.A2 - s.A1) - S * s.sy * (s.B2 - s.B1)) * inv;
+            const float Bc = live * -18.0f * S * (inv * s.B1);
+            const float Cc = live * 18.0f * s.A1 * inv;
+            st.HK[K2][3 * c + 0] = fmaf(wxw[0], dpp_from_left(A), fmaf(wxw[2], dpp_from_right(A), wxw[1] * A));
+            st.HK[K2][3 * c + 1] = fmaf(wxw[0], dpp_from_left(Bc), fmaf(wxw[2], dpp_from_right(Bc), wxw[1] * Bc));
+            st.HK[K2][3 * c + 2] = fmaf(wxw[0], dpp_from_left(Cc), fmaf(wxw[2], dpp_from_right(Cc), wxw[1] * Cc));
+        }
+    }
+    // (5) pixel row j-2 (slot K1): vertical gather of the coefficient rows j-3, j-2, j-1 -> dJ, then the chain rule
+    if (j >= 4) {
+        const int gyp = y_first + j - 2;
+        float wyw[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const int q = px + d - 1;
-            wxv[d] = (q >= 0 && q < W) ? window_mult(q, px, W) : 0.0f;
+            const int q = gyp + d - 1;
+            wyw[d] = (q >= 0 && q < H) ? window_mult(q, gyp, H) : 0.0f;
         }
+        const bool own = own_col && (j - 2 >= 2) && (j - 2 <= nrows - 3) && (gyp < H);
+        // slots: row j-3 -> K, row j-2 -> K1, row j-1 -> K2   (j-3 = j mod 3)
+        const float dprev2 = st.dk[K1];
+        float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int py = y0 + 4 * rg + i;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int q = py + d - 1;
-                wyv[i][d] = (q >= 0 && q < H) ? window_mult(q, py, H) : 0.0f;
-            }
+        for (int c = 0; c < 3; ++c) {
+            const float ha = wyw[0] * st.HK[K][3 * c + 0] + wyw[1] * st.HK[K1][3 * c + 0] + wyw[2] * st.HK[K2][3 * c + 0];
+            const float hb = wyw[0] * st.HK[K][3 * c + 1] + wyw[1] * st.HK[K1][3 * c + 1] + wyw[2] * st.HK[K2][3 * c + 1];
+            const float hc = wyw[0] * st.HK[K][3 * c + 2] + wyw[1] * st.HK[K1][3 * c + 2] + wyw[2] * st.HK[K2][3 * c + 2];
+            const float wv = st.Wp[K1][c];
+            const float Jp = fmaf(g.a, wv, g.b), Tp = st.Tk[K1][c];
+            const float diff = Jp - Tp;
+            const float sgn = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
+            const float dJ = fmaf(hb, Jp, fmaf(hc, Tp, ha)) + kl1 * mp * sgn;
+            da = fmaf(dJ, wv, da);
+            db += dJ;
+            const float dW = g.a * dJ;
+            gxs = fmaf(dW, st.gx[K1][c], gxs);
+            gys = fmaf(dW, st.gy[K1][c], gys);
         }
-    }
-
-    const float kss = gscale * alpha * (-0.5f);
-    const float kl1 = gscale * (1.0f - alpha);
-    // phase-2 role: 3 groups of 66 threads, each thread a column of 6 windows
-    const int wcol = tid % WSW, wgrp = tid / WSW;
-
-    float dJ[4][3];
-#pragma unroll 1   // rolled: keeps register pressure down; dJ is written through a uniform switch (static index)
-    for (int c = 0; c < 3; ++c) {
-        // phase 2: derivative coefficients of every window centre (tile + 1-px halo), sliding sums
-        if (wgrp < 3) {
-            float hx0 = 0.f, hx1 = 0.f, hy0 = 0.f, hy1 = 0.f, hxx0 = 0.f, hxx1 = 0.f, hyy0 = 0.f, hyy1 = 0.f,
-                  hxy0 = 0.f, hxy1 = 0.f;
-#pragma unroll 1
-            for (int j = 0; j < 8; ++j) {
-                const int sr = 6 * wgrp + j;
-                const float j0 = sJ[c][sr][wcol], j1 = sJ[c][sr][wcol + 1], j2 = sJ[c][sr][wcol + 2];
-                const float t0 = sT[c][sr][wcol], t1 = sT[c][sr][wcol + 1], t2 = sT[c][sr][wcol + 2];
-                const float hx2 = t0 + t1 + t2;
-                const float hy2 = j0 + j1 + j2;
-                const float hxx2 = t0 * t0 + t1 * t1 + t2 * t2;
-                const float hyy2 = j0 * j0 + j1 * j1 + j2 * j2;
-                const float hxy2 = t0 * j0 + t1 * j1 + t2 * j2;
-                if (j >= 2) {
-                    const int wy = sr - 2;
-                    float A = 0.f, Bc = 0.f, Cc = 0.f;
-                    if (sM[wy][wcol] != 0.0f) {
-                        const SsimTerms s = ssim_terms(hx0 + hx1 + hx2, hy0 + hy1 + hy2, hxx0 + hxx1 + hxx2,
-                                                       hyy0 + hyy1 + hyy2, hxy0 + hxy1 + hxy2);
-                        // refined reciprocal: d_a / d_b / d_pose are heavily cancelling sums of these terms
-                        const float inv = nr_rcp(s.B1 * s.B2);
-                        const float S = s.A1 * s.A2 * inv;
-                        const float ss = 0.5f * (1.0f - S);
-                        if (ss > 0.0f && ss < 1.0f) {
-                            // d S / d(sum J), d(sum J^2), d(sum T J) of the window
-                            const float dS_dsy = 2.0f * (s.sx * (s.A2 - s.A1) - S * s.sy * (s.B2 - s.B1)) * inv;
-                            A = kss * dS_dsy;
-                            Bc = kss * -18.0f * S * (inv * s.B1);
-                            Cc = kss * 18.0f * s.A1 * inv;
-                        }
-                    }
-                    sK[0][wy][wcol] = A; sK[1][wy][wcol] = Bc; sK[2][wy][wcol] = Cc;
-                }
-                hx0 = hx1; hx1 = hx2; hy0 = hy1; hy1 = hy2; hxx0 = hxx1; hxx1 = hxx2;
-                hyy0 = hyy1; hyy1 = hyy2; hxy0 = hxy1; hxy1 = hxy2;
-            }
-        }
-        __syncthreads();
-        // phase 3: every owned pixel gathers from the 9 windows that contain it (rows 4rg..4rg+5 of
-        // the window grid serve the thread's 4 pixels): horizontal weighted sums first, then vertical
-        {
-            float ha[6], hb[6], hc[6], v[4];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int wr = 4 * rg + j;
-                ha[j] = wxv[0] * sK[0][wr][col] + wxv[1] * sK[0][wr][col + 1] + wxv[2] * sK[0][wr][col + 2];
-                hb[j] = wxv[0] * sK[1][wr][col] + wxv[1] * sK[1][wr][col + 1] + wxv[2] * sK[1][wr][col + 2];
-                hc[j] = wxv[0] * sK[2][wr][col] + wxv[1] * sK[2][wr][col + 1] + wxv[2] * sK[2][wr][col + 2];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 4 * rg + i;
-                const float sa = wyv[i][0] * ha[i] + wyv[i][1] * ha[i + 1] + wyv[i][2] * ha[i + 2];
-                const float sb = wyv[i][0] * hb[i] + wyv[i][1] * hb[i + 1] + wyv[i][2] * hb[i + 2];
-                const float sc = wyv[i][0] * hc[i] + wyv[i][1] * hc[i + 1] + wyv[i][2] * hc[i + 2];
-                const float j = sJ[c][row + 2][col + 2], t = sT[c][row + 2][col + 2];
-                const float diff = j - t;
-                const float sgn = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
-                v[i] = sa + sb * j + sc * t + kl1 * sM[row + 1][col + 1] * sgn;
-            }
-            if (c == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dJ[i][0] = v[i];
-            } else if (c == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dJ[i][1] = v[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dJ[i][2] = v[i];
-            }
-        }
-        __syncthreads();
-    }
-
-    // phase 4: recompute the sample and chain through LCC, the bilinear taps and the projection
-    float part[NPART];
-#pragma unroll
-    for (int k = 0; k < NPART; ++k) part[k] = 0.0f;
-    {
-        int px[4], py[4];
-        bool own[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gy_ = y0 + 4 * rg + i, gx_ = x0 + col;
-            own[i] = (gy_ < H && gx_ < W);            // overhanging slots own no output
-            py[i] = min(gy_, H - 1); px[i] = min(gx_, W - 1);
-        }
-        Proj p[4];
-        float dval[4], J[4][3], T[4][3], Wp[4][3], gx[4][3], gy[4][3];
-        eval_batch<4, true>(g, im, px, py, H, W, p, dval, J, T, Wp, gx, gy);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!own[i]) continue;
-            float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                da += dJ[i][c] * Wp[i][c];
-                db += dJ[i][c];
-                const float dW = g.a * dJ[i][c];
-                gxs += dW * gx[i][c];
-                gys += dW * gy[i][c];
-            }
-            part[12] += da;
-            part[13] += db;
+        if (own) {
+            st.part[12] += da;
+            st.part[13] += db;
             float dd = 0.0f;
-            if (p[i].valid) {
-                const float iz = nr_rcp(p[i].Pz);
+            if (mp != 0.0f) {
+                const float iz = nr_rcp(Pzv);
                 const float dPx = gxs * g.fx * iz;
                 const float dPy = gys * g.fy * iz;
-                const float dPz = -(dPx * p[i].Px + dPy * p[i].Py) * iz;
-                // P = R (d * [Xh Yh 1]) + t
-                const float rx_ = g.r00 * p[i].Xh + g.r01 * p[i].Yh + g.r02;
-                const float ry_ = g.r10 * p[i].Xh + g.r11 * p[i].Yh + g.r12;
-                const float rz_ = g.r20 * p[i].Xh + g.r21 * p[i].Yh + g.r22;
+                const float dPz = -(dPx * Pxv + dPy * Pyv) * iz;
+                const float Yh = ((float)gyp - g.cy) * g.ify;
+                const float rx_ = g.r00 * Xh + g.r01 * Yh + g.r02;
+                const float ry_ = g.r10 * Xh + g.r11 * Yh + g.r12;
+                const float rz_ = g.r20 * Xh + g.r21 * Yh + g.r22;
                 dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
-                const float cX = p[i].Xh * dval[i], cY = p[i].Yh * dval[i], cZ = dval[i];
-                part[0] += dPx; part[1] += dPy; part[2] += dPz;
-                part[3] += dPx * cX; part[4] += dPx * cY; part[5] += dPx * cZ;
-                part[6] += dPy * cX; part[7] += dPy * cY; part[8] += dPy * cZ;
-                part[9] += dPz * cX; part[10] += dPz * cY; part[11] += dPz * cZ;
+                const float cX = Xh * dprev2, cY = Yh * dprev2, cZ = dprev2;
+                st.part[0] += dPx; st.part[1] += dPy; st.part[2] += dPz;
+                st.part[3] += dPx * cX; st.part[4] += dPx * cY; st.part[5] += dPx * cZ;
+                st.part[6] += dPy * cX; st.part[7] += dPy * cY; st.part[8] += dPy * cZ;
+                st.part[9] += dPz * cX; st.part[10] += dPz * cY; st.part[11] += dPz * cZ;
             }
-            d_depth[(size_t)b * plane + (size_t)py[i] * W + px[i]] = dd;
+            d_depth_img[(size_t)gyp * W + gxcol] = dd;
         }
     }
-    // block reduction of the 14 partial sums through LDS (the staging arrays are free now): two fixed-order
-    // stages instead of 14 x 6 cross-lane shuffles per thread
-    float* sRed = &sJ[0][0][0];          // [NPART][NT]
-    float* sRed2 = &sT[0][0][0];         // [NPART][16]
-#pragma unroll
-    for (int k = 0; k < NPART; ++k) sRed[k * NT + tid] = part[k];
+}
+
+__global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
+    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
+    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
+    const float* __restrict__ lcc_b, int B, int H, int W, int strips_x, int nseg, int seg_rows, float alpha,
+    const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
+    float* __restrict__ partials) {
+    __shared__ float s_geo[4][GEO_N + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: keeps the buffer descriptors uniform
+    const int nitems = B * nseg * strips_x;
+    const int item_raw = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // (image, segment, strip), strip fastest
+    const bool live = item_raw < nitems;
+    const int item = live ? item_raw : nitems - 1;
+    const int b = item / (nseg * strips_x), rem = item - b * (nseg * strips_x);
+    const int seg = rem / strips_x, strip = rem - seg * strips_x;
+    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave]);
     __syncthreads();
-    if (tid < NPART * 16) {
-        const int k = tid >> 4, seg = tid & 15;
-        const float* r = sRed + k * NT + seg * 16;
-        float a = 0.0f;
+    const Geo g = geo_load(s_geo[wave]);
+    const Img im = img_make(tgt, ref, depth, b, H, W);
+    const float gscale = grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
+    const float kss = gscale * alpha * (-0.5f);
+    const float kl1 = gscale * (1.0f - alpha);
+
+    const int x0 = strip * BCOLS, y0 = seg * seg_rows;
+    const int gxcol = x0 - 2 + lane;
+    const int px = reflect_idx(gxcol, W);
+    const bool own_col = live && (lane >= 2) && (lane < 2 + BCOLS) && (gxcol < W);
+    const int rows_here = min(seg_rows, H - y0);
+    const int nrows = rows_here + 4;
+    const int y_first = y0 - 2;
+    const float Xh = ((float)gxcol - g.cx) * g.ifx;
+    float wxw[3];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a += r[i];
-        sRed2[tid] = a;
+    for (int d = 0; d < 3; ++d) {
+        const int q = gxcol + d - 1;
+        wxw[d] = (gxcol >= 0 && gxcol < W && q >= 0 && q < W) ? window_mult(q, gxcol, W) : 0.0f;
     }
-    __syncthreads();
-    if (tid < NPART) {
-        float a = 0.0f;
+
+    BwdState st;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) a += sRed2[tid * 16 + i];
-        partials[(size_t)wid * NPART + tid] = a;
+    for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        st.m[r] = 0.0f; st.Px[r] = 0.f; st.Py[r] = 0.f; st.Pz[r] = 1.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.Wp[r][c] = 0.f; st.gx[r][c] = 0.f; st.gy[r][c] = 0.f; st.Tk[r][c] = 0.f; }
+        st.dk[r] = 1.0f;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) st.HK[r][q] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) st.H[r][q] = 0.0f;
+    }
+    // prologue: depth/target of rows 0 and 1, projection + taps of row 0
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int py = reflect_idx(y_first + r, H);
+        const int o4 = (py * W + px) * 4;
+        st.dv[r] = bload(im.dep, o4, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st.T[r][c] = bload(im.tgt, o4, c * im.plane4);
+    }
+    st.dv[2] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) st.T[2][c] = 0.0f;
+    {
+        const int py = reflect_idx(y_first, H);
+        const Proj p = project_px(g, st.dv[0], px, py, H, W);
+        const Taps t = make_taps_safe(p, H, W);
+        st.wx[0] = t.wx; st.wy[0] = t.wy; st.m[0] = p.valid ? 1.0f : 0.0f;
+        st.Px[0] = p.Px; st.Py[0] = p.Py; st.Pz[0] = p.Pz;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int so = c * im.plane4;
+            st.v[0][c][0] = bload(im.ref, t.o00, so); st.v[0][c][1] = bload(im.ref, t.o01, so);
+            st.v[0][c][2] = bload(im.ref, t.o10, so); st.v[0][c][3] = bload(im.ref, t.o11, so);
+        }
+    }
+    float* ddimg = d_depth + (size_t)b * H * W;
+#pragma unroll 1
+    for (int j = 0; j < nrows; j += 3) {
+        bwd_step<0>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
+        bwd_step<1>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
+        bwd_step<2>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
+    }
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) {
+        const float v = wave_sum(live ? st.part[k] : 0.0f);
+        if (lane == 0 && live) partials[(size_t)item * NPART + k] = v;
     }
 }
 
@@ -824,8 +744,6 @@ __global__ __launch_bounds__(NT) void k_inverse_warp(const float* __restrict__ r
     }
 }
 
-inline int tiles_x(int W) { return (W + TW - 1) / TW; }
-inline int tiles_y(int H) { return (H + TH - 1) / TH; }
 
 }  // namespace
 }  // namespace colvo
@@ -834,7 +752,7 @@ using namespace colvo;
 
 extern "C" size_t colvo_warp_loss_workspace_floats(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t bwd = (size_t)B * tiles_x(W) * tiles_y(H) * NPART;                                       // 14 per 64x16 tile
+    const size_t bwd = (size_t)B * ((W + BCOLS - 1) / BCOLS) * ((H + 3) / 4) * NPART;   // 14 per strip segment (>= 4 rows)
     const size_t fwd = (size_t)B * ((W + MCOLS - 1) / MCOLS) * ((H + 3) / 4) * 2;   // 2 per strip segment (>= 4 rows each)
     return bwd > fwd ? bwd : fwd;
 }
@@ -872,12 +790,15 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65535, "colvo_warp_loss_bwd: bad shape B=%d H=%d W=%d", B, H, W);
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_bwd: image too large");
     hipStream_t s = (hipStream_t)stream;
-    const int tx = tiles_x(W), ty = tiles_y(H);
-    COLVO_CHECK_ARG((long long)tx * ty * B < (1ll << 31), "colvo_warp_loss_bwd: too many tiles");
-    hipLaunchKernelGGL(k_warp_loss_bwd, dim3(tx * ty * B), dim3(NT), 0, s, tgt, ref, depth, pose, K, lcc_a, lcc_b, H, W,
-                       tx, ty, ssim_weight, loss_state, grad_loss, d_depth, workspace);
-    COLVO_CHECK_LAUNCH("k_warp_loss_bwd");
-    hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, tx * ty, pose,
+    // marching-wave backward: one wave per (image, row segment, 60-column strip)
+    const int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
+    const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
+    const long long nitems = (long long)B * nseg * strips_x;
+    COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");
+    hipLaunchKernelGGL(k_warp_loss_bwd_march, dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
+                       lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, loss_state, grad_loss, d_depth, workspace);
+    COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march");
+    hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, nseg * strips_x, pose,
                        d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_finalize");
     return 0;

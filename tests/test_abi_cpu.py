@@ -40,9 +40,9 @@ def test_abi_version_and_error_string(lib):
 
 
 def test_workspace_size_formula(lib):
-    # max(backward: 14 partial sums per 64x16 tile, forward: 2 per 62-column strip segment of >= 4 rows)
-    assert lib.colvo_warp_loss_workspace_floats(8, 256, 320) == max(8 * 5 * 16 * 14, 8 * 6 * 64 * 2)
-    assert lib.colvo_warp_loss_workspace_floats(2, 33, 47) == max(2 * 1 * 3 * 14, 2 * 1 * 9 * 2)
+    # max(backward: 14 partial sums per 60-column strip segment, forward: 2 per 62-column strip segment; >= 4 rows each)
+    assert lib.colvo_warp_loss_workspace_floats(8, 256, 320) == max(8 * 6 * 64 * 14, 8 * 6 * 64 * 2)
+    assert lib.colvo_warp_loss_workspace_floats(2, 33, 47) == max(2 * 1 * 9 * 14, 2 * 1 * 9 * 2)
     assert lib.colvo_warp_loss_workspace_floats(0, 10, 10) == 0
 
 
