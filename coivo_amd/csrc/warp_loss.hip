@@ -269,8 +269,9 @@ __device__ __forceinline__ void march_step(MarchState& st, const Geo& g, const I
         Jc[c] = fmaf(g.a, st.m[K] * fmaf(bot, st.wy[K], top * uy), g.b);
         Tc[c] = st.T[K][c];
     }
-    // (2) issue the loads of the next rows; they fly under the arithmetic of (3)
-    if (j + 1 < nrows) {
+    // (2) issue the loads of the next rows; they fly under the arithmetic of (3).  Rows past the end are clamped by
+    //     reflect_idx (always legal), so no step-index branches
+    {
         const int py = reflect_idx(y_first + j + 1, H);
         const Proj p = project_px(g, st.dv[K1], px, py, H, W);
         const Taps t = make_taps_safe(p, H, W);
@@ -282,7 +283,7 @@ __device__ __forceinline__ void march_step(MarchState& st, const Geo& g, const I
             st.v[K1][c][2] = bload(im.ref, t.o10, so); st.v[K1][c][3] = bload(im.ref, t.o11, so);
         }
     }
-    if (j + 2 < nrows) {
+    {
         const int py = reflect_idx(y_first + j + 2, H);
         const int o4 = (py * W + px) * 4;
         st.dv[K2] = bload(im.dep, o4, 0);
@@ -301,7 +302,7 @@ __device__ __forceinline__ void march_step(MarchState& st, const Geo& g, const I
         st.h[K][5 * c + 4] = hsum3(T * J);
         l1cur[c] = fabsf(T - J);
     }
-    if (j >= 2) {                                        // output row = slot row j-1
+    {                                                    // output row = slot row j-1 (mprev = 0 until it exists)
         float mrow = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -358,6 +359,10 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd_march(
     st.acc = 0.0f; st.cnt = 0.0f; st.mprev = 0.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) st.l1prev[c] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)          // zero window sums give S = 1 (zero dissimilarity): the first two steps are
+#pragma unroll                           // harmless without a branch on the step index
+        for (int q = 0; q < 15; ++q) st.h[r][q] = 0.0f;
     // prologue: A(0), A(1), B(0)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -469,13 +474,14 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
     }
     // rows j-2 and j+1 share a slot: snapshot what the chain rule of pixel row j-2 needs before (2) overwrites it
     const float mp = st.m[K1], Pxv = st.Px[K1], Pyv = st.Py[K1], Pzv = st.Pz[K1];
-    // (2) issue the loads of the next rows (they fly under the arithmetic below)
-    if (j + 1 < nrows) {
+    // (2) issue the loads of the next rows (they fly under the arithmetic below).  Rows past the end of the strip are
+    //     clamped by reflect_idx, so the loads are always legal and no step-index branch is needed.
+    {
         const int py = reflect_idx(y_first + j + 1, H);
         const Proj p = project_px(g, st.dv[K1], px, py, H, W);
         const Taps t = make_taps_safe(p, H, W);
         st.wx[K1] = t.wx; st.wy[K1] = t.wy; st.m[K1] = p.valid ? 1.0f : 0.0f;
-        st.Px[K1] = p.Px; st.Py[K1] = p.Py; st.Pz[K1] = p.Pz;
+        st.Px[K1] = p.Px; st.Py[K1] = p.Py; st.Pz[K1] = p.valid ? p.Pz : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int so = c * im.plane4;
@@ -483,7 +489,7 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             st.v[K1][c][2] = bload(im.ref, t.o10, so); st.v[K1][c][3] = bload(im.ref, t.o11, so);
         }
     }
-    if (j + 2 < nrows) {
+    {
         const int py = reflect_idx(y_first + j + 2, H);
         const int o4 = (py * W + px) * 4;
         st.dv[K2] = bload(im.dep, o4, 0);
@@ -500,10 +506,12 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
         st.H[K][5 * c + 3] = hsum3(J * J);
         st.H[K][5 * c + 4] = hsum3(T * J);
     }
-    // (4) derivative coefficients of window row j-1 (centre = row j-1, this lane's column), gathered horizontally
-    if (j >= 2) {
+    // (4) derivative coefficients of window row j-1 (centre = row j-1, this lane's column), gathered horizontally.
+    //     No branch on j: before two rows have been seen the zero-initialised H gives S = 1, i.e. zero coefficients,
+    //     and the window row does not exist (wmask = 0).
+    {
         const int gyw = y_first + j - 1;
-        const bool wexists = (gyw >= 0) && (gyw < H) && (gxcol >= 0) && (gxcol < W);
+        const bool wexists = (gyw >= 0) && (gyw < H) && (gxcol >= 0) && (gxcol < W) && (j >= 2);
         const float wmask = wexists ? st.m[K2] : 0.0f;   // row j-1 = slot (j+2) % 3
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -524,16 +532,18 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             st.HK[K2][3 * c + 2] = fmaf(wxw[0], dpp_from_left(Cc), fmaf(wxw[2], dpp_from_right(Cc), wxw[1] * Cc));
         }
     }
-    // (5) pixel row j-2 (slot K1): vertical gather of the coefficient rows j-3, j-2, j-1 -> dJ, then the chain rule
-    if (j >= 4) {
+    // (5) pixel row j-2 (slot K1): vertical gather of the coefficient rows j-3, j-2, j-1 -> dJ, then the chain rule.
+    //     Branch-free: pixels this wave does not own contribute through a 0/1 factor, only the store is predicated.
+    {
         const int gyp = y_first + j - 2;
         float wyw[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const int q = gyp + d - 1;
-            wyw[d] = (q >= 0 && q < H) ? window_mult(q, gyp, H) : 0.0f;
+            wyw[d] = (gyp >= 0 && q >= 0 && q < H) ? window_mult(q, gyp, H) : 0.0f;
         }
         const bool own = own_col && (j - 2 >= 2) && (j - 2 <= nrows - 3) && (gyp < H);
+        const float ownf = own ? 1.0f : 0.0f;
         // slots: row j-3 -> K, row j-2 -> K1, row j-1 -> K2   (j-3 = j mod 3)
         const float dprev2 = st.dk[K1];
         float da = 0.f, db = 0.f, gxs = 0.f, gys = 0.f;
@@ -546,35 +556,30 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             const float Jp = fmaf(g.a, wv, g.b), Tp = st.Tk[K1][c];
             const float diff = Jp - Tp;
             const float sgn = (diff > 0.0f) ? 1.0f : ((diff < 0.0f) ? -1.0f : 0.0f);
-            const float dJ = fmaf(hb, Jp, fmaf(hc, Tp, ha)) + kl1 * mp * sgn;
+            const float dJ = ownf * (fmaf(hb, Jp, fmaf(hc, Tp, ha)) + kl1 * mp * sgn);
             da = fmaf(dJ, wv, da);
             db += dJ;
             const float dW = g.a * dJ;
-            gxs = fmaf(dW, st.gx[K1][c], gxs);
+            gxs = fmaf(dW, st.gx[K1][c], gxs);       // gx, gy are already zero where the sample is invalid
             gys = fmaf(dW, st.gy[K1][c], gys);
         }
-        if (own) {
-            st.part[12] += da;
-            st.part[13] += db;
-            float dd = 0.0f;
-            if (mp != 0.0f) {
-                const float iz = nr_rcp(Pzv);
-                const float dPx = gxs * g.fx * iz;
-                const float dPy = gys * g.fy * iz;
-                const float dPz = -(dPx * Pxv + dPy * Pyv) * iz;
-                const float Yh = ((float)gyp - g.cy) * g.ify;
-                const float rx_ = g.r00 * Xh + g.r01 * Yh + g.r02;
-                const float ry_ = g.r10 * Xh + g.r11 * Yh + g.r12;
-                const float rz_ = g.r20 * Xh + g.r21 * Yh + g.r22;
-                dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
-                const float cX = Xh * dprev2, cY = Yh * dprev2, cZ = dprev2;
-                st.part[0] += dPx; st.part[1] += dPy; st.part[2] += dPz;
-                st.part[3] += dPx * cX; st.part[4] += dPx * cY; st.part[5] += dPx * cZ;
-                st.part[6] += dPy * cX; st.part[7] += dPy * cY; st.part[8] += dPy * cZ;
-                st.part[9] += dPz * cX; st.part[10] += dPz * cY; st.part[11] += dPz * cZ;
-            }
-            d_depth_img[(size_t)gyp * W + gxcol] = dd;
-        }
+        st.part[12] += da;
+        st.part[13] += db;
+        const float iz = nr_rcp(Pzv);                // Pz was stored as 1 for invalid samples
+        const float dPx = gxs * g.fx * iz;
+        const float dPy = gys * g.fy * iz;
+        const float dPz = -(dPx * Pxv + dPy * Pyv) * iz;
+        const float Yh = ((float)gyp - g.cy) * g.ify;
+        const float rx_ = g.r00 * Xh + g.r01 * Yh + g.r02;
+        const float ry_ = g.r10 * Xh + g.r11 * Yh + g.r12;
+        const float rz_ = g.r20 * Xh + g.r21 * Yh + g.r22;
+        const float dd = dPx * rx_ + dPy * ry_ + dPz * rz_;
+        const float cX = Xh * dprev2, cY = Yh * dprev2, cZ = dprev2;
+        st.part[0] += dPx; st.part[1] += dPy; st.part[2] += dPz;
+        st.part[3] += dPx * cX; st.part[4] += dPx * cY; st.part[5] += dPx * cZ;
+        st.part[6] += dPy * cX; st.part[7] += dPy * cY; st.part[8] += dPy * cZ;
+        st.part[9] += dPz * cX; st.part[10] += dPz * cY; st.part[11] += dPz * cZ;
+        if (own) d_depth_img[(size_t)gyp * W + gxcol] = dd;
     }
 }
 
