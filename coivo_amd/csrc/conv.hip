@@ -21,6 +21,10 @@
 //   - epilogue through LDS: bias, ReLU, 2x2 sum-pooling (input gradient of an up-sampled source),
 //     ReLU-mask of the producer, accumulate (skip fan-out), convert, 16-byte coalesced stores.
 //
+//   - measured (tools/scan_conv.py): t = 6 us + 1.5 us per 32-channel chunk even for ONE workgroup, unchanged by
+//     deeper prefetch, double-buffered LDS stages or 64-channel chunks: the chunk is bound by LDS throughput
+//     (~48 KB of ds_write + 4 waves x 54 ds_read_b128 per 72 MFMAs/wave); the next step is a 64x64 per-wave tile.
+//
 // k_wgrad3x3:  dW[co][tap][c] += sum_pixels dY[pixel][co] * X[pixel@tap][c]   (K = pixels)
 //   - workgroup = (co tile of 16*MT) x (channel chunk CK of one source) x (a range of pixel tiles);
 //     the sums of the whole range stay in MFMA accumulators, then ONE fp32 atomic add per element.
@@ -50,8 +54,11 @@ constexpr int BM = 128;   // output pixels per workgroup (4 waves x 2 fragments 
 // contiguous 16-lane groups): 8 lanes of one k-group plus 8 lanes of the next one (+16 B).  With a pitch of r
 // 16-byte slots per fragment row the group is conflict-free iff {r*l mod 16} are distinct EVEN slots for the 8 rows
 // of a half: r = 6 (96 B) for 64-byte payloads, r = 2 (32 B, no padding) for 32-byte payloads.
-constexpr int pitch_bytes(int payload) { return payload == 64 ? 96 : (payload == 32 ? 32 : payload + 16); }
-constexpr int wrow_bytes(int granules) { return ((granules * 16) % 256 == 64) ? granules * 16 + 32 : granules * 16 + 16; }
+// In general any pitch of r slots with r = 2 (mod 4) works: {r*l mod 16} are then 8 distinct even slots for the 8 rows
+// of a half group, and the other k-group sits on the odd slots.
+constexpr int pitch_slots(int n) { return n + ((2 - n % 4) + 4) % 4; }
+constexpr int pitch_bytes(int payload) { return pitch_slots(payload / 16) * 16; }
+constexpr int wrow_bytes(int granules) { return pitch_slots(granules) * 16; }
 
 enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
 
@@ -89,6 +96,12 @@ struct WgradK {
 };
 
 __device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
+// 16-byte buffer load: 32-bit per-lane byte offset + scalar byte offset; an offset beyond the descriptor's size
+// returns zeros (hardware bounds check), so padding / out-of-image granules need no branch: they get OOB_OFF.
+__device__ __forceinline__ u32x4 bld16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+constexpr int OOB_OFF = 0x40000000;
 __device__ __forceinline__ void st16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 // Stage the input patch of one tile / one channel chunk: sP[pix][CK] (pitch PIXP bytes).
@@ -180,44 +193,47 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     for (int it = 0; it < WIT; ++it) {
         const int i = it * NT + tid;
         const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
-        woff[it] = -1;
+        woff[it] = OOB_OFF;
         if (i < WTOT && gi < NGR && n0 + n < a.N) {
             const int tap = gi / NG, cg = gi - tap * NG;
             woff[it] = (((n0 + n) * 9 + tap) * a.Ctot + cg * G) * ES;
         }
     }
-    const char* img[2];
-    int poff[2][PPF];
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
+    // two named descriptors / offset sets (arrays of descriptors end up in scratch and turn every load into a
+    // waterfall loop)
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    auto make_img = [&](int sidx) {
+        const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx], Cs = a.g.C[sidx];
+        const char* base = a.g.src[sidx] + (size_t)b * Hs * Ws * Cs * ES;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, Cs > 0 ? Hs * Ws * Cs * ES : 0, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rimg0 = make_img(0), rimg1 = make_img(1);
+    auto patch_off = [&](int sidx, int i) -> int {
         const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
-        img[sidx] = a.g.src[sidx] + (size_t)b * Hs * Ws * Cs * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            const int pix = i / NG, cg = i - pix * NG;
-            const int py = pix / PW, px = pix - py * PW;
-            const int vy = iy0 + py, vx = ix0 + px;
-            bool inb = (Cs > 0) && (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
-            int sy = vy, sx = vx;
-            if (mode != MODE_DIRECT) {
-                if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
-                sy = vy >> 1; sx = vx >> 1;
-            }
-            inb = inb && (sy < Hs) && (sx < Ws);
-            poff[sidx][it] = inb ? ((sy * Ws + sx) * Cs + cg * G) * ES : -1;
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = pix / PW, px = pix - py * PW;
+        const int vy = iy0 + py, vx = ix0 + px;
+        bool inb = (Cs > 0) && (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
+        int sy = vy, sx = vx;
+        if (mode != MODE_DIRECT) {
+            if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
+            sy = vy >> 1; sx = vx >> 1;
         }
+        inb = inb && (sy < Hs) && (sx < Ws);
+        return inb ? ((sy * Ws + sx) * Cs + cg * G) * ES : OOB_OFF;
+    };
+    int poff0[PPF], poff1[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        poff0[it] = patch_off(0, it * NT + tid);
+        poff1[it] = patch_off(1, it * NT + tid);
     }
 
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
     auto load_w = [&](int k) {
-        const char* wk = a.w + (size_t)k * CK * ES;
+        const int so = k * CK * ES;
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (woff[it] >= 0) v = ld16(wk + woff[it]);
-            wv[it] = v;
-        }
+        for (int it = 0; it < WIT; ++it) wv[it] = bld16(rw, woff[it], so);      // branch-free, zero-filled
     };
     auto store_w = [&]() {
 #pragma unroll
@@ -227,32 +243,18 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
         }
     };
     auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
-        const int pix = i / NG, cg = i - pix * NG;
-        const int py = pix / PW, px = pix - py * PW;
-        const int vy = iy0 + py, vx = ix0 + px;
-        bool inb = (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
-        int sy = vy, sx = vx;
-        const int mode = a.g.mode[sidx];
-        if (mode != MODE_DIRECT) {
-            if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
-            sy = vy >> 1; sx = vx >> 1;
-        }
-        const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx];
-        inb = inb && (sy < Hs) && (sx < Ws);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (inb) v = ld16(img[sidx] + ((size_t)(sy * Ws + sx) * a.g.C[sidx] + c0 + cg * G) * ES);
-        return v;
+        return sidx == 0 ? bld16(rimg0, patch_off(0, i), c0 * ES) : bld16(rimg1, patch_off(1, i), c0 * ES);
     };
     auto load_p = [&](int k) {
         int sidx, c0;
         chunk_src(k, sidx, c0);
-        const char* base = img[sidx] + c0 * ES;
+        const int so = c0 * ES;
+        if (sidx == 0) {
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int o = sidx ? poff[1][it] : poff[0][it];
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (o >= 0) v = ld16(base + o);
-            pv[it] = v;
+            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg0, poff0[it], so);
+        } else {
+#pragma unroll
+            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, poff1[it], so);
         }
     };
     auto store_p = [&](int k) {
