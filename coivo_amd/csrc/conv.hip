@@ -481,6 +481,12 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
         oy0 = ty * a.toh; ox0 = tx * a.tow;
     };
+    // branch-free staging loads: buffer descriptors over the whole dY tensor / the whole source tensor, invalid
+    // granules get an out-of-range offset and come back as zeros (see k_conv3x3)
+    const long long dy_bytes = (long long)a.B * a.Ho * a.Wo * a.Cout * ES;
+    const long long x_bytes = (long long)a.B * a.g.Hs[s] * a.g.Ws[s] * a.g.C[s] * ES;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(dy_bytes < 0x7fffffffLL ? dy_bytes : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[s], 0, (int)(x_bytes < 0x7fffffffLL ? x_bytes : 0x7fffffffLL), 0x00020000);
     auto load_dy = [&](int t) {
         int b, oy0, ox0;
         tile_origin(t, b, oy0, ox0);
@@ -488,14 +494,11 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         for (int it = 0; it < DIT; ++it) {
             const int i = it * NT + tid;
             const int p = i / DGR, gch = i - p * DGR;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (i < BM * DGR && p < npix) {
-                const int oy = p / a.tow, ox = p - oy * a.tow;
-                const int gy = oy0 + oy, gx = ox0 + ox;
-                if (gy < a.Ho && gx < a.Wo && co0 + gch * G < a.Cout)
-                    v = ld16(a.dy + ((((size_t)b * a.Ho + gy) * a.Wo + gx) * a.Cout + co0 + gch * G) * ES);
-            }
-            dyv[it] = v;
+            const int oy = p / a.tow, ox = p - oy * a.tow;
+            const int gy = oy0 + oy, gx = ox0 + ox;
+            const bool ok = (i < BM * DGR) && (p < npix) && (gy < a.Ho) && (gx < a.Wo) && (co0 + gch * G < a.Cout);
+            const int off = ok ? ((((b * a.Ho + gy) * a.Wo + gx) * a.Cout) + co0 + gch * G) * ES : OOB_OFF;
+            dyv[it] = bld16(rdy, off, 0);
         }
     };
     auto store_dy = [&]() {
@@ -516,9 +519,8 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         if (a.g.mode[s] != MODE_DIRECT) { sy = vy >> 1; sx = vx >> 1; }
         const int Hs = a.g.Hs[s], Ws = a.g.Ws[s];
         inb = inb && (sy < Hs) && (sx < Ws);
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (inb) v = ld16(a.g.src[s] + ((((size_t)b * Hs + sy) * Ws + sx) * a.g.C[s] + c0 + cg * G) * ES);
-        return v;
+        const int off = inb ? ((((b * Hs + sy) * Ws + sx) * a.g.C[s]) + c0 + cg * G) * ES : OOB_OFF;
+        return bld16(rx, off, 0);
     };
     auto load_p = [&](int t) {
 #pragma unroll
@@ -840,6 +842,13 @@ extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const vo
                                 float* db, colvo_stream_t stream) {
     if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
     COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
+    {
+        const long long es = d->dtype == COLVO_F32 ? 4 : 2;
+        const long long cmax = d->C0 > d->C1 ? d->C0 : d->C1;
+        COLVO_CHECK_ARG((long long)d->B * d->Ho * d->Wo * d->Cout * es < 0x40000000LL &&
+                            (long long)d->B * d->Hi * d->Wi * cmax * es < 0x40000000LL,
+                        "colvo_conv_wgrad: tensors of 1 GiB or more are not supported (32-bit buffer offsets)");
+    }
     WgradK k{};
     fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
     k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
