@@ -30,6 +30,8 @@
 //     the sums of the whole range stay in MFMA accumulators, then ONE fp32 atomic add per element.
 //   - both operands have the reduction index (pixel) as the slow LDS dimension: bf16 fragments are
 //     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
+#include <algorithm>
+
 #include "common.h"
 
 namespace colvo {
@@ -127,6 +129,84 @@ __device__ __forceinline__ void stage_patch(const Gather& g, int s, int c0, int 
         u32x4 v = {0u, 0u, 0u, 0u};
         if (inb) v = ld16(base + ((((size_t)b * Hs + sy) * Ws + sx) * C + c0 + cg * G) * ES);
         st16(sP + pix * PIXP + cg * 16, v);
+    }
+}
+
+// Epilogue of one output tile from the fp32 staging tile in LDS: bias, ReLU, 2x2 sum-pool, producer's ReLU mask,
+// accumulate, convert, 16-byte coalesced stores.
+template <typename T, int BN>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut, int b, int oy0, int ox0, int n0, int tid) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int OUTP = BN + 4;
+    constexpr int GPR = BN / G;   // output granules per pixel row of the tile
+    const int Hout = a.pool2 ? (a.Ho >> 1) : a.Ho, Wout = a.pool2 ? (a.Wo >> 1) : a.Wo;
+    const int eh = a.pool2 ? (a.toh >> 1) : a.toh, ew = a.pool2 ? (a.tow >> 1) : a.tow;
+    const int ey0 = a.pool2 ? (oy0 >> 1) : oy0, ex0 = a.pool2 ? (ox0 >> 1) : ox0;
+    for (int i = tid; i < eh * ew * GPR; i += NT) {
+        const int q = i / GPR, gch = i - q * GPR;
+        const int qy = q / ew, qx = q - qy * ew;
+        const int gy = ey0 + qy, gx = ex0 + qx;
+        const int n = n0 + gch * G;
+        if (gy >= Hout || gx >= Wout || n >= a.N) continue;
+        float v[G];
+        if (a.pool2) {
+            const float* r0 = sOut + ((2 * qy) * a.tow + 2 * qx) * OUTP + gch * G;
+            const float* r1 = r0 + a.tow * OUTP;
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = (r0[k] + r0[OUTP + k]) + (r1[k] + r1[OUTP + k]);
+        } else {
+            const float* r0 = sOut + q * OUTP + gch * G;
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = r0[k];
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] += a.bias[n + k];
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < G; ++k) v[k] = fmaxf(v[k], 0.0f);
+        }
+        const size_t off = ((((size_t)b * Hout + gy) * Wout + gx) * a.N + n) * ES;
+        if constexpr (ES == 4) {
+            if (a.mask) {
+                const u32x4 m = ld16(a.mask + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (__uint_as_float(m[k]) > 0.0f) ? v[k] : 0.0f;
+            }
+            if (a.accumulate) {
+                const u32x4 o = ld16(a.out + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += __uint_as_float(o[k]);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(v[k]);
+            st16(a.out + off, o);
+        } else {
+            if (a.mask) {
+                const u32x4 m = ld16(a.mask + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // bf16 > 0  <=>  sign clear and magnitude non-zero
+                    const uint32_t lo = m[k] & 0xFFFFu, hi = m[k] >> 16;
+                    if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
+                    if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+                }
+            }
+            if (a.accumulate) {
+                const u32x4 o = ld16(a.out + off);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[2 * k] += bf2f((uint16_t)(o[k] & 0xFFFFu));
+                    v[2 * k + 1] += bf2f((uint16_t)(o[k] >> 16));
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+            st16(a.out + off, o);
+        }
     }
 }
 
@@ -341,75 +421,166 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
                 sOut[(wave * 32 + mf * 16 + 4 * kg + r) * OUTP + nf * 16 + l15] = acc[mf][nf][r];
     __syncthreads();
 
-    constexpr int GPR = BN / G;   // output granules per pixel row of the tile
-    const int Hout = a.pool2 ? (a.Ho >> 1) : a.Ho, Wout = a.pool2 ? (a.Wo >> 1) : a.Wo;
-    const int eh = a.pool2 ? (a.toh >> 1) : a.toh, ew = a.pool2 ? (a.tow >> 1) : a.tow;
-    const int ey0 = a.pool2 ? (oy0 >> 1) : oy0, ex0 = a.pool2 ? (ox0 >> 1) : ox0;
-    for (int i = tid; i < eh * ew * GPR; i += NT) {
-        const int q = i / GPR, gch = i - q * GPR;
-        const int qy = q / ew, qx = q - qy * ew;
-        const int gy = ey0 + qy, gx = ex0 + qx;
-        const int n = n0 + gch * G;
-        if (gy >= Hout || gx >= Wout || n >= a.N) continue;
-        float v[G];
-        if (a.pool2) {
-            const float* r0 = sOut + ((2 * qy) * a.tow + 2 * qx) * OUTP + gch * G;
-            const float* r1 = r0 + a.tow * OUTP;
+    conv_epilogue<T, BN>(a, sOut, b, oy0, ox0, n0, tid);
+}
+
+// --------------------------------------------------------------------------------------------- //
+// forward / input-gradient kernel, weights-resident persistent form                              //
+// --------------------------------------------------------------------------------------------- //
+// For single-chunk layers (C <= 32 bf16 / 16 f32: the high-resolution ends of the networks) a workgroup's work is a
+// few KB of traffic and ~10 MFMAs per wave, so the one-tile-per-workgroup kernel is bound by its fixed costs (address
+// setup, weight staging, two exposed memory round trips) times ~10^4 workgroups.  Here a workgroup stages its weight
+// slab ONCE, then loops over output tiles (grid-stride), prefetching the next tile's patch into registers while the
+// current tile's MFMAs and epilogue run.  The fp32 output staging tile aliases the patch region.
+template <typename T, int BN, int NG>
+__global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int NGR = 9 * NG;
+    constexpr int STEPS = (NGR + 3) / 4;
+    constexpr int WROW = wrow_bytes(STEPS * 4);
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int NF = BN / 16;
+    constexpr int OUTP = BN + 4;
+    constexpr int WTOT = BN * STEPS * 4;
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = 3;                          // stride 1: patch <= 10 x 18 pixels x NG <= 768 granules
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+    float* sOut = reinterpret_cast<float*>(sP);    // aliases the patch (dead once the MFMAs have read it)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.y * BN;
+    const int PH = a.toh + 2, PW = a.tow + 2;
+    const int npix = a.toh * a.tow;
+    const int ptotal = PH * PW * NG;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+
+    // weights: staged once
+    {
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+        u32x4 wv[WIT];
 #pragma unroll
-            for (int k = 0; k < G; ++k) v[k] = (r0[k] + r0[OUTP + k]) + (r1[k] + r1[OUTP + k]);
-        } else {
-            const float* r0 = sOut + q * OUTP + gch * G;
-#pragma unroll
-            for (int k = 0; k < G; ++k) v[k] = r0[k];
-        }
-        if (a.bias) {
-#pragma unroll
-            for (int k = 0; k < G; ++k) v[k] += a.bias[n + k];
-        }
-        if (a.relu) {
-#pragma unroll
-            for (int k = 0; k < G; ++k) v[k] = fmaxf(v[k], 0.0f);
-        }
-        const size_t off = ((((size_t)b * Hout + gy) * Wout + gx) * a.N + n) * ES;
-        if constexpr (ES == 4) {
-            if (a.mask) {
-                const u32x4 m = ld16(a.mask + off);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = (__uint_as_float(m[k]) > 0.0f) ? v[k] : 0.0f;
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * NT + tid;
+            const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
+            int off = OOB_OFF;
+            if (i < WTOT && gi < NGR && n0 + n < a.N) {
+                const int tap = gi / NG, cg = gi - tap * NG;
+                off = (((n0 + n) * 9 + tap) * a.Ctot + cg * G) * ES;
             }
-            if (a.accumulate) {
-                const u32x4 o = ld16(a.out + off);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] += __uint_as_float(o[k]);
-            }
-            u32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = __float_as_uint(v[k]);
-            st16(a.out + off, o);
-        } else {
-            if (a.mask) {
-                const u32x4 m = ld16(a.mask + off);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // bf16 > 0  <=>  sign clear and magnitude non-zero
-                    const uint32_t lo = m[k] & 0xFFFFu, hi = m[k] >> 16;
-                    if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
-                    if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
-                }
-            }
-            if (a.accumulate) {
-                const u32x4 o = ld16(a.out + off);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    v[2 * k] += bf2f((uint16_t)(o[k] & 0xFFFFu));
-                    v[2 * k + 1] += bf2f((uint16_t)(o[k] >> 16));
-                }
-            }
-            u32x4 o;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
-            st16(a.out + off, o);
+            wv[it] = bld16(rw, off, 0);
         }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * NT + tid;
+            if (i < WTOT) { const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4); st16(sW + n * WROW + gi * 16, wv[it]); }
+        }
+    }
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = p / a.tow, ox = p - oy * a.tow;
+        pbase[mf] = (oy * PW + ox) * PIXP;
+    }
+    // patch granules of this thread: (pixel, granule) inside the patch are tile-invariant
+    int ppy[PPF], ppx[PPF], pcg[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG;
+        pcg[it] = i - pix * NG;
+        ppy[it] = pix / PW; ppx[it] = pix - ppy[it] * PW;
+    }
+    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0], mode = a.g.mode[0];
+    // descriptor over the WHOLE source tensor (host guarantees < 1 GiB): offsets >= its size (OOB_OFF) read as zero
+    const int xbytes = (ntiles / tiles_per_img) * Hs * Ws * Cs * ES;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, xbytes, 0x00020000);
+    u32x4 pv[PPF];
+    auto load_p = [&](int tile) {
+        const int b = tile / tiles_per_img, tr_ = tile - b * tiles_per_img;
+        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
+        const int iy0 = ty * a.toh - 1, ix0 = tx * a.tow - 1;
+        const int ibase = b * Hs * Ws;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int vy = iy0 + ppy[it], vx = ix0 + ppx[it];
+            bool inb = (it * NT + tid < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
+            int sy = vy, sx = vx;
+            if (mode != MODE_DIRECT) {
+                if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
+                sy = vy >> 1; sx = vx >> 1;
+            }
+            inb = inb && (sy < Hs) && (sx < Ws);
+            const int off = inb ? ((ibase + sy * Ws + sx) * Cs + pcg[it] * G) * ES : OOB_OFF;
+            pv[it] = bld16(rx, off, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_p(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                      // the previous tile's epilogue has finished reading sOut (= sP)
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) st16(sP + (ppy[it] * PW + ppx[it]) * PIXP + pcg[it] * 16, pv[it]);
+        }
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) load_p(next);      // in flight during the MFMAs and the epilogue below
+
+        f32x4 acc[2][NF];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < STEPS; ++m) {
+            const int gi = 4 * m + kg;
+            int tap = gi / NG;
+            const int cg = gi - tap * NG;
+            tap = min(tap, 8);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+            u32x4 av[2], bv[NF];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
+            }
+        }
+        __syncthreads();                      // every wave is done reading the patch: it becomes the output tile
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sOut[(wave * 32 + mf * 16 + 4 * kg + r) * OUTP + nf * 16 + l15] = acc[mf][nf][r];
+        __syncthreads();
+        const int b = tile / tiles_per_img, tr_ = tile - b * tiles_per_img;
+        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
+        conv_epilogue<T, BN>(a, sOut, b, ty * a.toh, tx * a.tow, n0, tid);
     }
 }
 
@@ -683,8 +854,37 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     return 0;
 }
 
+template <typename T, int BN, int NG>
+int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
+    constexpr int STEPS = (9 * NG + 3) / 4;
+    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
+    const int PH = k.toh + 2, PW = k.tow + 2;
+    const size_t p_or_out = std::max((size_t)PH * PW * PIXP, (size_t)BM * (BN + 4) * 4);
+    const size_t lds = (size_t)BN * WROW + p_or_out;
+    const int ntiles = k.tiles_x * k.tiles_y * B;
+    int gx = 256 * 4;                           // ~4 workgroups per CU, each walking ntiles / gx tiles
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid(gx, (k.N + BN - 1) / BN, 1);
+    hipLaunchKernelGGL((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles);
+    COLVO_CHECK_LAUNCH("k_conv3x3_res");
+    return 0;
+}
+
 template <typename T, int BN>
 int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
+    // single-chunk layers with narrow outputs: weights-resident persistent kernel
+    if constexpr (BN <= 32) {
+        const int ck = ng * TT<T>::G;
+        const long long src_bytes = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * TT<T>::ES;
+        if (k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL &&
+            (long)k.tiles_x * k.tiles_y * B >= 2048) {
+            switch (ng) {
+                case 4: return launch_conv_res<T, BN, 4>(k, B, s);
+                case 2: return launch_conv_res<T, BN, 2>(k, B, s);
+                default: return launch_conv_res<T, BN, 1>(k, B, s);
+            }
+        }
+    }
     switch (ng) {
         case 4: return launch_conv<T, BN, 4>(k, B, s);
         case 2: return launch_conv<T, BN, 2>(k, B, s);
