@@ -1042,12 +1042,27 @@ extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const vo
                                 float* db, colvo_stream_t stream) {
     if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
     COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
+    // The kernel addresses dY and the sources with 32-bit buffer offsets (< 1 GiB per tensor): larger batches are
+    // processed in image slices -- the gradient accumulates into dw / db anyway.
     {
         const long long es = d->dtype == COLVO_F32 ? 4 : 2;
         const long long cmax = d->C0 > d->C1 ? d->C0 : d->C1;
-        COLVO_CHECK_ARG((long long)d->B * d->Ho * d->Wo * d->Cout * es < 0x40000000LL &&
-                            (long long)d->B * d->Hi * d->Wi * cmax * es < 0x40000000LL,
-                        "colvo_conv_wgrad: tensors of 1 GiB or more are not supported (32-bit buffer offsets)");
+        const long long per_img = std::max((long long)d->Ho * d->Wo * d->Cout, (long long)d->Hi * d->Wi * cmax) * es;
+        COLVO_CHECK_ARG(per_img < 0x40000000LL, "colvo_conv_wgrad: a single image of %lld bytes is not supported", per_img);
+        const int bmax = (int)std::max(1LL, (0x40000000LL - 1) / per_img);
+        if (d->B > bmax) {
+            const long long e0 = (long long)(d->up0 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C0 * es;
+            const long long e1 = (long long)(d->up1 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C1 * es;
+            const long long ey = (long long)d->Ho * d->Wo * d->Cout * es;
+            for (int b0 = 0; b0 < d->B; b0 += bmax) {
+                ColvoConvDesc sub = *d;
+                sub.B = std::min(bmax, d->B - b0);
+                if (int e = colvo_conv_wgrad(&sub, (const char*)x0 + b0 * e0, x1 ? (const char*)x1 + b0 * e1 : nullptr,
+                                             (const char*)dy + b0 * ey, dw, db, stream))
+                    return e;
+            }
+            return 0;
+        }
     }
     WgradK k{};
     fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
