@@ -31,6 +31,7 @@
 //   - both operands have the reduction index (pixel) as the slow LDS dimension: bf16 fragments are
 //     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -900,7 +901,11 @@ int launch_conv_t(const ConvK& k, int B, hipStream_t s) {
         if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
     for (int i = 0; i < 2; ++i)
         COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "conv: channel count %d is not a multiple of %d", k.g.C[i], G);
-    if (k.N >= 64) return launch_conv_ng<T, 64>(k, B, ng, s);
+    // Output-channel tile: 64 wide by default; when that grid would leave CUs idle (deep, low-resolution layers at small
+    // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
+    const long tiles = (long)k.tiles_x * k.tiles_y * B;
+    static const long bn64_min_wgs = [] { const char* e = getenv("COLVO_BN64_MIN_WGS"); return e ? atol(e) : 1024L; }();   // tuning knob
+    if (k.N >= 64 && tiles * ((k.N + 63) / 64) >= bn64_min_wgs) return launch_conv_ng<T, 64>(k, B, ng, s);
     if (k.N >= 32) return launch_conv_ng<T, 32>(k, B, ng, s);
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
