@@ -163,6 +163,13 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from coivo_amd import _lib as _colvo_lib
+    if not os.path.exists(_colvo_lib.LIB_PATH):       # fresh checkout: build the HIP extension in-tree (rank 0 first)
+        from coivo_amd import build as _colvo_build
+        if local_rank == 0:
+            _colvo_build.build()
+        if world > 1:
+            dist.barrier()
     from coivo_amd import functional as Fh
     from coivo_amd import nn as hnn
     from coivo_amd import synth

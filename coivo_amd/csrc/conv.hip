@@ -931,8 +931,11 @@ int launch_wgrad(WgradK k, hipStream_t s) {
     // the atomic traffic at ~12 MB per launch, but keep at least ~256 workgroups in flight and at most ~1024.
     const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
     const int per_split = chunks * cot;
-    int nsplit = (int)(12.0e6 / wbytes);
-    const int lo = (256 + per_split - 1) / per_split, hi = (1024 + per_split - 1) / per_split;
+    static const double atomic_budget = [] { const char* e = getenv("COLVO_WGRAD_ATOMIC_MB"); return (e ? atof(e) : 12.0) * 1e6; }();
+    static const int wg_lo = [] { const char* e = getenv("COLVO_WGRAD_WG_LO"); return e ? atoi(e) : 256; }();
+    static const int wg_hi = [] { const char* e = getenv("COLVO_WGRAD_WG_HI"); return e ? atoi(e) : 1024; }();
+    int nsplit = (int)(atomic_budget / wbytes);
+    const int lo = (wg_lo + per_split - 1) / per_split, hi = (wg_hi + per_split - 1) / per_split;
     if (nsplit > hi) nsplit = hi;
     if (nsplit < lo) nsplit = lo;
     if (nsplit > k.ntiles) nsplit = k.ntiles;

@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _ensure_library_built():
+    """The in-tree libcolvo.so travels with the tree, but a fresh checkout has none: build it (hipcc cross-compiles
+    without a GPU, seconds when objects are cached)."""
+    from coivo_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
