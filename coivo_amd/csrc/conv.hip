@@ -32,6 +32,7 @@
 //     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
 #include <algorithm>
 #include <stdlib.h>
+#include <vector>
 
 #include "common.h"
 
@@ -43,6 +44,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 struct bf16_t { uint16_t v; };
 
@@ -85,7 +87,25 @@ struct ConvK {
     const char* mask;         // same shape as out or null
     int accumulate, pool2;
     int toh, tow, tiles_x, tiles_y;
+    uint32_t m_pw, m_tow;     // ceil(2^32 / patch width), ceil(2^32 / tow): index / d == umulhi(index, m) for index < 2^16
+#ifdef COLVO_ABLATE
+    int abl;                  // developer build only (tools/ablate_conv.sh): bit mask of kernel phases to skip
+    long long* trace;         // developer build only: [workgroup][8] wall-clock stamps (100 MHz) of the kernel phases
+#endif
 };
+
+#ifdef COLVO_ABLATE
+#define ABL(bit) ((a.abl & (bit)) != 0)
+#define TRACE(slot)                                                                                       \
+    do {                                                                                                  \
+        if (a.trace && threadIdx.x == 0)                                                                  \
+            a.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
+                (long long)wall_clock64();                                                                \
+    } while (0)
+#else
+#define ABL(bit) false
+#define TRACE(slot) do {} while (0)
+#endif
 
 struct WgradK {
     Gather g;
@@ -96,7 +116,13 @@ struct WgradK {
     int Ctot;
     float* db;
     int toh, tow, tiles_x, tiles_y, ntiles, tiles_per_split;
+    uint32_t m_pw, m_tow;     // see ConvK
 };
+
+// i / d for 0 <= i < 2^16, 2 <= d < 2^16 with m = ceil(2^32 / d): one v_mul_hi_u32 instead of the ~35-instruction
+// runtime division (the address set-up of a workgroup was most of its VALU time)
+__device__ __forceinline__ int mdiv(int i, uint32_t m) { return (int)__umulhi((uint32_t)i, m); }
+inline uint32_t mdiv_magic(int d) { return (uint32_t)((0x100000000ULL + (uint32_t)d - 1) / (uint32_t)d); }
 
 __device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 // 16-byte buffer load: 32-bit per-lane byte offset + scalar byte offset; an offset beyond the descriptor's size
@@ -214,6 +240,90 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut,
 // --------------------------------------------------------------------------------------------- //
 // forward / input-gradient kernel                                                                //
 // --------------------------------------------------------------------------------------------- //
+// The MFMAs are issued with the operands SWAPPED (A = weight rows, B = pixels): lane (l15, kg) of accumulator
+// [mf][nf] then holds 4 CONSECUTIVE output channels n0 + nf*16 + kg*4 + {0..3} of ONE pixel (wave*32 + mf*16 + l15),
+// i.e. 8 / 16 contiguous bytes of the NHWC output -- the epilogue stores straight from the accumulators (bias, ReLU,
+// mask, accumulate per lane; buffer stores drop out-of-range lanes), with no LDS transposition and no index division.
+// Only pool2 (input gradient of an up-sampled source) still goes through the fp32 tile in LDS.
+template <typename T, int NF>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvK& a, const f32x4 (&acc)[2][NF], int b, int oy0, int ox0,
+                                                     int n0, int wave, int l15, int kg) {
+    constexpr int ES = TT<T>::ES;
+    const int npix = a.toh * a.tow;
+    const int img_bytes = a.Ho * a.Wo * a.N * ES;
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbias =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+    int obase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        const int p = wave * 32 + mf * 16 + l15;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        const int gy = oy0 + oy, gx = ox0 + ox;
+        const bool ok = (p < npix) && (gy < a.Ho) && (gx < a.Wo);
+        obase[mf] = ok ? (gy * a.Wo + gx) * a.N * ES : OOB_OFF;
+    }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        const int n = n0 + nf * 16 + kg * 4;
+        const int noff = (n < a.N) ? n * ES : OOB_OFF;
+        const u32x4 bs = bld16(rbias, n * 4, 0);          // zeros without a bias / beyond N
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + __uint_as_float(bs[r]);
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            }
+            const int off = obase[mf] + noff;
+            if constexpr (ES == 4) {
+                if (a.mask) {
+                    const u32x4 m = bld16(rmask, off, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (__uint_as_float(m[r]) > 0.0f) ? v[r] : 0.0f;
+                }
+                if (a.accumulate) {
+                    const u32x4 o = bld16(rout, off, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(o[r]);
+                }
+                u32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = __float_as_uint(v[r]);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rout, off, 0, 0);
+            } else {
+                if (a.mask) {
+                    const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rmask, off, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        // bf16 > 0  <=>  sign clear and magnitude non-zero
+                        const uint32_t lo = m[k] & 0xFFFFu, hi = m[k] >> 16;
+                        if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
+                        if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+                    }
+                }
+                if (a.accumulate) {
+                    const u32x2 o = __builtin_amdgcn_raw_buffer_load_b64(rout, off, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        v[2 * k] += bf2f((uint16_t)(o[k] & 0xFFFFu));
+                        v[2 * k + 1] += bf2f((uint16_t)(o[k] >> 16));
+                    }
+                }
+                u32x2 o;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+                __builtin_amdgcn_raw_buffer_store_b64(o, rout, off, 0, 0);
+            }
+        }
+    }
+}
+
 template <typename T, int BN, int NG>
 __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
@@ -223,11 +333,12 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     constexpr int WROW = wrow_bytes(STEPS * 4);     // weight-row pitch in LDS (bytes)
     constexpr int PIXP = pitch_bytes(NG * 16);     // patch-pixel pitch in LDS (bytes)
     constexpr int NF = BN / 16;
-    constexpr int OUTP = BN + 4;                   // epilogue row pitch (floats)
+    constexpr int OUTP = BN + 4;                   // pool2 epilogue row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;
     char* sP = smem + BN * WROW;
 
+    TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
     const int b = blockIdx.z;
@@ -239,13 +350,13 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int npix = a.toh * a.tow;
 
-    // the two fragment rows (pixels) of this lane
+    // the two fragment columns (pixels) of this lane
     int pbase[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
-        const int oy = p / a.tow, ox = p - oy * a.tow;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
         pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
     }
 
@@ -259,25 +370,37 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     // Staging goes global -> registers -> LDS.  The registers of chunk k+1 are loaded (all loads of a thread
     // issued back to back) BEFORE the MFMAs of chunk k and written to LDS after them, so global latency hides
     // under the matrix work instead of being paid once per 16-byte granule.
-    constexpr int WTOT = BN * STEPS * 4;                   // weight granules per chunk (incl. zero padding)
+    constexpr int WTOT = BN * NGR;                         // real weight granules per chunk
     constexpr int WIT = (WTOT + NT - 1) / NT;
     constexpr int PPF = 3;                                 // patch granules per thread that are prefetched
     const int ptotal = PH * PW * NG;
     const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
     u32x4 wv[WIT], pv[PPF];
 
-    // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread:
-    // byte offsets of this thread's weight granules (inside a.w, chunk 0) and of its patch granules inside the
-    // image of each source (-1 = zero fill).  Per chunk only `+ k*CK*ES` (weights) / `+ c0*ES` (patch) remains.
-    int woff[WIT];
+    // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread, and
+    // cheaply -- the set-up used to be most of a workgroup's VALU time:
+    //  * weights: granule i = it*256 + tid of the slab [BN][9][CK] sits at a.w + woff0 + it * (256/NG taps), i.e. ONE
+    //    per-thread offset plus a scalar stride (256 granules = 256/NG whole taps); rows beyond N fall outside the
+    //    descriptor and read as zero without a test.
+    //  * patch: magic-number division by the patch width, branch-free mode handling (shift / parity mask).
+    const int tapB = a.Ctot * ES;                          // bytes from tap to tap inside a weight row
+    int woff0, woffL, wlds[WIT];
+    {
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+    }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
         const int i = it * NT + tid;
-        const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4);
-        woff[it] = OOB_OFF;
-        if (i < WTOT && gi < NGR && n0 + n < a.N) {
-            const int tap = gi / NG, cg = gi - tap * NG;
-            woff[it] = (((n0 + n) * 9 + tap) * a.Ctot + cg * G) * ES;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
+        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
         }
     }
     // two named descriptors / offset sets (arrays of descriptors end up in scratch and turn every load into a
@@ -290,38 +413,45 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     };
     const __amdgpu_buffer_rsrc_t rimg0 = make_img(0), rimg1 = make_img(1);
     auto patch_off = [&](int sidx, int i) -> int {
-        const int Hs = a.g.Hs[sidx], Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
+        const int Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
+        const int sh = (mode != MODE_DIRECT) ? 1 : 0;       // up-sampled / zero-dilated sources are stored at half size
+        const int par = (mode == MODE_DILATE) ? 1 : 0;      // zero-dilated: only even virtual positions hold data
         const int pix = i / NG, cg = i - pix * NG;
-        const int py = pix / PW, px = pix - py * PW;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
         const int vy = iy0 + py, vx = ix0 + px;
-        bool inb = (Cs > 0) && (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
-        int sy = vy, sx = vx;
-        if (mode != MODE_DIRECT) {
-            if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
-            sy = vy >> 1; sx = vx >> 1;
-        }
-        inb = inb && (sy < Hs) && (sx < Ws);
-        return inb ? ((sy * Ws + sx) * Cs + cg * G) * ES : OOB_OFF;
+        // Hi = Hs << sh, Wi = Ws << sh, so the virtual-extent test covers the stored extent too
+        const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi) &&
+                         (((vy | vx) & par) == 0);
+        return inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + cg * G) * ES : OOB_OFF;
     };
     int poff0[PPF], poff1[PPF];
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         poff0[it] = patch_off(0, it * NT + tid);
-        poff1[it] = patch_off(1, it * NT + tid);
+        poff1[it] = OOB_OFF;
+    }
+    if (a.g.C[1] > 0) {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) poff1[it] = patch_off(1, it * NT + tid);
     }
 
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
     auto load_w = [&](int k) {
         const int so = k * CK * ES;
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) wv[it] = bld16(rw, woff[it], so);      // branch-free, zero-filled
+        for (int it = 0; it < WIT; ++it)                  // branch-free, zero-filled
+            wv[it] = bld16(rw, ((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB, so);
     };
+#ifdef COLVO_ABLATE
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) wv[it] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) pv[it] = u32x4{0u, 0u, 0u, 0u};
+#endif
     auto store_w = [&]() {
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = it * NT + tid;
-            if (i < WTOT) { const int n = i / (STEPS * 4), gi = i - n * (STEPS * 4); st16(sW + n * WROW + gi * 16, wv[it]); }
-        }
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
     };
     auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
         return sidx == 0 ? bld16(rimg0, patch_off(0, i), c0 * ES) : bld16(rimg1, patch_off(1, i), c0 * ES);
@@ -359,14 +489,15 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
         }
     };
 
-    load_w(0);
-    load_p(0);
+    TRACE(1);
+    if (!ABL(4)) { load_w(0); load_p(0); }
     for (int k = 0; k < nch; ++k) {
-        __syncthreads();                  // the MFMAs of chunk k-1 have finished reading LDS
-        store_w();
-        store_p(k);
-        __syncthreads();
-        if (k + 1 < nch) { load_w(k + 1); load_p(k + 1); }    // in flight during the MFMAs below
+        if (!ABL(16)) __syncthreads();    // the MFMAs of chunk k-1 have finished reading LDS
+        if (!ABL(8)) { store_w(); store_p(k); }
+        if (!ABL(16)) __syncthreads();
+        if (k == 0) TRACE(2);
+        if (k == 1) TRACE(3);
+        if (k + 1 < nch && !ABL(4)) { load_w(k + 1); load_p(k + 1); }    // in flight during the MFMAs below
         // MFMA phase: the fragments of k-group m+1 are read from LDS BEFORE the MFMAs of k-group m are issued
         // (two register sets), so the ~150-cycle LDS latency hides under the matrix pipe even at one wave per SIMD.
         {
@@ -375,7 +506,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
                 const int gi = 4 * m + kg;
                 int tap = gi / NG;
                 const int cg = gi - tap * NG;
-                tap = min(tap, 8);                      // padded k-groups multiply real A by zero B
+                tap = min(tap, 8);                      // padded k-groups multiply real pixels by zero weights
                 const int ky = tap / 3, kx = tap - 3 * ky;
                 const int aoff = (ky * PW + kx) * PIXP + cg * 16;
 #pragma unroll
@@ -383,18 +514,31 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
 #pragma unroll
                 for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
             };
-            read_frags(0, av[0], bv[0]);
+#ifdef COLVO_ABLATE
+            for (int q = 0; q < 2; ++q) {
+                for (int mf = 0; mf < 2; ++mf) av[q][mf] = u32x4{0u, 0u, 0u, 0u};
+                for (int nf = 0; nf < NF; ++nf) bv[q][nf] = u32x4{0u, 0u, 0u, 0u};
+            }
+#endif
+            if (!ABL(2)) read_frags(0, av[0], bv[0]);
 #pragma unroll
             for (int m = 0; m < STEPS; ++m) {
                 const int cur = m & 1;
-                if (m + 1 < STEPS) read_frags(m + 1, av[cur ^ 1], bv[cur ^ 1]);
+                if (m + 1 < STEPS && !ABL(2)) read_frags(m + 1, av[cur ^ 1], bv[cur ^ 1]);
+#ifdef COLVO_ABLATE
+                if (ABL(1)) {
+                    for (int mf = 0; mf < 2; ++mf) asm volatile("" ::"v"(av[cur][mf]));
+                    for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(bv[cur][nf]));
+                    continue;
+                }
+#endif
                 if constexpr (ES == 2) {
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
                             acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, av[cur][mf]), __builtin_bit_cast(bf16x8, bv[cur][nf]),
+                                __builtin_bit_cast(bf16x8, bv[cur][nf]), __builtin_bit_cast(bf16x8, av[cur][mf]),
                                 acc[mf][nf], 0, 0, 0);
                 } else {
 #pragma unroll
@@ -404,24 +548,34 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
 #pragma unroll
                             for (int nf = 0; nf < NF; ++nf)
                                 acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    __uint_as_float(av[cur][mf][j]), __uint_as_float(bv[cur][nf][j]), acc[mf][nf], 0, 0, 0);
+                                    __uint_as_float(bv[cur][nf][j]), __uint_as_float(av[cur][mf][j]), acc[mf][nf], 0, 0, 0);
                 }
             }
         }
     }
 
-    // ---- epilogue through LDS ----
+#ifdef COLVO_ABLATE
+    if (ABL(32)) {
+        for (int mf = 0; mf < 2; ++mf)
+            for (int nf = 0; nf < NF; ++nf) asm volatile("" ::"v"(acc[mf][nf]));
+        return;
+    }
+#endif
+    TRACE(4);
+    if (!a.pool2) {
+        conv_epilogue_direct<T, NF>(a, acc, b, oy0, ox0, n0, wave, l15, kg);
+        TRACE(5);
+        return;
+    }
+    // ---- pool2 epilogue through LDS ----
     __syncthreads();
     float* sOut = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                sOut[(wave * 32 + mf * 16 + 4 * kg + r) * OUTP + nf * 16 + l15] = acc[mf][nf][r];
+            *reinterpret_cast<f32x4*>(&sOut[(wave * 32 + mf * 16 + l15) * OUTP + nf * 16 + 4 * kg]) = acc[mf][nf];
     __syncthreads();
-
     conv_epilogue<T, BN>(a, sOut, b, oy0, ox0, n0, tid);
 }
 
@@ -647,90 +801,130 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     const int ptotal = PH * PW * NG;
     u32x4 dyv[DIT], pv[PPF];
 
-    auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
-        b = t / tiles_per_img;
-        const int tr_ = t - b * tiles_per_img;
-        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
-        oy0 = ty * a.toh; ox0 = tx * a.tow;
+    // Tile coordinates (image, tile row, tile column) are wave-uniform and advance incrementally; everything that
+    // depends on the thread only (its pixel / granule inside the tile or patch) is computed ONCE, with magic-number
+    // divisions.  Per tile a thread then needs a handful of adds and compares per staged granule -- this loop was
+    // VALU-bound on ~20 runtime integer divisions per tile.
+    struct TileC { int b, ty, tx; };
+    auto tile_next = [&](TileC& c) {
+        if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.b; } }
     };
+    TileC cur;
+    {
+        const int t = __builtin_amdgcn_readfirstlane(t_begin);
+        cur.b = t / tiles_per_img;
+        const int tr_ = t - cur.b * tiles_per_img;
+        cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
+    }
     // branch-free staging loads: buffer descriptors over the whole dY tensor / the whole source tensor, invalid
     // granules get an out-of-range offset and come back as zeros (see k_conv3x3)
     const long long dy_bytes = (long long)a.B * a.Ho * a.Wo * a.Cout * ES;
     const long long x_bytes = (long long)a.B * a.g.Hs[s] * a.g.Ws[s] * a.g.C[s] * ES;
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(dy_bytes < 0x7fffffffLL ? dy_bytes : 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[s], 0, (int)(x_bytes < 0x7fffffffLL ? x_bytes : 0x7fffffffLL), 0x00020000);
-    auto load_dy = [&](int t) {
-        int b, oy0, ox0;
-        tile_origin(t, b, oy0, ox0);
+    const int Hs = a.g.Hs[s], Ws = a.g.Ws[s], Cs = a.g.C[s];
+    const int sh = (a.g.mode[s] != MODE_DIRECT) ? 1 : 0;   // up-sampled source: stored at half size
+
+    int dy_off[DIT], dy_yx[DIT], dy_lds[DIT];             // offset inside the tile's image region, (oy << 16 | ox), LDS
 #pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            const int i = it * NT + tid;
-            const int p = i / DGR, gch = i - p * DGR;
-            const int oy = p / a.tow, ox = p - oy * a.tow;
-            const int gy = oy0 + oy, gx = ox0 + ox;
-            const bool ok = (i < BM * DGR) && (p < npix) && (gy < a.Ho) && (gx < a.Wo) && (co0 + gch * G < a.Cout);
-            const int off = ok ? ((((b * a.Ho + gy) * a.Wo + gx) * a.Cout) + co0 + gch * G) * ES : OOB_OFF;
-            dyv[it] = bld16(rdy, off, 0);
+    for (int it = 0; it < DIT; ++it) {
+        const int i = it * NT + tid;
+        const int pp_ = i / DGR, gch = i - pp_ * DGR;
+        const int oy = mdiv(pp_, a.m_tow), ox = pp_ - oy * a.tow;
+        const bool ok = (BM * DGR % NT == 0 || i < BM * DGR) && (pp_ < npix) && (co0 + gch * G < a.Cout);
+        dy_off[it] = ok ? ((oy * a.Wo + ox) * a.Cout + co0 + gch * G) * ES : OOB_OFF;
+        dy_yx[it] = (oy << 16) | ox;
+        dy_lds[it] = pp_ * DYP + gch * 16;
+    }
+    int p_yx[PPF], p_cg[PPF];                              // (py << 16 | px) inside the patch (py = 0x7fff: none), granule
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG;
+        p_cg[it] = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
+    }
+    auto load_dy = [&](const TileC& c) {
+        const int oy0 = c.ty * a.toh, ox0 = c.tx * a.tow;
+        const int base = ((c.b * a.Ho + oy0) * a.Wo + ox0) * a.Cout * ES;      // wave-uniform: the scalar offset
+        const int remy = a.Ho - oy0, remx = a.Wo - ox0;
+        if (remy >= a.toh && remx >= a.tow) {              // interior tile: no per-granule test
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) dyv[it] = bld16(rdy, dy_off[it], base);
+        } else {
+#pragma unroll
+            for (int it = 0; it < DIT; ++it) {
+                const bool ok = ((dy_yx[it] >> 16) < remy) && ((dy_yx[it] & 0xffff) < remx);
+                dyv[it] = bld16(rdy, ok ? dy_off[it] : OOB_OFF, base);
+            }
         }
     };
     auto store_dy = [&]() {
 #pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            const int i = it * NT + tid;
-            if (i < BM * DGR) { const int p = i / DGR, gch = i - p * DGR; st16(sDY + p * DYP + gch * 16, dyv[it]); }
-        }
+        for (int it = 0; it < DIT; ++it)
+            if (BM * DGR % NT == 0 || it * NT + tid < BM * DGR) st16(sDY + dy_lds[it], dyv[it]);
     };
-    auto patch_granule = [&](int t, int i) -> u32x4 {
-        int b, oy0, ox0;
-        tile_origin(t, b, oy0, ox0);
-        const int pix = i / NG, cg = i - pix * NG;
-        const int py = pix / PW, px = pix - py * PW;
-        const int vy = oy0 * S - 1 + py, vx = ox0 * S - 1 + px;
-        bool inb = (i < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
-        int sy = vy, sx = vx;
-        if (a.g.mode[s] != MODE_DIRECT) { sy = vy >> 1; sx = vx >> 1; }
-        const int Hs = a.g.Hs[s], Ws = a.g.Ws[s];
-        inb = inb && (sy < Hs) && (sx < Ws);
-        const int off = inb ? ((((b * Hs + sy) * Ws + sx) * a.g.C[s]) + c0 + cg * G) * ES : OOB_OFF;
-        return bld16(rx, off, 0);
+    auto patch_voff = [&](const TileC& c, int yx, int cg) -> int {
+        const int vy = c.ty * a.toh * S - 1 + (yx >> 16), vx = c.tx * a.tow * S - 1 + (yx & 0xffff);
+        const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi);
+        return inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + c0 + cg * G) * ES : OOB_OFF;
     };
-    auto load_p = [&](int t) {
+    auto load_p = [&](const TileC& c) {
+        const int base = c.b * Hs * Ws * Cs * ES;
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) pv[it] = patch_granule(t, it * NT + tid);
+        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rx, patch_voff(c, p_yx[it], p_cg[it]), base);
     };
-    auto store_p = [&](int t) {
+    auto store_p = [&](const TileC& c) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
             if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
         }
-        for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
+        // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
+        const int base = c.b * Hs * Ws * Cs * ES;
+        for (int g0 = PPF * NT; g0 < ptotal; g0 += 3 * NT) {
             u32x4 tt[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) tt[u] = patch_granule(t, base + u * NT + tid);
+            for (int u = 0; u < 3; ++u) {
+                const int i = g0 + u * NT + tid;
+                const int pix = i / NG, cg = i - pix * NG;
+                const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+                tt[u] = bld16(rx, (i < ptotal) ? patch_voff(c, (py << 16) | px, cg) : OOB_OFF, base);
+            }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int i = base + u * NT + tid;
+                const int i = g0 + u * NT + tid;
                 if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, tt[u]); }
             }
         }
     };
+    // bias gradient: all 256 threads, thread = (channel, pixel phase); NPH partial sums per channel meet in the atomics
+    constexpr int NPH = NT / (16 * MT);
+    const int db_co = tid % (16 * MT), db_ph = tid / (16 * MT);
 
-    if (t_begin < t_end) { load_dy(t_begin); load_p(t_begin); }
+    if (t_begin < t_end) { load_dy(cur); load_p(cur); }
     for (int t = t_begin; t < t_end; ++t) {
         __syncthreads();
         store_dy();
-        store_p(t);
+        store_p(cur);
         __syncthreads();
-        if (t + 1 < t_end) { load_dy(t + 1); load_p(t + 1); }      // in flight during the MFMAs below
+        tile_next(cur);
+        if (t + 1 < t_end) { load_dy(cur); load_p(cur); }          // in flight during the MFMAs below
 
-        if (blockIdx.z == 0 && a.db && tid < 16 * MT) {
-            float sacc = 0.0f;
-            for (int p = 0; p < npix; ++p) {
-                if constexpr (ES == 2) sacc += bf2f(*reinterpret_cast<const uint16_t*>(sDY + p * DYP + tid * 2));
-                else sacc += *reinterpret_cast<const float*>(sDY + p * DYP + tid * 4);
+        if (blockIdx.z == 0 && a.db) {
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 4
+            for (int p = db_ph; p < BM; p += 2 * NPH) {   // rows beyond the tile hold zeros
+                if constexpr (ES == 2) {
+                    s0 += bf2f(*reinterpret_cast<const uint16_t*>(sDY + p * DYP + db_co * 2));
+                    s1 += bf2f(*reinterpret_cast<const uint16_t*>(sDY + (p + NPH) * DYP + db_co * 2));
+                } else {
+                    s0 += *reinterpret_cast<const float*>(sDY + p * DYP + db_co * 4);
+                    s1 += *reinterpret_cast<const float*>(sDY + (p + NPH) * DYP + db_co * 4);
+                }
             }
-            dbacc += sacc;
+            dbacc += s0 + s1;
         }
 
         if constexpr (ES == 2) {
@@ -744,7 +938,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
                     int p = 32 * ks + 8 * kg + q + 4 * h;
                     yo[h] = p * DYP;
                     if (p >= npix) p = 0;     // its dY row is zero
-                    const int oy = p / a.tow, ox = p - oy * a.tow;
+                    const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
                     xo[h] = ((oy * S) * PW + ox * S) * PIXP;
                 }
                 s16x8 af[MT];
@@ -772,7 +966,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         } else {
             // K = 128 pixels in 32 steps of 4 (exact f32 MFMA 16x16x4); lane k-slot = kg
             int p = kg;
-            int oy = p / a.tow, ox = p - oy * a.tow;
+            int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
             for (int ks = 0; ks < BM / 4; ++ks) {
                 const bool live = p < npix;
                 const int xo = live ? ((oy * S) * PW + ox * S) * PIXP : 0;
@@ -805,7 +999,18 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
                 if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
             }
         }
-    if (blockIdx.z == 0 && a.db && tid < 16 * MT && co0 + tid < a.Cout) atomicAdd(a.db + co0 + tid, dbacc);
+    if (blockIdx.z == 0 && a.db) {                       // fold the NPH pixel phases in LDS: one atomic per channel
+        __syncthreads();
+        float* sdb = reinterpret_cast<float*>(smem);
+        sdb[tid] = dbacc;
+        __syncthreads();
+        if (tid < 16 * MT && co0 + tid < a.Cout) {
+            float t = 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
+            atomicAdd(a.db + co0 + tid, t);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------- //
@@ -850,6 +1055,43 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
         configured = 160 * 1024;
     }
     dim3 grid(k.tiles_x * k.tiles_y, (k.N + BN - 1) / BN, B);
+#ifdef COLVO_ABLATE
+    ConvK ka = k;
+    { const char* e = getenv("COLVO_ABL"); ka.abl = e ? atoi(e) : 0; }
+    ka.trace = nullptr;
+    static long long* tbuf = nullptr;
+    static int tcount = 0;
+    const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+    const bool tracing = getenv("COLVO_TRACE") && nwg <= (1u << 16);
+    if (tracing) {
+        if (!tbuf) hipMalloc(&tbuf, (size_t)(1u << 16) * 8 * sizeof(long long));
+        hipMemsetAsync(tbuf, 0, nwg * 8 * sizeof(long long), s);
+        ka.trace = tbuf;
+    }
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG>), grid, dim3(NT), lds, s, ka);
+    COLVO_CHECK_LAUNCH("k_conv3x3");
+    if (tracing && (++tcount % atoi(getenv("COLVO_TRACE"))) == 0) {     // every n-th launch: print the phase statistics
+        hipStreamSynchronize(s);
+        std::vector<long long> h(nwg * 8);
+        hipMemcpy(h.data(), tbuf, nwg * 8 * sizeof(long long), hipMemcpyDeviceToHost);
+        long long t0 = h[0], t1 = 0;
+        for (size_t i = 0; i < nwg; ++i) { t0 = std::min(t0, h[i * 8]); t1 = std::max(t1, h[i * 8 + 5] ? h[i * 8 + 5] : h[i * 8 + 4]); }
+        double ph[5] = {0, 0, 0, 0, 0}, start = 0, life = 0;
+        for (size_t i = 0; i < nwg; ++i) {
+            const long long* r = &h[i * 8];
+            const long long end = r[5] ? r[5] : r[4];
+            ph[0] += r[1] - r[0]; ph[1] += r[2] - r[1]; ph[2] += (r[3] ? r[3] - r[2] : 0); ph[3] += r[4] - (r[3] ? r[3] : r[2]);
+            ph[4] += end - r[4];
+            start += r[0] - t0; life += end - r[0];
+        }
+        const double c = 0.01 / nwg;   // 100 MHz ticks -> us, mean over workgroups
+        fprintf(stderr, "[trace] BN=%d NG=%d grid=%ux%ux%u nch=%d | span %.2f us | mean wg: start +%.2f life %.2f = setup %.2f"
+                " first-stage %.2f chunk0 %.2f rest %.2f epilogue %.2f\n", BN, NG, grid.x, grid.y, grid.z,
+                (k.g.C[0] + k.g.C[1]) / (NG * TT<T>::G), (t1 - t0) * 0.01, start * c, life * c, ph[0] * c, ph[1] * c, ph[2] * c,
+                ph[3] * c, ph[4] * c);
+    }
+    return 0;
+#endif
     hipLaunchKernelGGL((k_conv3x3<T, BN, NG>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
@@ -1013,6 +1255,7 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
     const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * d->stride + 3);
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
 }
@@ -1042,6 +1285,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     const Tile t = pick_tile(d->Hi, d->Wi, 1, up != 0);
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (d->Wi + t.tow - 1) / t.tow; k.tiles_y = (d->Hi + t.toh - 1) / t.toh;
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 2);
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
 }
@@ -1080,6 +1324,7 @@ extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const vo
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
     k.ntiles = d->B * k.tiles_x * k.tiles_y;
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * d->stride + 3);
     return d->dtype == COLVO_F32 ? launch_wgrad_t<float>(k, (hipStream_t)stream)
                                  : launch_wgrad_t<bf16_t>(k, (hipStream_t)stream);
 }

@@ -43,6 +43,7 @@ def timeit(fn, n=30):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.bfloat16
+    fwdonly = len(sys.argv) > 3 and sys.argv[3] == "fwdonly"
     dev = torch.device("cuda:0")
     tot = [0.0, 0.0, 0.0]
     print(f"{'layer':8s} {'shape':28s} {'GFLOP':>7s} | {'fwd us':>8s} {'GF/us':>6s} | {'dgrad us':>8s} {'GF/us':>6s} | {'wgrad us':>8s} {'GF/us':>6s}")
@@ -62,8 +63,8 @@ def main():
         db = torch.zeros(cout, device=dev)
         gf = 2.0 * cout * cin * 9 * d.Ho * d.Wo * b / 1e9
         tf = timeit(lambda: ops.conv_fwd(d, x0, x1, wf, bias, y))
-        td = timeit(lambda: ops.conv_dgrad(d, 0, dy, wb, x0, dx, False))
-        tw = timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db))
+        td = 1.0 if fwdonly else timeit(lambda: ops.conv_dgrad(d, 0, dy, wb, x0, dx, False))
+        tw = 1.0 if fwdonly else timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db))
         gd = gf * c0 / cin
         tot[0] += tf; tot[1] += td; tot[2] += tw
         shape = "%d+%d->%d @%dx%d s%d%s" % (c0, c1, cout, d.Ho, d.Wo, stride, " up" if up else "")
