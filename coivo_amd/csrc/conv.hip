@@ -245,87 +245,114 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut,
 // i.e. 8 / 16 contiguous bytes of the NHWC output -- the epilogue stores straight from the accumulators (bias, ReLU,
 // mask, accumulate per lane; buffer stores drop out-of-range lanes), with no LDS transposition and no index division.
 // Only pool2 (input gradient of an up-sampled source) still goes through the fp32 tile in LDS.
+template <typename T> struct EV;
+template <> struct EV<float> { typedef u32x4 type; };
+template <> struct EV<bf16_t> { typedef u32x2 type; };
+template <typename T>
+__device__ __forceinline__ typename EV<T>::type epi_load(__amdgpu_buffer_rsrc_t r, int off, int soff) {
+    if constexpr (TT<T>::ES == 4) return bld16(r, off, soff);
+    else return __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
+}
+
+// Direct epilogue in three steps so that a caller can issue the mask / accumulate loads early (persistent kernel:
+// before the tile's MFMAs): (1) byte offsets of the lane's two pixels, (2) loads, (3) arithmetic + stores.
+// rout / rmask: descriptors whose base + soff (wave-uniform) is pixel (0, 0) of the output image of this tile.
 template <typename T, int NF>
-__device__ __forceinline__ void conv_epilogue_direct(const ConvK& a, const f32x4 (&acc)[2][NF], int b, int oy0, int ox0,
-                                                     int n0, int wave, int l15, int kg) {
-    constexpr int ES = TT<T>::ES;
-    const int npix = a.toh * a.tow;
-    const int img_bytes = a.Ho * a.Wo * a.N * ES;
-    const __amdgpu_buffer_rsrc_t rout =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbias =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
-    int obase[2];
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        const int p = wave * 32 + mf * 16 + l15;
-        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        const int gy = oy0 + oy, gx = ox0 + ox;
-        const bool ok = (p < npix) && (gy < a.Ho) && (gx < a.Wo);
-        obase[mf] = ok ? (gy * a.Wo + gx) * a.N * ES : OOB_OFF;
-    }
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-        const int n = n0 + nf * 16 + kg * 4;
-        const int noff = (n < a.N) ? n * ES : OOB_OFF;
-        const u32x4 bs = bld16(rbias, n * 4, 0);          // zeros without a bias / beyond N
+struct Epi {
+    typedef typename EV<T>::type V;
+    static constexpr int ES = TT<T>::ES;
+    int off[2][NF];
+    V pm[2][NF], pa[2][NF];
+
+    __device__ __forceinline__ void offsets(const ConvK& a, int oy0, int ox0, int n0, int wave, int l15, int kg) {
+        const int npix = a.toh * a.tow;
+        int obase[2];
 #pragma unroll
         for (int mf = 0; mf < 2; ++mf) {
-            float v[4];
+            const int p = wave * 32 + mf * 16 + l15;
+            const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+            const int gy = oy0 + oy, gx = ox0 + ox;
+            const bool ok = (p < npix) && (gy < a.Ho) && (gx < a.Wo);
+            obase[mf] = ok ? (gy * a.Wo + gx) * a.N * ES : OOB_OFF;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + __uint_as_float(bs[r]);
-            if (a.relu) {
+        for (int nf = 0; nf < NF; ++nf) {
+            const int n = n0 + nf * 16 + kg * 4;
+            const int noff = (n < a.N) ? n * ES : OOB_OFF;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-            }
-            const int off = obase[mf] + noff;
-            if constexpr (ES == 4) {
-                if (a.mask) {
-                    const u32x4 m = bld16(rmask, off, 0);
+            for (int mf = 0; mf < 2; ++mf) off[mf][nf] = obase[mf] + noff;     // out of range -> loads 0 / store dropped
+        }
+    }
+    __device__ __forceinline__ void prefetch(const ConvK& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rmask, int soff) {
+        if (a.mask) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (__uint_as_float(m[r]) > 0.0f) ? v[r] : 0.0f;
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) pm[mf][nf] = epi_load<T>(rmask, off[mf][nf], soff);
+        }
+        if (a.accumulate) {
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) pa[mf][nf] = epi_load<T>(rout, off[mf][nf], soff);
+        }
+    }
+    __device__ __forceinline__ void finish(const ConvK& a, const f32x4 (&acc)[2][NF], const u32x4 (&biasv)[NF],
+                                           __amdgpu_buffer_rsrc_t rout, int soff) {
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const u32x4 bs = biasv[nf];                   // zeros without a bias / beyond N
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mf][nf][r] + __uint_as_float(bs[r]);
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
                 }
-                if (a.accumulate) {
-                    const u32x4 o = bld16(rout, off, 0);
+                if constexpr (ES == 4) {
+                    if (a.mask) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(o[r]);
-                }
-                u32x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = __float_as_uint(v[r]);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rout, off, 0, 0);
-            } else {
-                if (a.mask) {
-                    const u32x2 m = __builtin_amdgcn_raw_buffer_load_b64(rmask, off, 0, 0);
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        // bf16 > 0  <=>  sign clear and magnitude non-zero
-                        const uint32_t lo = m[k] & 0xFFFFu, hi = m[k] >> 16;
-                        if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
-                        if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+                        for (int r = 0; r < 4; ++r) v[r] = (__uint_as_float(pm[mf][nf][r]) > 0.0f) ? v[r] : 0.0f;
                     }
-                }
-                if (a.accumulate) {
-                    const u32x2 o = __builtin_amdgcn_raw_buffer_load_b64(rout, off, 0, 0);
+                    if (a.accumulate) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        v[2 * k] += bf2f((uint16_t)(o[k] & 0xFFFFu));
-                        v[2 * k + 1] += bf2f((uint16_t)(o[k] >> 16));
+                        for (int r = 0; r < 4; ++r) v[r] += __uint_as_float(pa[mf][nf][r]);
                     }
-                }
-                u32x2 o;
+                    u32x4 o;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
-                __builtin_amdgcn_raw_buffer_store_b64(o, rout, off, 0, 0);
+                    for (int r = 0; r < 4; ++r) o[r] = __float_as_uint(v[r]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rout, off[mf][nf], soff, 0);
+                } else {
+                    if (a.mask) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            // bf16 > 0  <=>  sign clear and magnitude non-zero
+                            const uint32_t lo = pm[mf][nf][k] & 0xFFFFu, hi = pm[mf][nf][k] >> 16;
+                            if (!(lo != 0 && lo < 0x8000u)) v[2 * k] = 0.0f;
+                            if (!(hi != 0 && hi < 0x8000u)) v[2 * k + 1] = 0.0f;
+                        }
+                    }
+                    if (a.accumulate) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            v[2 * k] += bf2f((uint16_t)(pa[mf][nf][k] & 0xFFFFu));
+                            v[2 * k + 1] += bf2f((uint16_t)(pa[mf][nf][k] >> 16));
+                        }
+                    }
+                    u32x2 o;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, rout, off[mf][nf], soff, 0);
+                }
             }
         }
     }
-}
+};
 
-template <typename T, int BN, int NG>
-__global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
+template <typename T, int BN, int NG, int DEPTH>
+__global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x3(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G;
     constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     constexpr int PPF = 3;                                 // patch granules per thread that are prefetched
     const int ptotal = PH * PW * NG;
     const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
-    u32x4 wv[WIT], pv[PPF];
+    u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];                  // DEPTH chunks in flight (register ring)
 
     // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread, and
     // cheaply -- the set-up used to be most of a workgroup's VALU time:
@@ -436,43 +463,46 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
     }
 
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
-    auto load_w = [&](int k) {
+    auto load_w = [&](int k, u32x4 (&w)[WIT]) {
         const int so = k * CK * ES;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)                  // branch-free, zero-filled
-            wv[it] = bld16(rw, ((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB, so);
+            w[it] = bld16(rw, ((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB, so);
     };
 #ifdef COLVO_ABLATE
 #pragma unroll
-    for (int it = 0; it < WIT; ++it) wv[it] = u32x4{0u, 0u, 0u, 0u};
+    for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-    for (int it = 0; it < PPF; ++it) pv[it] = u32x4{0u, 0u, 0u, 0u};
+        for (int it = 0; it < WIT; ++it) wv[d][it] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) pv[d][it] = u32x4{0u, 0u, 0u, 0u};
+    }
 #endif
-    auto store_w = [&]() {
+    auto store_w = [&](const u32x4 (&w)[WIT]) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
     };
     auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
         return sidx == 0 ? bld16(rimg0, patch_off(0, i), c0 * ES) : bld16(rimg1, patch_off(1, i), c0 * ES);
     };
-    auto load_p = [&](int k) {
+    auto load_p = [&](int k, u32x4 (&pvv)[PPF]) {
         int sidx, c0;
         chunk_src(k, sidx, c0);
         const int so = c0 * ES;
         if (sidx == 0) {
 #pragma unroll
-            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg0, poff0[it], so);
+            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg0, poff0[it], so);
         } else {
 #pragma unroll
-            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, poff1[it], so);
+            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg1, poff1[it], so);
         }
     };
-    auto store_p = [&](int k) {
+    auto store_p = [&](int k, const u32x4 (&pvv)[PPF]) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pv[it]); }
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
         int sidx, c0;
@@ -488,16 +518,32 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
             }
         }
     };
+    // bias of this lane's output channels, fetched now so that its latency is not paid in the epilogue
+    u32x4 biasv[NF];
+    {
+        const __amdgpu_buffer_rsrc_t rbias =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);   // zeros without a bias
+    }
 
     TRACE(1);
-    if (!ABL(4)) { load_w(0); load_p(0); }
-    for (int k = 0; k < nch; ++k) {
+    if (!ABL(4)) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (d < nch) { load_w(d, wv[d]); load_p(d, pv[d]); }
+    }
+    for (int k0 = 0; k0 < nch; k0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 + d;
+        if (DEPTH > 1 && k >= nch) break;
         if (!ABL(16)) __syncthreads();    // the MFMAs of chunk k-1 have finished reading LDS
-        if (!ABL(8)) { store_w(); store_p(k); }
+        if (!ABL(8)) { store_w(wv[d]); store_p(k, pv[d]); }
         if (!ABL(16)) __syncthreads();
         if (k == 0) TRACE(2);
         if (k == 1) TRACE(3);
-        if (k + 1 < nch && !ABL(4)) { load_w(k + 1); load_p(k + 1); }    // in flight during the MFMAs below
+        if (k + DEPTH < nch && !ABL(4)) { load_w(k + DEPTH, wv[d]); load_p(k + DEPTH, pv[d]); }    // in flight during the next DEPTH MFMA phases
         // MFMA phase: the fragments of k-group m+1 are read from LDS BEFORE the MFMAs of k-group m are issued
         // (two register sets), so the ~150-cycle LDS latency hides under the matrix pipe even at one wave per SIMD.
         {
@@ -552,6 +598,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
                 }
             }
         }
+      }
     }
 
 #ifdef COLVO_ABLATE
@@ -563,7 +610,15 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
 #endif
     TRACE(4);
     if (!a.pool2) {
-        conv_epilogue_direct<T, NF>(a, acc, b, oy0, ox0, n0, wave, l15, kg);
+        const int img_bytes = a.Ho * a.Wo * a.N * ES;
+        const __amdgpu_buffer_rsrc_t rout =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
+        Epi<T, NF> ep;
+        ep.offsets(a, oy0, ox0, n0, wave, l15, kg);
+        ep.prefetch(a, rout, rmask, 0);
+        ep.finish(a, acc, biasv, rout, 0);
         TRACE(5);
         return;
     }
@@ -588,7 +643,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3(const ConvK a) {
 // slab ONCE, then loops over output tiles (grid-stride), prefetching the next tile's patch into registers while the
 // current tile's MFMAs and epilogue run.  The fp32 output staging tile aliases the patch region.
 template <typename T, int BN, int NG>
-__global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
+__global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, uint32_t m_tpi, uint32_t m_tx) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int NGR = 9 * NG;
     constexpr int STEPS = (NGR + 3) / 4;
@@ -602,7 +657,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;
     char* sP = smem + BN * WROW;
-    float* sOut = reinterpret_cast<float*>(sP);    // aliases the patch (dead once the MFMAs have read it)
+    float* sOut = reinterpret_cast<float*>(sP);    // pool2 only: aliases the patch (dead once the MFMAs have read it)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
@@ -638,7 +693,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
     for (int mf = 0; mf < 2; ++mf) {
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
-        const int oy = p / a.tow, ox = p - oy * a.tow;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
         pbase[mf] = (oy * PW + ox) * PIXP;
     }
     // patch granules of this thread: (pixel, granule) inside the patch are tile-invariant
@@ -648,37 +703,49 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
         const int i = it * NT + tid;
         const int pix = i / NG;
         pcg[it] = i - pix * NG;
-        ppy[it] = pix / PW; ppx[it] = pix - ppy[it] * PW;
+        ppy[it] = (i < ptotal) ? mdiv(pix, a.m_pw) : 0x4000; ppx[it] = pix - mdiv(pix, a.m_pw) * PW;   // 0x4000: never in range
     }
     const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0], mode = a.g.mode[0];
-    // descriptor over the WHOLE source tensor (host guarantees < 1 GiB): offsets >= its size (OOB_OFF) read as zero
-    const int xbytes = (ntiles / tiles_per_img) * Hs * Ws * Cs * ES;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, xbytes, 0x00020000);
+    const int sh = (mode != MODE_DIRECT) ? 1 : 0, par = (mode == MODE_DILATE) ? 1 : 0;
+    // descriptors over the WHOLE tensors (host guarantees < 1 GiB each): offsets >= the size (OOB_OFF) read as zero
+    const int nimg = ntiles / tiles_per_img;
+    const int img_in = Hs * Ws * Cs * ES, img_out = a.Ho * a.Wo * a.N * ES;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, nimg * img_in, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, nimg * img_out, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? nimg * img_out : 0, 0x00020000);
+    u32x4 biasv[NF];
+    {
+        const __amdgpu_buffer_rsrc_t rbias =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);
+    }
+    struct TileO { int b, oy0, ox0; };
+    auto tile_origin = [&](int tile) -> TileO {      // wave-uniform; magic divisions (host checks the ranges)
+        const int t = __builtin_amdgcn_readfirstlane(tile);
+        const int b = mdiv(t, m_tpi), tr_ = t - b * tiles_per_img;
+        const int ty = mdiv(tr_, m_tx), tx = tr_ - ty * a.tiles_x;
+        return TileO{b, ty * a.toh, tx * a.tow};
+    };
     u32x4 pv[PPF];
-    auto load_p = [&](int tile) {
-        const int b = tile / tiles_per_img, tr_ = tile - b * tiles_per_img;
-        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
-        const int iy0 = ty * a.toh - 1, ix0 = tx * a.tow - 1;
-        const int ibase = b * Hs * Ws;
+    auto load_p = [&](const TileO& o) {
+        const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
+        const int soff = o.b * img_in;
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int vy = iy0 + ppy[it], vx = ix0 + ppx[it];
-            bool inb = (it * NT + tid < ptotal) && (vy >= 0) && (vy < a.g.Hi) && (vx >= 0) && (vx < a.g.Wi);
-            int sy = vy, sx = vx;
-            if (mode != MODE_DIRECT) {
-                if (mode == MODE_DILATE) inb = inb && !((vy | vx) & 1);
-                sy = vy >> 1; sx = vx >> 1;
-            }
-            inb = inb && (sy < Hs) && (sx < Ws);
-            const int off = inb ? ((ibase + sy * Ws + sx) * Cs + pcg[it] * G) * ES : OOB_OFF;
-            pv[it] = bld16(rx, off, 0);
+            const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi) && (((vy | vx) & par) == 0);
+            const int off = inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + pcg[it] * G) * ES : OOB_OFF;
+            pv[it] = bld16(rx, off, soff);
         }
     };
 
     int tile = blockIdx.x;
-    if (tile < ntiles) load_p(tile);
+    TileO cur = tile_origin(tile < ntiles ? tile : 0);
+    if (tile < ntiles) load_p(cur);
     for (; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();                      // the previous tile's epilogue has finished reading sOut (= sP)
+        __syncthreads();                      // the previous tile's MFMAs (pool2: epilogue) have finished reading sP
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
@@ -686,7 +753,13 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
         }
         __syncthreads();
         const int next = tile + gridDim.x;
-        if (next < ntiles) load_p(next);      // in flight during the MFMAs and the epilogue below
+        const TileO nxt = tile_origin(next < ntiles ? next : 0);
+        if (next < ntiles) load_p(nxt);       // in flight during the MFMAs and the epilogue below
+        Epi<T, NF> ep;                        // mask / accumulate operands of THIS tile: also in flight during its MFMAs
+        if (!a.pool2) {
+            ep.offsets(a, cur.oy0, cur.ox0, n0, wave, l15, kg);
+            ep.prefetch(a, rout, rmask, cur.b * img_out);
+        }
 
         f32x4 acc[2][NF];
 #pragma unroll
@@ -706,13 +779,14 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
             for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+            // operands swapped (A = weights, B = pixels): see k_conv3x3
             if constexpr (ES == 2) {
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
                     for (int nf = 0; nf < NF; ++nf)
                         acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, av[mf]), __builtin_bit_cast(bf16x8, bv[nf]), acc[mf][nf], 0, 0, 0);
+                            __builtin_bit_cast(bf16x8, bv[nf]), __builtin_bit_cast(bf16x8, av[mf]), acc[mf][nf], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -721,21 +795,22 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles) {
 #pragma unroll
                         for (int nf = 0; nf < NF; ++nf)
                             acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                __uint_as_float(av[mf][j]), __uint_as_float(bv[nf][j]), acc[mf][nf], 0, 0, 0);
+                                __uint_as_float(bv[nf][j]), __uint_as_float(av[mf][j]), acc[mf][nf], 0, 0, 0);
             }
         }
-        __syncthreads();                      // every wave is done reading the patch: it becomes the output tile
+        if (!a.pool2) {
+            ep.finish(a, acc, biasv, rout, cur.b * img_out);
+        } else {
+            __syncthreads();                  // every wave is done reading the patch: it becomes the output tile
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+            for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-            for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    sOut[(wave * 32 + mf * 16 + 4 * kg + r) * OUTP + nf * 16 + l15] = acc[mf][nf][r];
-        __syncthreads();
-        const int b = tile / tiles_per_img, tr_ = tile - b * tiles_per_img;
-        const int ty = tr_ / a.tiles_x, tx = tr_ - ty * a.tiles_x;
-        conv_epilogue<T, BN>(a, sOut, b, ty * a.toh, tx * a.tow, n0, tid);
+                for (int nf = 0; nf < NF; ++nf)
+                    *reinterpret_cast<f32x4*>(&sOut[(wave * 32 + mf * 16 + l15) * OUTP + nf * 16 + 4 * kg]) = acc[mf][nf];
+            __syncthreads();
+            conv_epilogue<T, BN>(a, sOut, cur.b, cur.oy0, cur.ox0, n0, tid);
+        }
+        cur = nxt;
     }
 }
 
@@ -1037,7 +1112,7 @@ Tile pick_tile(int Ho, int Wo, int stride, bool even) {
     return best;
 }
 
-template <typename T, int BN, int NG>
+template <typename T, int BN, int NG, int DEPTH = 1>
 int launch_conv(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
@@ -1049,7 +1124,7 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;   // per instantiation
     if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG, DEPTH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
@@ -1068,7 +1143,7 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
         hipMemsetAsync(tbuf, 0, nwg * 8 * sizeof(long long), s);
         ka.trace = tbuf;
     }
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG>), grid, dim3(NT), lds, s, ka);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH>), grid, dim3(NT), lds, s, ka);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     if (tracing && (++tcount % atoi(getenv("COLVO_TRACE"))) == 0) {     // every n-th launch: print the phase statistics
         hipStreamSynchronize(s);
@@ -1092,7 +1167,7 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     }
     return 0;
 #endif
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG>), grid, dim3(NT), lds, s, k);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
 }
@@ -1108,7 +1183,8 @@ int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     int gx = 256 * 4;                           // ~4 workgroups per CU, each walking ntiles / gx tiles
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
-    hipLaunchKernelGGL((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles);
+    hipLaunchKernelGGL((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
+                       mdiv_magic(k.tiles_x));
     COLVO_CHECK_LAUNCH("k_conv3x3_res");
     return 0;
 }
@@ -1119,8 +1195,11 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
     if constexpr (BN <= 32) {
         const int ck = ng * TT<T>::G;
         const long long src_bytes = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * TT<T>::ES;
-        if (k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL &&
-            (long)k.tiles_x * k.tiles_y * B >= 2048) {
+        const long long out_bytes = (long long)B * k.Ho * k.Wo * k.N * TT<T>::ES / (k.pool2 ? 4 : 1);
+        const long long tpi = (long long)k.tiles_x * k.tiles_y;
+        if (k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL && out_bytes < 0x40000000LL &&
+            tpi >= 2 && k.tiles_x >= 2 && tpi * tpi * B < 0x100000000LL &&        // magic-division ranges
+            tpi * B >= 2048) {
             switch (ng) {
                 case 4: return launch_conv_res<T, BN, 4>(k, B, s);
                 case 2: return launch_conv_res<T, BN, 2>(k, B, s);
@@ -1129,7 +1208,16 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
         }
     }
     switch (ng) {
-        case 4: return launch_conv<T, BN, 4>(k, B, s);
+        case 4:
+            // many-chunk layers at the lowest resolutions: two chunks in flight, because one MFMA phase (~0.5 us) is
+            // shorter than the global-load latency it is supposed to hide
+            if constexpr (BN == 32) {
+                // measured: pays only when the grid is at most one workgroup per CU (it costs occupancy: 176 VGPRs)
+                static const int depth2_min = [] { const char* e = getenv("COLVO_DEPTH2_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
+                const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
+                if (wgs <= 256 && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) return launch_conv<T, BN, 4, 2>(k, B, s);
+            }
+            return launch_conv<T, BN, 4>(k, B, s);
         case 2: return launch_conv<T, BN, 2>(k, B, s);
         default: return launch_conv<T, BN, 1>(k, B, s);
     }
