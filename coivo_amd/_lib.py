@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -24,6 +24,15 @@ class ConvDesc(C.Structure):
 
 
 # name -> (restype, argtypes); lists every symbol include/colvo.h declares
+class Cmd(C.Structure):
+    """Mirror of ColvoCmd (include/colvo.h)."""
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("desc", ConvDesc), ("p", C.c_void_p * 8),
+                ("i", C.c_int32 * 12), ("f", C.c_float * 4)]
+
+
+(CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
+ CMD_DEPTH_HEAD_BWD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN) = range(1, 12)
+
 SIGNATURES = {
     "colvo_abi_version": (_i, []),
     "colvo_last_error": (C.c_char_p, []),
@@ -44,6 +53,7 @@ SIGNATURES = {
     "colvo_pose_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
+    "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -42,22 +42,46 @@ struct PackEntry {
     long long w_off, fwd_off, bwd_off;
     int Cout, kk, Cin, blk_begin;
 };
+constexpr int PK_CO = 32, PK_C = 64;       // transpose tile: 32 output channels x 64 input channels of one tap
 template <int ES>
 __global__ __launch_bounds__(NT) void k_pack_weights_multi(const float* __restrict__ master, const PackEntry* __restrict__ tab,
                                                            int nlayers, void* __restrict__ fwd, void* __restrict__ bwd) {
+    // LDS-tiled transpose: reads (and the forward copy) run along Cin, the transposed copy is written along Cout --
+    // the element-per-thread version scattered 2-byte stores at a stride of Cout and ran at ~1 TB/s
+    __shared__ float tile[PK_CO][PK_C + 1];
     int l = 0;
     for (int i = 1; i < nlayers; ++i)
         if ((int)blockIdx.x >= tab[i].blk_begin) l = i;
     const PackEntry e = tab[l];
-    const size_t n = (size_t)e.Cout * e.kk * e.Cin;
-    const size_t i = (size_t)(blockIdx.x - e.blk_begin) * NT + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % e.Cin);
-    const int t = (int)((i / e.Cin) % e.kk);
-    const int co = (int)(i / ((size_t)e.Cin * e.kk));
-    const float v = master[e.w_off + i];
-    if (fwd && e.fwd_off >= 0) Elem<ES>::st(fwd, e.fwd_off + i, v);
-    Elem<ES>::st(bwd, e.bwd_off + ((size_t)c * e.kk + (e.kk - 1 - t)) * e.Cout + co, v);
+    const int nct = (e.Cin + PK_C - 1) / PK_C, ncot = (e.Cout + PK_CO - 1) / PK_CO;
+    const int lb = blockIdx.x - e.blk_begin;
+    const int t = lb / (ncot * nct), r = lb - t * (ncot * nct);
+    const int cot = r / nct, ct = r - cot * nct;
+    const int co0 = cot * PK_CO, c0 = ct * PK_C;
+    const int tid = threadIdx.x;
+    {
+        const int cc = c0 + (tid & 63);
+#pragma unroll
+        for (int i = 0; i < PK_CO / 4; ++i) {
+            const int row = (tid >> 6) + 4 * i, co = co0 + row;
+            if (co < e.Cout && cc < e.Cin) {
+                const size_t idx = ((size_t)co * e.kk + t) * e.Cin + cc;
+                const float v = master[e.w_off + idx];
+                tile[row][tid & 63] = v;
+                if (fwd && e.fwd_off >= 0) Elem<ES>::st(fwd, e.fwd_off + idx, v);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int co = co0 + (tid & 31);
+#pragma unroll
+        for (int i = 0; i < PK_C / 8; ++i) {
+            const int col = (tid >> 5) + 8 * i, cc = c0 + col;
+            if (co < e.Cout && cc < e.Cin)
+                Elem<ES>::st(bwd, e.bwd_off + ((size_t)cc * e.kk + (e.kk - 1 - t)) * e.Cout + co, tile[tid & 31][col]);   // taps flipped
+        }
+    }
 }
 
 // ---------------------------------------------------------------- NCHW <-> NHWC -------------- //

@@ -13,6 +13,10 @@ MI355X-first host design
     and reporting each finished layer to an optional hook (gradient buckets for data parallel).
   * Feature maps are NHWC in `compute_dtype` (torch.float32 = exact-f32 MFMA parity mode,
     torch.bfloat16 = throughput mode, fp32 accumulation in both).
+  * Each pass (forward / backward of a network at one shape) is RECORDED once as a command list with persistent
+    activation buffers and replayed by one native call (program.py, colvo_run_commands): driven layer by layer from
+    Python the batch-8 step was bound by the host's ~18 us per launch, not by the GPU.  COLVO_NO_PROGRAM=1 keeps the
+    layer-by-layer path (same code, not recorded).
 """
 from __future__ import annotations
 
@@ -25,6 +29,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .program import Program
 
 ENC_CH = (32, 64, 128, 256, 512)
 DEC_CH = (16, 32, 64, 128, 256)
@@ -65,6 +70,9 @@ class _ArenaModule(nn.Module):
         self._pack_dtype = None
         self._side = None
         self._plans = {}
+        self._insts: Dict[tuple, List["_PassInst"]] = {}     # recorded programs + their activation buffers, per shape
+        self.use_programs = os.environ.get("COLVO_NO_PROGRAM") is None
+        self._rec: Optional[Program] = None
         self.overlap_wgrad = os.environ.get("COLVO_NO_OVERLAP") is None
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
 
@@ -106,6 +114,7 @@ class _ArenaModule(nn.Module):
         self.flat_param, self.flat_grad = flat, grad
         self._packed_version = None
         self._pack_table = None
+        self._insts = {}            # recorded programs hold pointers into the old arena
 
     def _apply(self, fn, *a, **kw):   # .to() / .cuda(): rebuild the arena on the new device
         super()._apply(fn, *a, **kw)
@@ -143,6 +152,7 @@ class _ArenaModule(nn.Module):
             tab = np.zeros(len(layers), dtype=np.dtype([("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"),
                                                         ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4")]))
             total = sum(L.cout * 9 * L.cin_pad for L in layers)
+            self._insts = {}        # recorded programs hold pointers into the old operand copies
             self._op_bwd = torch.empty(total, device=dev, dtype=dt)
             self._op_fwd = None if dt == torch.float32 else torch.empty(total, device=dev, dtype=dt)
             off = blk = 0
@@ -152,12 +162,66 @@ class _ArenaModule(nn.Module):
                 L.w_bwd = self._op_bwd[off:off + n].view(L.cin_pad, 9, L.cout)
                 L.w_fwd = L.w_master if self._op_fwd is None else self._op_fwd[off:off + n].view(L.cout, 9, L.cin_pad)
                 off += n
-                blk += (n + 255) // 256
+                blk += 9 * ((L.cout + 31) // 32) * ((L.cin_pad + 63) // 64)   # include/colvo.h: colvo_pack_weights_multi
             self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
             self._pack_n, self._pack_blocks, self._pack_dtype = len(layers), blk, dt
         ops.pack_weights_multi(self.flat_param, self._pack_table, self._pack_n, self._pack_blocks, dt, self._op_fwd,
                                self._op_bwd)
         self._packed_version = ver
+
+    # ---- recorded passes ------------------------------------------------------------------------------- #
+    def clear_programs(self) -> None:
+        """Drop the recorded programs and their persistent activation buffers."""
+        self._insts = {}
+
+    def _acquire(self, key) -> "_PassInst":
+        pool = self._insts.setdefault(key, [])
+        for inst in pool:
+            if not inst.busy:
+                inst.busy = True
+                return inst
+        inst = _PassInst()
+        inst.busy = True
+        pool.append(inst)
+        return inst
+
+    def _run_pass(self, inst: "_PassInst", which: str, externals: Dict[str, torch.Tensor], body):
+        """Run body() -- a sequence of ops.* calls -- as the pass `which` of `inst`: recorded on first use, replayed
+        afterwards with the externals' pointers patched in.  Returns what body() returned when it was recorded."""
+        if not self.use_programs:
+            return body()
+        entry = inst.passes.get(which)
+        if entry is None:
+            with Program() as pr:
+                self._rec = pr
+                try:
+                    for name, t in externals.items():
+                        pr.external(name, t)
+                    out = body()
+                finally:
+                    self._rec = None
+            entry = inst.passes[which] = (pr, out)
+        else:
+            pr = entry[0]
+            for name, t in externals.items():
+                pr.patch(name, t)
+        pr, out = entry
+        if pr.uses_side and self._side is None:
+            self._side = torch.cuda.Stream(device=self.flat_param.device)
+        if self.grad_ready_hook is None or not pr.marks:
+            pr.run(self._side)
+        else:                       # data parallel: report every finished layer between the segments of the program
+            done = 0
+            for idx, (L, on_side) in pr.marks:
+                pr.run(self._side, done, idx)
+                done = idx
+                if on_side:
+                    with torch.cuda.stream(self._side):
+                        self.grad_ready_hook(self, L.span[0], L.span[1])
+                else:
+                    self.grad_ready_hook(self, L.span[0], L.span[1])
+            pr.run(self._side, done, None)
+        return out
 
     # ---- backward scheduling: weight gradients on a side stream, concurrent with the input gradients ------ #
     def _bwd_begin(self) -> None:
@@ -170,9 +234,18 @@ class _ArenaModule(nn.Module):
         """fn() enqueues the weight-gradient kernel(s) of layer L; with overlap it runs on the side stream,
         ordered after everything already enqueued on the main stream (its inputs), and so does the
         gradient-ready hook (the data-parallel all-reduce of finished buckets)."""
+        rec = self._rec
         if not self.overlap_wgrad:
             fn()
             self._layer_done(L)
+            return
+        if rec is not None:
+            rec.fork()
+            rec.stream = 1
+            fn()
+            self._layer_done(L)
+            rec.stream = 0
+            self._side_used = True
             return
         ev = torch.cuda.Event()
         ev.record(self._main)
@@ -187,10 +260,15 @@ class _ArenaModule(nn.Module):
 
     def _bwd_end(self) -> None:
         if self.overlap_wgrad and self._side_used:
-            self._main.wait_stream(self._side)
+            if self._rec is not None:
+                self._rec.join()
+            else:
+                self._main.wait_stream(self._side)
 
     def _layer_done(self, L: ConvParams) -> None:
-        if self.grad_ready_hook is not None:
+        if self._rec is not None:
+            self._rec.mark((L, self._rec.stream == 1))
+        elif self.grad_ready_hook is not None:
             self.grad_ready_hook(self, L.span[0], L.span[1])
 
     def _trigger(self) -> torch.Tensor:
@@ -200,6 +278,30 @@ class _ArenaModule(nn.Module):
             t = torch.zeros(1, device=self.flat_param.device, requires_grad=True)
             self._trig = t
         return t
+
+
+class _PassInst:
+    """The recorded passes of one network at one shape, with the activation buffers they refer to.  `busy` from a
+    forward that may still get a backward until that backward ran (or its autograd context died): a second forward
+    in between gets its own instance instead of overwriting the saved activations."""
+
+    def __init__(self):
+        self.busy = False
+        self.passes: Dict[str, tuple] = {}
+        self.saved = None
+
+
+class _Lease:
+    def __init__(self, inst: Optional[_PassInst]):
+        self.inst = inst
+
+    def release(self) -> None:
+        if self.inst is not None:
+            self.inst.busy = False
+            self.inst = None
+
+    def __del__(self):
+        self.release()
 
 
 def _conv(x0, L: ConvParams, desc, x1=None):
@@ -262,65 +364,75 @@ class DepthNet(_ArenaModule):
             raise RuntimeError("DepthNet: expects a float32 CUDA tensor (no CPU fallback)")
         self._prepare_weights()
         P = self._plan(B, H, W)
-        A: Dict[str, torch.Tensor] = {}
-        x = ops.pack_nchw([img], 8, self.compute_dtype)
-        A["in"] = x
-        for i in range(1, 6):
-            x = _conv(x, getattr(self, f"enc{i}a"), P[f"enc{i}a"]); A[f"enc{i}a"] = x
-            x = _conv(x, getattr(self, f"enc{i}b"), P[f"enc{i}b"]); A[f"enc{i}b"] = x
-        for i in range(5, 0, -1):
-            x = _conv(x, getattr(self, f"up{i}"), P[f"up{i}"]); A[f"up{i}"] = x
-            x = _conv(x, getattr(self, f"iconv{i}"), P[f"iconv{i}"], A[f"enc{i - 1}b"] if i >= 2 else None)
-            A[f"iconv{i}"] = x
+        img = img.contiguous()
         depth = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
-        ops.depth_head_fwd(x, self.head.w_master, self.head.bias.data, depth)
-        return depth, (A, P)
+        inst = self._acquire((B, H, W, self.compute_dtype))
+
+        def body():
+            A: Dict[str, torch.Tensor] = {}
+            x = ops.pack_nchw([img], 8, self.compute_dtype)
+            A["in"] = x
+            for i in range(1, 6):
+                x = _conv(x, getattr(self, f"enc{i}a"), P[f"enc{i}a"]); A[f"enc{i}a"] = x
+                x = _conv(x, getattr(self, f"enc{i}b"), P[f"enc{i}b"]); A[f"enc{i}b"] = x
+            for i in range(5, 0, -1):
+                x = _conv(x, getattr(self, f"up{i}"), P[f"up{i}"]); A[f"up{i}"] = x
+                x = _conv(x, getattr(self, f"iconv{i}"), P[f"iconv{i}"], A[f"enc{i - 1}b"] if i >= 2 else None)
+                A[f"iconv{i}"] = x
+            ops.depth_head_fwd(x, self.head.w_master, self.head.bias.data, depth)
+            return A
+
+        A = self._run_pass(inst, "fwd", {"img": img, "depth": depth}, body)
+        return depth, (A, P, inst)
 
     def _backward_impl(self, saved, depth: torch.Tensor, d_depth: torch.Tensor) -> None:
-        A, P = saved
+        A, P, inst = saved
         self.attach_grads()
         B, _, H, W = depth.shape
         dev = depth.device
+        d_depth = d_depth.contiguous()
 
-        self._bwd_begin()
+        def body():
+            self._bwd_begin()
 
-        def wgrad(name, x0, x1, dy):
-            L = getattr(self, name)
-            self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias), x0, x1, dy)
+            def wgrad(name, x0, x1, dy):
+                L = getattr(self, name)
+                self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias), x0, x1, dy)
 
-        def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
-            L = getattr(self, name)
-            if dx is None:
-                dx = torch.empty_like(mask_like)
-            ops.conv_dgrad(P[name], src, dy, L.w_bwd, mask_like, dx, accumulate)
-            return dx
+            def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
+                L = getattr(self, name)
+                if dx is None:
+                    dx = torch.empty_like(mask_like)
+                ops.conv_dgrad(P[name], src, dy, L.w_bwd, mask_like, dx, accumulate)
+                return dx
 
-        x1 = A["iconv1"]
-        g = torch.empty_like(x1)
-        scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
-        ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth.contiguous(), scratch, g, self.head.g_master,
-                           self.head.g_bias)
-        self._layer_done(self.head)
-        d_skip: Dict[int, torch.Tensor] = {}
-        for i in range(1, 6):                       # decoder, output side first
-            u = A[f"up{i}"]
-            skip = A[f"enc{i - 1}b"] if i >= 2 else None
-            wgrad(f"iconv{i}", u, skip, g)
-            d_u = dgrad(f"iconv{i}", 0, g, u)
-            if skip is not None:
-                d_skip[i - 1] = dgrad(f"iconv{i}", 1, g, skip)
-            below = A[f"iconv{i + 1}"] if i < 5 else A["enc5b"]
-            wgrad(f"up{i}", below, None, d_u)
-            g = dgrad(f"up{i}", 0, d_u, below)
-        for i in range(5, 0, -1):                   # encoder
-            a = A[f"enc{i}a"]
-            wgrad(f"enc{i}b", a, None, g)
-            g_a = dgrad(f"enc{i}b", 0, g, a)
-            src = A["in"] if i == 1 else A[f"enc{i - 1}b"]
-            wgrad(f"enc{i}a", src, None, g_a)
-            if i > 1:
-                g = dgrad(f"enc{i}a", 0, g_a, src, dx=d_skip[i - 1], accumulate=True)
-        self._bwd_end()
+            x1 = A["iconv1"]
+            g = torch.empty_like(x1)
+            scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
+            ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, self.head.g_master, self.head.g_bias)
+            self._layer_done(self.head)
+            d_skip: Dict[int, torch.Tensor] = {}
+            for i in range(1, 6):                       # decoder, output side first
+                u = A[f"up{i}"]
+                skip = A[f"enc{i - 1}b"] if i >= 2 else None
+                wgrad(f"iconv{i}", u, skip, g)
+                d_u = dgrad(f"iconv{i}", 0, g, u)
+                if skip is not None:
+                    d_skip[i - 1] = dgrad(f"iconv{i}", 1, g, skip)
+                below = A[f"iconv{i + 1}"] if i < 5 else A["enc5b"]
+                wgrad(f"up{i}", below, None, d_u)
+                g = dgrad(f"up{i}", 0, d_u, below)
+            for i in range(5, 0, -1):                   # encoder
+                a = A[f"enc{i}a"]
+                wgrad(f"enc{i}b", a, None, g)
+                g_a = dgrad(f"enc{i}b", 0, g, a)
+                src = A["in"] if i == 1 else A[f"enc{i - 1}b"]
+                wgrad(f"enc{i}a", src, None, g_a)
+                if i > 1:
+                    g = dgrad(f"enc{i}a", 0, g_a, src, dx=d_skip[i - 1], accumulate=True)
+            self._bwd_end()
+
+        self._run_pass(inst, "bwd", {"depth": depth, "d_depth": d_depth}, body)
 
 
 class _DepthNetFn(torch.autograd.Function):
@@ -328,6 +440,7 @@ class _DepthNetFn(torch.autograd.Function):
     def forward(ctx, net: DepthNet, img, trigger):
         depth, saved = net._forward_impl(img)
         ctx.net, ctx.saved = net, saved
+        ctx.lease = _Lease(saved[2])          # frees the pass instance when this context dies without a backward
         ctx.save_for_backward(depth)
         return depth
 
@@ -336,6 +449,7 @@ class _DepthNetFn(torch.autograd.Function):
         (depth,) = ctx.saved_tensors
         ctx.net._backward_impl(ctx.saved, depth, d_depth)
         ctx.saved = None
+        ctx.lease.release()
         return None, None, None
 
 
@@ -367,9 +481,8 @@ class PoseNet(_ArenaModule):
                 raise ValueError("PoseNet: depth maps must be [B,1,H,W]")
         self._prepare_weights()
         dt = self.compute_dtype
-        srcs = [tgt, ref] + ([d_t.contiguous(), d_r.contiguous()] if d_t is not None else [])
-        x = ops.pack_nchw(srcs, 8, dt)
-        A = {"in": x}
+        has_depth = d_t is not None
+        srcs = [tgt.contiguous(), ref.contiguous()] + ([d_t.contiguous(), d_r.contiguous()] if has_depth else [])
         key = (B, H, W, dt)
         P = self._plans.get(key)
         if P is None:
@@ -378,39 +491,58 @@ class PoseNet(_ArenaModule):
             for i, c in enumerate(POSE_CH, start=1):
                 P[i] = ops.conv_desc(dt, B, h, w, cin, c, stride=2)
                 h, w, cin = P[i].Ho, P[i].Wo, c
-        for i in range(1, 8):
-            x = _conv(x, getattr(self, f"conv{i}"), P[i])
-            A[i] = x
         out = torch.empty(8 * B, device=tgt.device, dtype=torch.float32)     # planar: [pose Bx6 | a B | b B]
-        ops.pose_head_fwd(x, self.pred.w_master, self.pred.bias.data, out)
-        return out, (A, P, (B, H, W), d_t is not None)
+        inst = self._acquire((B, H, W, dt, has_depth))
+
+        def body():
+            x = ops.pack_nchw(srcs, 8, dt)
+            A = {"in": x}
+            for i in range(1, 8):
+                x = _conv(x, getattr(self, f"conv{i}"), P[i])
+                A[i] = x
+            ops.pose_head_fwd(x, self.pred.w_master, self.pred.bias.data, out)
+            return A
+
+        ext = {f"src{k}": t for k, t in enumerate(srcs)}
+        ext["out"] = out
+        A = self._run_pass(inst, "fwd", ext, body)
+        return out, (A, P, (B, H, W), has_depth, inst)
 
     def _backward_impl(self, saved, d_pose, d_a, d_b):
-        A, P, (B, H, W), has_depth = saved
+        A, P, (B, H, W), has_depth, inst = saved
         self.attach_grads()
-        self._bwd_begin()
-        x = A[7]
-        g = torch.empty_like(x)
-        ops.pose_head_bwd(x, self.pred.w_master, None if d_pose is None else d_pose.contiguous(),
-                          None if d_a is None else d_a.contiguous(), None if d_b is None else d_b.contiguous(),
-                          g, self.pred.g_master, self.pred.g_bias)
-        self._layer_done(self.pred)
-        for i in range(7, 0, -1):
-            L = getattr(self, f"conv{i}")
-            src = A["in"] if i == 1 else A[i - 1]
-            self._run_wgrad(L, lambda L=L, i=i, src=src, g=g: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias),
-                            src, g)
-            if i > 1 or has_depth:
-                dx = torch.empty_like(src)
-                ops.conv_dgrad(P[i], 0, g, L.w_bwd, src if i > 1 else None, dx, False)
-                g = dx
-        self._bwd_end()
-        if not has_depth:
-            return None, None
-        d_t = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)
-        d_r = torch.empty(B, 1, H, W, device=g.device, dtype=torch.float32)
-        ops.unpack_nhwc_grad(g, 6, 1, d_t, False)
-        ops.unpack_nhwc_grad(g, 7, 1, d_r, False)
+        dev = self.flat_param.device
+        grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b}
+        grads = {k: v.contiguous() for k, v in grads.items() if v is not None}
+        d_t = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
+        d_r = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
+
+        def body():
+            self._bwd_begin()
+            x = A[7]
+            g = torch.empty_like(x)
+            ops.pose_head_bwd(x, self.pred.w_master, grads.get("d_pose"), grads.get("d_a"), grads.get("d_b"),
+                              g, self.pred.g_master, self.pred.g_bias)
+            self._layer_done(self.pred)
+            for i in range(7, 0, -1):
+                L = getattr(self, f"conv{i}")
+                src = A["in"] if i == 1 else A[i - 1]
+                self._run_wgrad(L, lambda L=L, i=i, src=src, g=g: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias),
+                                src, g)
+                if i > 1 or has_depth:
+                    dx = torch.empty_like(src)
+                    ops.conv_dgrad(P[i], 0, g, L.w_bwd, src if i > 1 else None, dx, False)
+                    g = dx
+            self._bwd_end()
+            if has_depth:
+                ops.unpack_nhwc_grad(g, 6, 1, d_t, False)
+                ops.unpack_nhwc_grad(g, 7, 1, d_r, False)
+
+        ext = dict(grads)
+        if has_depth:
+            ext["d_t"], ext["d_r"] = d_t, d_r
+        which = "bwd:" + ",".join(sorted(grads))       # a missing (None) gradient changes the recorded commands
+        self._run_pass(inst, which, ext, body)
         return d_t, d_r
 
 
@@ -419,6 +551,7 @@ class _PoseNetFn(torch.autograd.Function):
     def forward(ctx, net: PoseNet, tgt, ref, d_t, d_r, trigger):
         out, saved = net._forward_impl(tgt, ref, d_t, d_r)
         ctx.net, ctx.saved = net, saved
+        ctx.lease = _Lease(saved[4])
         B = tgt.shape[0]
         # three contiguous views of the planar head output: no slicing kernels forward or backward
         return out[:6 * B].view(B, 6), out[6 * B:7 * B].view(B, 1), out[7 * B:].view(B, 1)
@@ -427,6 +560,7 @@ class _PoseNetFn(torch.autograd.Function):
     def backward(ctx, d_pose, d_a, d_b):
         d_t, d_r = ctx.net._backward_impl(ctx.saved, d_pose, d_a, d_b)
         ctx.saved = None
+        ctx.lease.release()
         return None, None, None, d_t, d_r, None
 
 

@@ -10,7 +10,7 @@ from typing import Optional, Sequence, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, program
 from ._lib import ConvDesc
 
 MIN_DEPTH, MAX_DEPTH = 0.1, 10.0
@@ -44,6 +44,9 @@ def conv_desc(dtype: torch.dtype, B: int, Hi: int, Wi: int, C0: int, Cout: int, 
 
 def conv_fwd(d: ConvDesc, x0, x1, w_fwd, bias, y) -> None:
     _need_cuda(x0, x1, w_fwd, bias, y)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_FWD, d, (x0, x1, w_fwd, bias, y))
     lib = _lib.load()
     _lib.check(lib.colvo_conv_fwd(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(w_fwd), _lib.ptr(bias),
                                   _lib.ptr(y), _lib.stream_ptr()), "colvo_conv_fwd")
@@ -51,6 +54,9 @@ def conv_fwd(d: ConvDesc, x0, x1, w_fwd, bias, y) -> None:
 
 def conv_dgrad(d: ConvDesc, src: int, dy, w_bwd, relu_mask, dx, accumulate: bool) -> None:
     _need_cuda(dy, w_bwd, relu_mask, dx)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_DGRAD, d, (dy, w_bwd, relu_mask, dx), (src, int(accumulate)))
     lib = _lib.load()
     _lib.check(lib.colvo_conv_dgrad(C.byref(d), src, _lib.ptr(dy), _lib.ptr(w_bwd), _lib.ptr(relu_mask),
                                     _lib.ptr(dx), int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad")
@@ -58,6 +64,9 @@ def conv_dgrad(d: ConvDesc, src: int, dy, w_bwd, relu_mask, dx, accumulate: bool
 
 def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db) -> None:
     _need_cuda(x0, x1, dy, dw, db)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, dw, db))
     lib = _lib.load()
     _lib.check(lib.colvo_conv_wgrad(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw),
                                     _lib.ptr(db), _lib.stream_ptr()), "colvo_conv_wgrad")
@@ -91,6 +100,11 @@ def pack_nchw(srcs: Sequence[torch.Tensor], Cpad: int, dtype: torch.dtype, out: 
     if out is None:
         out = torch.empty(B, H, W, Cpad, device=srcs[0].device, dtype=dtype)
     n = len(srcs)
+    rec = program.recording()
+    if rec is not None:
+        rec.add(_lib.CMD_PACK_NCHW, None, list(srcs) + [None] * (4 - n) + [out],
+                [dt_code(dtype)] + [s.shape[1] for s in srcs] + [0] * (4 - n) + [n, B, H, W, Cpad])
+        return out
     ptrs = (C.c_void_p * n)(*[s.data_ptr() for s in srcs])
     chans = (C.c_int32 * n)(*[s.shape[1] for s in srcs])
     lib = _lib.load()
@@ -102,6 +116,10 @@ def pack_nchw(srcs: Sequence[torch.Tensor], Cpad: int, dtype: torch.dtype, out: 
 def unpack_nhwc_grad(dsrc: torch.Tensor, c_begin: int, c_count: int, dst: torch.Tensor, accumulate: bool) -> None:
     _need_cuda(dsrc, dst)
     B, H, W, Cpad = dsrc.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_UNPACK_NHWC_GRAD, None, (dsrc, dst),
+                       (dt_code(dsrc.dtype), B, H, W, Cpad, c_begin, c_count, int(accumulate)))
     lib = _lib.load()
     _lib.check(lib.colvo_unpack_nhwc_grad(dt_code(dsrc.dtype), _lib.ptr(dsrc), B, H, W, Cpad, c_begin, c_count,
                                           _lib.ptr(dst), int(accumulate), _lib.stream_ptr()), "colvo_unpack_nhwc_grad")
@@ -117,6 +135,10 @@ def relu_bwd_inplace(y: torch.Tensor, dy: torch.Tensor) -> None:
 def depth_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, depth: torch.Tensor) -> None:
     _need_cuda(x, w, bias, depth)
     B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_DEPTH_HEAD_FWD, None, (x, w, bias, depth), (dt_code(x.dtype), B, H, W, Cc),
+                       (MIN_DEPTH, MAX_DEPTH))
     lib = _lib.load()
     _lib.check(lib.colvo_depth_head_fwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), B, H, W, Cc,
                                         MIN_DEPTH, MAX_DEPTH, _lib.ptr(depth), _lib.stream_ptr()), "colvo_depth_head_fwd")
@@ -125,6 +147,10 @@ def depth_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, depth: 
 def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
     _need_cuda(x, w, depth, d_depth, scratch, dx, dw, db)
     B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_DEPTH_HEAD_BWD, None, (x, w, depth, d_depth, scratch, dx, dw, db),
+                       (dt_code(x.dtype), B, H, W, Cc), (MIN_DEPTH, MAX_DEPTH))
     lib = _lib.load()
     _lib.check(lib.colvo_depth_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(depth), _lib.ptr(d_depth),
                                         B, H, W, Cc, MIN_DEPTH, MAX_DEPTH, _lib.ptr(scratch), _lib.ptr(dx), _lib.ptr(dw),
@@ -135,6 +161,10 @@ def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: tor
     """out: 8*B floats, planar [pose Bx6 | lcc_a B | lcc_b B]."""
     _need_cuda(x, w, bias, out)
     B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_POSE_HEAD_FWD, None, (x, w, bias, out), (dt_code(x.dtype), B, H * W, Cc),
+                       (POSE_SCALE, LCC_SCALE))
     lib = _lib.load()
     _lib.check(lib.colvo_pose_head_fwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(bias), B, H * W, Cc,
                                        POSE_SCALE, LCC_SCALE, _lib.ptr(out), _lib.stream_ptr()), "colvo_pose_head_fwd")
@@ -144,6 +174,10 @@ def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db) -> None:
     """d_pose [B,6] / d_a [B,1] / d_b [B,1] contiguous or None (= zero)."""
     _need_cuda(x, w, d_pose, d_a, d_b, dx, dw, db)
     B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_POSE_HEAD_BWD, None, (x, w, d_pose, d_a, d_b, dx, dw, db),
+                       (dt_code(x.dtype), B, H * W, Cc), (POSE_SCALE, LCC_SCALE))
     lib = _lib.load()
     _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_pose), _lib.ptr(d_a),
                                        _lib.ptr(d_b), B, H * W, Cc, POSE_SCALE, LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw),

@@ -1,0 +1,114 @@
+"""Recorded command lists: the host side of colvo_run_commands (include/colvo.h).
+
+`ops.*` calls made while a Program is recording are appended to it instead of being launched.  The recorded list is then
+replayed with ONE C-ABI call per network pass.  All tensors a command refers to are kept alive by the Program (the
+activation buffers of a plan are therefore persistent); the few pointers that differ from call to call -- input images,
+the output, incoming gradients -- are registered as externals and patched before each replay.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_active: Optional["Program"] = None
+
+
+def recording() -> Optional["Program"]:
+    return _active
+
+
+class Program:
+    def __init__(self):
+        self.cmds: List[_lib.Cmd] = []
+        self.keep: List[torch.Tensor] = []
+        self.stream = 0                      # stream selector of the commands being recorded (0 main, 1 side)
+        self.marks: List[Tuple[int, object]] = []     # (number of commands recorded so far, payload) -- hook points
+        self._ext: Dict[str, int] = {}       # external name -> data pointer at record time
+        self._slots: Dict[str, List[Tuple[int, int]]] = {}
+        self._arr = None
+        self.uses_side = False
+
+    # ---- recording ------------------------------------------------------------------------------------------- #
+    def __enter__(self):
+        global _active
+        if _active is not None:
+            raise RuntimeError("nested Program recording")
+        _active = self
+        return self
+
+    def __exit__(self, *exc):
+        global _active
+        _active = None
+        if exc[0] is None:
+            self._finalize()
+        return False
+
+    def external(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """Declare `t` (used by the commands recorded from now on) as a per-call pointer called `name`."""
+        self._ext[name] = t.data_ptr()
+        return t
+
+    def add(self, op: int, desc=None, p: Sequence[Optional[torch.Tensor]] = (), i: Sequence[int] = (),
+            f: Sequence[float] = ()) -> None:
+        c = _lib.Cmd()
+        c.op, c.stream = op, self.stream
+        if desc is not None:
+            c.desc = desc
+        for k, t in enumerate(p):
+            if t is not None:
+                c.p[k] = t.data_ptr()
+                self.keep.append(t)
+        for k, v in enumerate(i):
+            c.i[k] = int(v)
+        for k, v in enumerate(f):
+            c.f[k] = float(v)
+        if self.stream:
+            self.uses_side = True
+        self.cmds.append(c)
+
+    def fork(self) -> None:
+        self.uses_side = True
+        self.add(_lib.CMD_FORK)
+
+    def join(self) -> None:
+        self.add(_lib.CMD_JOIN)
+
+    def mark(self, payload) -> None:
+        self.marks.append((len(self.cmds), payload))
+
+    def _finalize(self) -> None:
+        n = len(self.cmds)
+        self._arr = (_lib.Cmd * max(n, 1))(*self.cmds)
+        by_ptr = {ptr: name for name, ptr in self._ext.items()}
+        if len(by_ptr) != len(self._ext):
+            raise RuntimeError("two externals of a Program share one address")
+        self._slots = {name: [] for name in self._ext}
+        for ci in range(n):
+            for k in range(8):
+                name = by_ptr.get(self._arr[ci].p[k])
+                if name is not None:
+                    self._slots[name].append((ci, k))
+        self.cmds = []   # the array is the program now
+
+    # ---- replay ---------------------------------------------------------------------------------------------- #
+    def patch(self, name: str, t: torch.Tensor) -> None:
+        ptr = t.data_ptr()
+        arr = self._arr
+        for ci, k in self._slots[name]:
+            arr[ci].p[k] = ptr
+
+    def run(self, side: Optional[torch.cuda.Stream], begin: int = 0, end: Optional[int] = None) -> None:
+        n = len(self._arr) if end is None else end
+        if n <= begin:
+            return
+        lib = _lib.load()
+        base = C.addressof(self._arr) + begin * C.sizeof(_lib.Cmd)
+        _lib.check(lib.colvo_run_commands(base, n - begin, torch.cuda.current_stream().cuda_stream,
+                                          0 if side is None else side.cuda_stream), "colvo_run_commands")
+
+    def __len__(self) -> int:
+        return len(self._arr) if self._arr is not None else len(self.cmds)

@@ -11,7 +11,7 @@
  *   - the caller owns every buffer (inputs, outputs, workspace); the library never allocates,
  *     frees or keeps a pointer after return.
  *   - every call only ENQUEUES work on `stream` and returns; no internal synchronisation, no
- *     global mutable state -> safe under one-process-per-GPU data parallel and under hipGraph
+ *     global mutable state (colvo_run_commands keeps a ring of fork/join events) -> safe under one-process-per-GPU data parallel and under hipGraph
  *     capture.
  *   - return 0 on success, a non-zero hipError_t-style code otherwise; the message is available
  *     from colvo_last_error() (thread-local).  Nothing throws across the ABI.
@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 1
+#define COLVO_ABI_VERSION 2
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -119,8 +119,8 @@ int colvo_pack_weights(int dtype, const float* w_master, int Cout, int kk, int C
 /* The same for every 3x3 layer of a network in ONE launch.  `table` (device memory) is an array of
  *   struct { int64 w_off, fwd_off, bwd_off; int32 Cout, kk, Cin, blk_begin; }
  * with element offsets into `master` (fp32 arena), `fwd` and `bwd` (flat operand buffers in `dtype`; fwd_off < 0
- * or fwd == NULL skips the forward copy) and the index of the layer's first 256-thread workgroup;
- * nblocks = sum over layers of ceil(Cout*kk*Cin / 256). */
+ * or fwd == NULL skips the forward copy) and the index of the layer's first workgroup; a layer takes
+ * kk * ceil(Cout/32) * ceil(Cin/64) workgroups (one 32 x 64 transpose tile of one tap each) and nblocks is their sum. */
 int colvo_pack_weights_multi(int dtype, const float* master, const void* table, int nlayers, int nblocks,
                              void* fwd, void* bwd, colvo_stream_t stream);
 
@@ -157,6 +157,38 @@ int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d
 int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     int32_t* step_count, colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * Command lists: ONE call enqueues a recorded sequence of the entry points above (a network's  *
+ * forward or backward) on a main and a side stream -- the host's per-launch cost, not the GPU, *
+ * bounded the batch-8 step when every layer was a separate host call.                          *
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    COLVO_CMD_CONV_FWD = 1,      /* p: x0 x1 w_fwd bias y */
+    COLVO_CMD_CONV_DGRAD,        /* i: src accumulate; p: dy w_bwd relu_mask dx */
+    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db */
+    COLVO_CMD_PACK_NCHW,         /* i: dtype c0 c1 c2 c3 nsrc B H W Cpad; p: src0..src3 dst */
+    COLVO_CMD_UNPACK_NHWC_GRAD,  /* i: dtype B H W Cpad c_begin c_count accumulate; p: dsrc dst */
+    COLVO_CMD_DEPTH_HEAD_FWD,    /* i: dtype B H W C; f: min max; p: x w bias depth */
+    COLVO_CMD_DEPTH_HEAD_BWD,    /* i: dtype B H W C; f: min max; p: x w depth d_depth scratch dx dw db */
+    COLVO_CMD_POSE_HEAD_FWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w bias out */
+    COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db */
+    COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
+    COLVO_CMD_JOIN               /* main stream waits for the side stream's work so far */
+};
+
+typedef struct ColvoCmd {
+    int32_t op;                  /* COLVO_CMD_* */
+    int32_t stream;              /* 0 = main, 1 = side */
+    ColvoConvDesc desc;          /* conv commands */
+    const void* p[8];            /* pointer arguments in the order listed above (device memory, caller-owned) */
+    int32_t i[12];               /* integer arguments in the order listed above */
+    float f[4];
+} ColvoCmd;
+
+/* Enqueue cmds[0..n) in order; side_stream may be NULL when no command uses it.  FORK/JOIN use a small ring of
+ * library-owned events (host objects; still no device allocation).  Stops at the first failing command. */
+int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, colvo_stream_t side_stream);
 
 #ifdef __cplusplus
 }

@@ -234,3 +234,35 @@ def test_adam_matches_torch():
                       beta2=S.ADAM_KW["betas"][1], eps=S.ADAM_KW["eps"])
     assert int(step.item()) == 3
     assert torch.allclose(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pack_weights_multi_matches_permute(dtype):
+    """One-launch packing of several layers (ragged against the 32 x 64 transpose tile) == cast / permute + tap flip."""
+    import numpy as np
+    from coivo_amd import ops
+    d = torch.device("cuda:0")
+    shapes = [(32, 8), (40, 72), (16, 16), (136, 200), (8, 64)]        # (Cout, Cin)
+    g = torch.Generator().manual_seed(5)
+    total = sum(co * 9 * ci for co, ci in shapes)
+    master = torch.randn(total + 64, generator=g)                       # 64 spare floats in front: non-zero w_off
+    tab = np.zeros(len(shapes), dtype=np.dtype([("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"),
+                                                ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4")]))
+    off, blk = 0, 0
+    for i, (co, ci) in enumerate(shapes):
+        tab[i] = (64 + off, off, off, co, 9, ci, blk)
+        off += co * 9 * ci
+        blk += 9 * ((co + 31) // 32) * ((ci + 63) // 64)
+    fwd = torch.full((total,), 3.0, device=d, dtype=dtype)
+    bwd = torch.full((total,), 3.0, device=d, dtype=dtype)
+    table = torch.from_numpy(tab.view(np.uint8).copy()).to(d)
+    ops.pack_weights_multi(master.to(d), table, len(shapes), blk, dtype, fwd, bwd)
+    off = 0
+    for co, ci in shapes:
+        n = co * 9 * ci
+        w = master[64 + off:64 + off + n].view(co, 9, ci)
+        assert torch.equal(fwd[off:off + n].cpu().view(co, 9, ci), w.to(dtype)), (co, ci, "fwd")
+        ref_b = w.flip(1).permute(2, 1, 0).contiguous().to(dtype)
+        assert torch.equal(bwd[off:off + n].cpu().view(ci, 9, co), ref_b), (co, ci, "bwd")
+        off += n
