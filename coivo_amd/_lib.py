@@ -31,7 +31,7 @@ class Cmd(C.Structure):
 
 
 (CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
- CMD_DEPTH_HEAD_BWD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN) = range(1, 12)
+ CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN) = range(1, 13)
 
 SIGNATURES = {
     "colvo_abi_version": (_i, []),
@@ -50,6 +50,7 @@ SIGNATURES = {
     "colvo_unpack_nhwc_grad": (_i, [_i, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "colvo_depth_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_depth_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "colvo_depth_head_wgrad": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "colvo_pose_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),

@@ -264,8 +264,24 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
     for (int q = p0 + (int)threadIdx.x; q < p1; q += NT) {
         const int qy = q / W, qx = q - qy * W;
         float xv[C];
+        {   // the pixel's C channels as 16-byte vectors (C * ES is a multiple of 16)
+            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+            const u4* px = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(x) + ((size_t)b * HW + q) * C * ES);
 #pragma unroll
-        for (int c = 0; c < C; ++c) xv[c] = Elem<ES>::ld(x, ((size_t)b * HW + q) * C + c);
+            for (int v = 0; v < C * ES / 16; ++v) {
+                const u4 t = px[v];
+                if constexpr (ES == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xv[4 * v + k] = __uint_as_float(t[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xv[8 * v + 2 * k] = __uint_as_float(t[k] << 16);
+                        xv[8 * v + 2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
+                    }
+                }
+            }
+        }
         sb += dpre[(size_t)b * HW + q];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -512,7 +528,8 @@ extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, co
 extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* depth, const float* d_depth,
                                     int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
                                     void* dx, float* dw, float* db, colvo_stream_t stream) {
-    COLVO_CHECK_ARG(x && w && depth && d_depth && scratch && dx && dw && db, "colvo_depth_head_bwd: null pointer argument");
+    COLVO_CHECK_ARG(x && w && depth && d_depth && scratch && dx && ((dw == nullptr) == (db == nullptr)),
+                    "colvo_depth_head_bwd: null pointer argument");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_bwd: bad dtype");
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
                     "colvo_depth_head_bwd: bad shape / range");
@@ -521,19 +538,34 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
     const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
     hipLaunchKernelGGL(k_depth_head_dpre, dim3(nblk(n)), dim3(NT), 0, s, depth, d_depth, n, lo, hi, scratch);
     COLVO_CHECK_LAUNCH("k_depth_head_dpre");
-    if (C == 16) {
-        const int ppb = 2048;   // pixels per workgroup (8 per thread)
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
-                                              dim3(NT), 0, s, x, scratch, H, W, ppb, dw, db));
-    } else {
-        const int rows = 4;
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
-                                              0, s, x, scratch, H, W, C, rows, dw, db));
+    if (dw) {
+        if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
     }
-    COLVO_CHECK_LAUNCH("k_depth_head_wgrad");
     DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
                                           x, w, scratch, H, W, C, dx));
     COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
+    return 0;
+}
+
+// The weight / bias gradient alone, from the d(pre) plane colvo_depth_head_bwd left in `scratch` (so that it can run on
+// another stream than the input gradient).
+extern "C" int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw,
+                                      float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && dpre && dw && db, "colvo_depth_head_wgrad: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_wgrad: bad dtype");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024, "colvo_depth_head_wgrad: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W;
+    if (C == 16) {
+        const int ppb = 2048;   // pixels per workgroup (8 per thread)
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
+                                              dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+    } else {
+        const int rows = 4;
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
+                                              0, s, x, dpre, H, W, C, rows, dw, db));
+    }
+    COLVO_CHECK_LAUNCH("k_depth_head_wgrad");
     return 0;
 }
 

@@ -63,6 +63,10 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                                           c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[4], (void*)c.p[5],
                                           (float*)c.p[6], (float*)c.p[7], s);
                 break;
+            case COLVO_CMD_DEPTH_HEAD_WGRAD:
+                rc = colvo_depth_head_wgrad(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4],
+                                            (float*)c.p[2], (float*)c.p[3], s);
+                break;
             case COLVO_CMD_POSE_HEAD_FWD:
                 rc = colvo_pose_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3],
                                          c.f[0], c.f[1], (float*)c.p[3], s);

@@ -409,8 +409,10 @@ class DepthNet(_ArenaModule):
             x1 = A["iconv1"]
             g = torch.empty_like(x1)
             scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
-            ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, self.head.g_master, self.head.g_bias)
-            self._layer_done(self.head)
+            # head: d(pre) + input gradient on the main stream, its weight gradient beside it like every other layer's
+            ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
+            self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias),
+                            x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
             for i in range(1, 6):                       # decoder, output side first
                 u = A[f"up{i}"]
@@ -463,7 +465,8 @@ class PoseNet(_ArenaModule):
             setattr(self, f"conv{i}", ConvParams(cin, c, 3))
             cin = c
         self.pred = ConvParams(cin, 8, 1)
-        self.overlap_wgrad = False      # 7 tiny layers: the fork/join bookkeeping costs more than it hides
+        # 7 tiny layers: driven from Python the fork/join bookkeeping costs more than it hides; recorded it is free
+        self.overlap_wgrad = self.overlap_wgrad and self.use_programs and os.environ.get("COLVO_POSE_OVERLAP") is not None
         self._build_arena(torch.device(device))
 
     def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):

@@ -157,6 +157,18 @@ def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
                                         _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_bwd")
 
 
+def depth_head_wgrad(x, dpre, dw, db) -> None:
+    """Weight / bias gradient of the depth head from the d(pre) plane depth_head_bwd(dw=None, db=None) left in scratch."""
+    _need_cuda(x, dpre, dw, db)
+    B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_DEPTH_HEAD_WGRAD, None, (x, dpre, dw, db), (dt_code(x.dtype), B, H, W, Cc))
+    lib = _lib.load()
+    _lib.check(lib.colvo_depth_head_wgrad(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(dpre), B, H, W, Cc, _lib.ptr(dw),
+                                          _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_wgrad")
+
+
 def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> None:
     """out: 8*B floats, planar [pose Bx6 | lcc_a B | lcc_b B]."""
     _need_cuda(x, w, bias, out)

@@ -133,12 +133,15 @@ int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H, int W, int
 
 /* DepthNet head: conv3x3 (C -> 1) + sigmoid + disp_to_depth, output NCHW fp32 [B,1,H,W]; and its
  * backward (d_depth -> dx NHWC [masked by x>0, the producer's ReLU], dw[9*C] += , db[1] +=).
- * scratch: B*H*W floats. */
+ * scratch: B*H*W floats; it receives the gradient w.r.t. the pre-activation.  dw = db = NULL skips the weight
+ * gradient, which colvo_depth_head_wgrad then computes from `scratch` (e.g. on another stream). */
 int colvo_depth_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int H, int W, int C,
                          float min_depth, float max_depth, float* depth, colvo_stream_t stream);
 int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* depth, const float* d_depth,
                          int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
                          void* dx, float* dw, float* db, colvo_stream_t stream);
+int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C,
+                           float* dw, float* db, colvo_stream_t stream);
 
 /* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.
  * out (8*B floats) is PLANAR: [ pose B x 6 | lcc_a B | lcc_b B ] so the three results are contiguous views;
@@ -171,6 +174,7 @@ enum {
     COLVO_CMD_UNPACK_NHWC_GRAD,  /* i: dtype B H W Cpad c_begin c_count accumulate; p: dsrc dst */
     COLVO_CMD_DEPTH_HEAD_FWD,    /* i: dtype B H W C; f: min max; p: x w bias depth */
     COLVO_CMD_DEPTH_HEAD_BWD,    /* i: dtype B H W C; f: min max; p: x w depth d_depth scratch dx dw db */
+    COLVO_CMD_DEPTH_HEAD_WGRAD,  /* i: dtype B H W C; p: x dpre dw db */
     COLVO_CMD_POSE_HEAD_FWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w bias out */
     COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db */
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
