@@ -46,6 +46,11 @@ CASES = [
     (2, 5, 5, 64, 0, False, False, 64, 2),        # PoseNet tail sizes
     (1, 32, 40, 16, 16, True, False, 16, 1),      # up + concat, narrow
     (2, 9, 7, 24, 0, False, False, 40, 1),        # channel counts that are only multiples of 8
+    (2, 16, 24, 8, 0, False, False, 8, 1),        # narrower than the smallest channel tile (rows beyond N read as zero)
+    (2, 8, 10, 256, 0, False, False, 64, 1),      # 8 chunks, <= 256 workgroups: the two-chunk register ring
+    (4, 256, 320, 16, 0, False, False, 16, 1),    # >= 2048 tiles, single chunk: weights-resident persistent kernel
+    (4, 256, 320, 32, 0, True, False, 16, 1),     # ... its dgrad with the 2x2 sum-pool of an up-sampled source
+    (8, 128, 160, 32, 0, False, False, 32, 1),    # ... 32-wide
 ]
 
 
