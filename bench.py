@@ -216,8 +216,7 @@ def main():
         if graphed is not None and not timed:
             return graphed()
         opt.zero_grad()
-        d = dn(frames)
-        d_t, d_r = d[:B], d[B:]
+        d_t, d_r = dn.forward_pair(frames)
         pose, a, b = pn(tgt, ref, d_t, d_r)
         loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
         loss.backward()

@@ -21,6 +21,9 @@
 // L1/L2 for smooth flows; loads are buffer loads (32-bit lane offset + scalar plane offset).
 #include <type_traits>
 
+#include <algorithm>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace colvo {
@@ -771,7 +774,8 @@ extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_fwd: image too large");
     hipStream_t s = (hipStream_t)stream;
     // marching-wave forward: one wave per (image, 32-row segment, 62-column strip)
-    const int seg_rows = pick_march_rows(B, H, W);
+    int seg_rows = pick_march_rows(B, H, W);
+    if (const char* e = getenv("COLVO_MARCH_ROWS_FWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
     const int strips_x = (W + MCOLS - 1) / MCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fwd: too many strips");
@@ -796,7 +800,8 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_bwd: image too large");
     hipStream_t s = (hipStream_t)stream;
     // marching-wave backward: one wave per (image, row segment, 60-column strip)
-    const int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
+    int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
+    if (const char* e = getenv("COLVO_MARCH_ROWS_BWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");

@@ -34,8 +34,7 @@ class GraphedTrainStep:
     def _step(self) -> torch.Tensor:
         B = self.B
         self.opt.zero_grad()
-        d = self.depth_net(self.frames)
-        d_t, d_r = d[:B], d[B:]
+        d_t, d_r = self.depth_net.forward_pair(self.frames)
         tgt, ref = self.frames[:B], self.frames[B:]
         pose, a, b = self.pose_net(tgt, ref, d_t, d_r)
         loss = photometric_loss(tgt, ref, d_t, pose, self.K, a, b, ssim_weight=self.ssim_weight)

@@ -332,6 +332,15 @@ class DepthNet(_ArenaModule):
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         return _DepthNetFn.apply(self, img, self._trigger())
 
+    def forward_pair(self, frames: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """frames [2B,3,H,W] = target frames then reference frames -> (depth_t, depth_r), each [B,1,H,W].
+        Same as `d = self(frames); d[:B], d[B:]`, but the two halves are outputs of ONE autograd node: the backward
+        gets their gradients directly instead of through two slice-backward nodes (zero-fill + copy + add each, ~8
+        small launches on the critical path between the PoseNet and the DepthNet backward)."""
+        if frames.dim() != 4 or frames.shape[0] % 2:
+            raise ValueError("forward_pair: expected [2B,3,H,W]")
+        return _DepthNetPairFn.apply(self, frames, self._trigger())
+
     # ---- whole-network forward / backward ---------------------------------------------------- #
     def _plan(self, B, H, W):
         dt = self.compute_dtype
@@ -455,6 +464,30 @@ class _DepthNetFn(torch.autograd.Function):
         return None, None, None
 
 
+class _DepthNetPairFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net: DepthNet, frames, trigger):
+        depth, saved = net._forward_impl(frames)
+        ctx.net, ctx.saved = net, saved
+        ctx.lease = _Lease(saved[2])
+        ctx.save_for_backward(depth)
+        B = frames.shape[0] // 2
+        return depth[:B], depth[B:]
+
+    @staticmethod
+    def backward(ctx, g_t, g_r):
+        (depth,) = ctx.saved_tensors
+        B = depth.shape[0] // 2
+        if g_t is None:
+            g_t = torch.zeros_like(depth[:B])
+        if g_r is None:
+            g_r = torch.zeros_like(depth[B:])
+        ctx.net._backward_impl(ctx.saved, depth, torch.cat([g_t, g_r], dim=0))
+        ctx.saved = None
+        ctx.lease.release()
+        return None, None, None
+
+
 class PoseNet(_ArenaModule):
     """forward(tgt, ref, tgt_depth=None, ref_depth=None) -> (pose [B,6], lcc_a [B,1], lcc_b [B,1])."""
 
@@ -571,8 +604,7 @@ def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_we
     """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss."""
     from .functional import photometric_loss
     B = tgt.shape[0]
-    d = depth_net(torch.cat([tgt, ref], dim=0))
-    d_t, d_r = d[:B], d[B:]
+    d_t, d_r = depth_net.forward_pair(torch.cat([tgt, ref], dim=0))
     pose, a, b = pose_net(tgt, ref, d_t, d_r)
     loss = photometric_loss(tgt, ref, d_t, pose, K, a, b, ssim_weight=ssim_weight)
     return loss, d_t, d_r, pose, a, b

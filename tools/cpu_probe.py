@@ -23,8 +23,7 @@ def main():
 
     def step():
         opt.zero_grad()
-        d = dn(frames)
-        d_t, d_r = d[:B], d[B:]
+        d_t, d_r = dn.forward_pair(frames)
         tgt, ref = frames[:B], frames[B:]
         pose, a, b = pn(tgt, ref, d_t, d_r)
         loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
