@@ -8,22 +8,25 @@
 // Layout: feature maps NHWC, channels a multiple of 8; T = float (exact-f32 MFMA 16x16x4, parity mode)
 // or bf16 (MFMA 16x16x32, throughput mode), fp32 accumulation in both.
 //
-// k_conv3x3 (forward AND input-gradient):  D[pixel][n] = sum_{tap,c} A[pixel@tap][c] * W[n][tap][c]
+// k_conv3x3 (forward AND input-gradient):  D[n][pixel] = sum_{tap,c} W[n][tap][c] * A[pixel@tap][c]
 //   - one 256-thread workgroup = a tile of <=128 output pixels (toh x tow region of one image) x BN
-//     output channels; wave w owns pixel rows 32w..32w+31 (2 MFMA row fragments) x all BN columns.
+//     output channels; wave w owns pixels 32w..32w+31 (2 MFMA fragments) x all BN channels.
 //   - K loop over channel chunks of CK = NG*16 bytes: the input PATCH of the tile (tile + halo, CK
 //     channels) is staged in LDS ONCE and re-read by all 9 taps (9x fewer global reads than a per-tap
 //     gather); the weight slab [BN][9][CK] is staged beside it.  Pixel pitch / weight-row pitch are
-//     padded by one 16-byte granule so the 16 lanes of a ds_read_b128 group fall on distinct banks.
+//     padded so the lane groups of a ds_read_b128 fall on distinct banks.
 //   - the gather that fills the patch folds in: zero padding, nearest 2x up-sampling (decoder "up"
 //     convs), channel concat of two sources (skip connections), and zero-insertion (the input gradient
 //     of a stride-2 conv is a stride-1 conv over the zero-dilated output gradient, flipped weights).
-//   - epilogue through LDS: bias, ReLU, 2x2 sum-pooling (input gradient of an up-sampled source),
-//     ReLU-mask of the producer, accumulate (skip fan-out), convert, 16-byte coalesced stores.
-//
-//   - measured (tools/scan_conv.py): t = 6 us + 1.5 us per 32-channel chunk even for ONE workgroup, unchanged by
-//     deeper prefetch, double-buffered LDS stages or 64-channel chunks: the chunk is bound by LDS throughput
-//     (~48 KB of ds_write + 4 waves x 54 ds_read_b128 per 72 MFMAs/wave); the next step is a 64x64 per-wave tile.
+//   - the MFMA operands are swapped (A = weights, B = pixels), so a lane's accumulator holds 4 consecutive
+//     channels of one pixel: the epilogue (bias, ReLU, producer's ReLU mask, accumulate for skip fan-out,
+//     convert) stores straight from the accumulators; only the 2x2 sum-pooling (input gradient of an
+//     up-sampled source) goes through an fp32 tile in LDS.
+//   - address set-up is kept to a few dozen instructions per thread (magic-number divisions, scalar strides,
+//     out-of-range offsets instead of tests): before that it was most of a workgroup's VALU time.
+//   - measured (tools/ablate_conv.sh, COLVO_TRACE): a workgroup's life is 0.5 us set-up + 1-1.8 us first stage
+//     + 1.3-1.5 us per 32-channel chunk + 1 us epilogue; with 2-3 workgroups per CU the chunk is bound by LDS
+//     bandwidth (a 32x32 per-wave tile reads 1 KB of LDS per MFMA).
 //
 // k_wgrad3x3:  dW[co][tap][c] += sum_pixels dY[pixel][co] * X[pixel@tap][c]   (K = pixels)
 //   - workgroup = (co tile of 16*MT) x (channel chunk CK of one source) x (a range of pixel tiles);
