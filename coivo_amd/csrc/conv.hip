@@ -354,8 +354,13 @@ struct Epi {
     }
 };
 
-template <typename T, int BN, int NG, int DEPTH>
-__global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x3(const ConvK a) {
+// TAIL: the patch may exceed PPF*256 granules (stride-2 tiles); compiled out otherwise -- its (never executed) loads made
+// hipcc wait for ALL outstanding loads, the just-issued prefetch included, in front of the MFMA phase.
+// NCH > 0: the chunk count is a compile-time constant and the K loop is fully unrolled -- in straight-line code hipcc counts
+// the outstanding loads exactly, so the register ring really keeps DEPTH chunks in flight (with a loop it drains to
+// vmcnt(0) at every other store phase).
+template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0>
+__global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void k_conv3x3(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G;
     constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
@@ -402,9 +407,11 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
     // under the matrix work instead of being paid once per 16-byte granule.
     constexpr int WTOT = BN * NGR;                         // real weight granules per chunk
     constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = 3;                                 // patch granules per thread that are prefetched
+    // patch granules per thread that are prefetched: 3 cover every stride-1 patch (<= 10 x 18 pixels x 4 granules); the
+    // stride-2 instantiations take 9 (17 x 33 x 4 = 2244 granules) so that nothing is left to the synchronous tail loop
+    constexpr int PPF = TAIL ? 9 : 3;
     const int ptotal = PH * PW * NG;
-    const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
+    const int nch0 = a.g.C[0] / CK, nch = NCH ? NCH : nch0 + a.g.C[1] / CK;
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];                  // DEPTH chunks in flight (register ring)
 
     // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread, and
@@ -466,11 +473,13 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
     }
 
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
-    auto load_w = [&](int k, u32x4 (&w)[WIT]) {
-        const int so = k * CK * ES;
+    // `dead` (wave-uniform, 0 or OOB_OFF) is OR-ed into every offset: the prefetch past the last chunk is issued all the
+    // same and reads zeros, so the K loop has no branch around its loads (a join there costs a vmcnt(0))
+    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
+        const int so = dead ? 0 : k * CK * ES;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)                  // branch-free, zero-filled
-            w[it] = bld16(rw, ((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB, so);
+            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
     };
 #ifdef COLVO_ABLATE
 #pragma unroll
@@ -489,16 +498,16 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
     auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
         return sidx == 0 ? bld16(rimg0, patch_off(0, i), c0 * ES) : bld16(rimg1, patch_off(1, i), c0 * ES);
     };
-    auto load_p = [&](int k, u32x4 (&pvv)[PPF]) {
+    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
         int sidx, c0;
-        chunk_src(k, sidx, c0);
+        chunk_src(dead ? 0 : k, sidx, c0);
         const int so = c0 * ES;
         if (sidx == 0) {
 #pragma unroll
-            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg0, poff0[it], so);
+            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg0, poff0[it] | dead, so);
         } else {
 #pragma unroll
-            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg1, poff1[it], so);
+            for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg1, poff1[it] | dead, so);
         }
     };
     auto store_p = [&](int k, const u32x4 (&pvv)[PPF]) {
@@ -508,16 +517,18 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
             if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
-        int sidx, c0;
-        chunk_src(k, sidx, c0);
-        for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
-            u32x4 t[3];
+        if constexpr (TAIL) {
+            int sidx, c0;
+            chunk_src(k, sidx, c0);
+            for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
+                u32x4 t[3];
 #pragma unroll
-            for (int u = 0; u < 3; ++u) t[u] = patch_granule(sidx, c0, base + u * NT + tid);
+                for (int u = 0; u < 3; ++u) t[u] = patch_granule(sidx, c0, base + u * NT + tid);
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = base + u * NT + tid;
-                if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, t[u]); }
+                for (int u = 0; u < 3; ++u) {
+                    const int i = base + u * NT + tid;
+                    if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, t[u]); }
+                }
             }
         }
     };
@@ -533,9 +544,13 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
     TRACE(1);
     if (!ABL(4)) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (d < nch) { load_w(d, wv[d]); load_p(d, pv[d]); }
+        for (int d = 0; d < DEPTH; ++d) {
+            const int dead = (d < nch) ? 0 : OOB_OFF;
+            load_w(d, dead, wv[d]);
+            load_p(d, dead, pv[d]);
+        }
     }
+#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
@@ -546,11 +561,18 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
         if (!ABL(16)) __syncthreads();
         if (k == 0) TRACE(2);
         if (k == 1) TRACE(3);
-        if (k + DEPTH < nch && !ABL(4)) { load_w(k + DEPTH, wv[d]); load_p(k + DEPTH, pv[d]); }    // in flight during the next DEPTH MFMA phases
-        // MFMA phase: the fragments of k-group m+1 are read from LDS BEFORE the MFMAs of k-group m are issued
-        // (two register sets), so the ~150-cycle LDS latency hides under the matrix pipe even at one wave per SIMD.
+        if (!ABL(4)) {                    // in flight during the next DEPTH MFMA phases
+            const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
+            load_w(k + DEPTH, dead, wv[d]);
+            load_p(k + DEPTH, dead, pv[d]);
+        }
+        // MFMA phase: the fragments of k-group m+FD are read from LDS BEFORE the MFMAs of k-group m are issued (FD+1
+        // register sets).  FD = 1 hides the LDS latency when other waves share the SIMD; the lone-workgroup variant
+        // (DEPTH 2: at most ~1 workgroup per CU, one wave per SIMD) needs FD = 2 -- a 32-wide k-group is only 64
+        // MFMA cycles, less than the LDS round trip.
         {
-            u32x4 av[2][2], bv[2][NF];
+            constexpr int FD = (DEPTH > 1) ? 2 : 1, NS = FD + 1;   // (measured: FD 2 alone changes nothing; kept with the ring)
+            u32x4 av[NS][2], bv[NS][NF];
             auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
                 const int gi = 4 * m + kg;
                 int tap = gi / NG;
@@ -564,16 +586,20 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1) ? 4 : 2) void k_conv3x
                 for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
             };
 #ifdef COLVO_ABLATE
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NS; ++q) {
                 for (int mf = 0; mf < 2; ++mf) av[q][mf] = u32x4{0u, 0u, 0u, 0u};
                 for (int nf = 0; nf < NF; ++nf) bv[q][nf] = u32x4{0u, 0u, 0u, 0u};
             }
 #endif
-            if (!ABL(2)) read_frags(0, av[0], bv[0]);
+            if (!ABL(2)) {
+#pragma unroll
+                for (int q = 0; q < FD; ++q)
+                    if (q < STEPS) read_frags(q, av[q], bv[q]);
+            }
 #pragma unroll
             for (int m = 0; m < STEPS; ++m) {
-                const int cur = m & 1;
-                if (m + 1 < STEPS && !ABL(2)) read_frags(m + 1, av[cur ^ 1], bv[cur ^ 1]);
+                const int cur = m % NS;
+                if (m + FD < STEPS && !ABL(2)) read_frags(m + FD, av[(m + FD) % NS], bv[(m + FD) % NS]);
 #ifdef COLVO_ABLATE
                 if (ABL(1)) {
                     for (int mf = 0; mf < 2; ++mf) asm volatile("" ::"v"(av[cur][mf]));
@@ -820,7 +846,8 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
 // --------------------------------------------------------------------------------------------- //
 // weight-gradient kernel                                                                         //
 // --------------------------------------------------------------------------------------------- //
-template <typename T, int MT, int NG>
+// TAIL: see k_conv3x3 (the stride-2 patch tail; its dead loads made hipcc drain the prefetch in front of the MFMA phase)
+template <typename T, int MT, int NG, bool TAIL>
 __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G;
@@ -961,6 +988,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
         const int base = c.b * Hs * Ws * Cs * ES;
+        if constexpr (TAIL)
         for (int g0 = PPF * NT; g0 < ptotal; g0 += 3 * NT) {
             u32x4 tt[3];
 #pragma unroll
@@ -1115,8 +1143,8 @@ Tile pick_tile(int Ho, int Wo, int stride, bool even) {
     return best;
 }
 
-template <typename T, int BN, int NG, int DEPTH = 1>
-int launch_conv(const ConvK& k, int B, hipStream_t s) {
+template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0>
+int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
     const int S = k.g.stride;
@@ -1127,7 +1155,7 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;   // per instantiation
     if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG, DEPTH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
@@ -1146,7 +1174,7 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
         hipMemsetAsync(tbuf, 0, nwg * 8 * sizeof(long long), s);
         ka.trace = tbuf;
     }
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH>), grid, dim3(NT), lds, s, ka);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>), grid, dim3(NT), lds, s, ka);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     if (tracing && (++tcount % atoi(getenv("COLVO_TRACE"))) == 0) {     // every n-th launch: print the phase statistics
         hipStreamSynchronize(s);
@@ -1170,9 +1198,22 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     }
     return 0;
 #endif
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH>), grid, dim3(NT), lds, s, k);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
+}
+
+template <typename T, int BN, int NG, int DEPTH = 1>
+int launch_conv(const ConvK& k, int B, hipStream_t s) {
+    const int S = k.g.stride;
+    const long ptotal = (long)((k.toh - 1) * S + 3) * ((k.tow - 1) * S + 3) * NG;
+    if (ptotal > 3 * NT) return launch_conv_tail<T, BN, NG, (DEPTH > 2 ? 2 : DEPTH), true>(k, B, s);   // depth 3 would spill
+    if constexpr (DEPTH >= 2) {
+        const int nch = (k.g.C[0] + k.g.C[1]) / (NG * TT<T>::G);
+        if (nch == 8) return launch_conv_tail<T, BN, NG, DEPTH, false, 8>(k, B, s);
+        if (nch == 16) return launch_conv_tail<T, BN, NG, DEPTH, false, 16>(k, B, s);
+    }
+    return launch_conv_tail<T, BN, NG, DEPTH, false>(k, B, s);
 }
 
 template <typename T, int BN, int NG>
@@ -1215,10 +1256,15 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
             // many-chunk layers at the lowest resolutions: two chunks in flight, because one MFMA phase (~0.5 us) is
             // shorter than the global-load latency it is supposed to hide
             if constexpr (BN == 32) {
-                // measured: pays only when the grid is at most one workgroup per CU (it costs occupancy: 176 VGPRs)
+                // measured: pays only when the grid is about one workgroup per CU (it costs occupancy: ~190 VGPRs)
                 static const int depth2_min = [] { const char* e = getenv("COLVO_DEPTH2_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
+                static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 512L; }();
                 const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
-                if (wgs <= 256 && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) return launch_conv<T, BN, 4, 2>(k, B, s);
+                if (wgs <= lone_max && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) {
+                    static const int lone_depth = [] { const char* e = getenv("COLVO_LONE_DEPTH"); return e ? atoi(e) : 2; }();
+                    if (lone_depth == 3) return launch_conv<T, BN, 4, 3>(k, B, s);
+                    return launch_conv<T, BN, 4, 2>(k, B, s);
+                }
             }
             return launch_conv<T, BN, 4>(k, B, s);
         case 2: return launch_conv<T, BN, 2>(k, B, s);
@@ -1238,13 +1284,14 @@ int launch_conv_t(const ConvK& k, int B, hipStream_t s) {
     // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
     const long tiles = (long)k.tiles_x * k.tiles_y * B;
     static const long bn64_min_wgs = [] { const char* e = getenv("COLVO_BN64_MIN_WGS"); return e ? atol(e) : 1024L; }();   // tuning knob
+    static const long bn32_min_wgs = [] { const char* e = getenv("COLVO_BN32_MIN_WGS"); return e ? atol(e) : 0L; }();      // tuning knob (16-wide tiles: measured ~neutral)
     if (k.N >= 64 && tiles * ((k.N + 63) / 64) >= bn64_min_wgs) return launch_conv_ng<T, 64>(k, B, ng, s);
-    if (k.N >= 32) return launch_conv_ng<T, 32>(k, B, ng, s);
+    if (k.N >= 32 && tiles * ((k.N + 31) / 32) >= bn32_min_wgs) return launch_conv_ng<T, 32>(k, B, ng, s);
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
 
-template <typename T, int MT, int NG>
-int launch_wgrad(WgradK k, hipStream_t s) {
+template <typename T, int MT, int NG, bool TAIL>
+int launch_wgrad_tail(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
     const int S = k.g.stride;
@@ -1253,7 +1300,7 @@ int launch_wgrad(WgradK k, hipStream_t s) {
     COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;
     if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<T, MT, NG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<T, MT, NG, TAIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
@@ -1276,9 +1323,17 @@ int launch_wgrad(WgradK k, hipStream_t s) {
     k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
     dim3 grid(nsplit, cot, chunks);
-    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG>), grid, dim3(NT), lds, s, k);
+    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3");
     return 0;
+}
+
+template <typename T, int MT, int NG>
+int launch_wgrad(const WgradK& k, hipStream_t s) {
+    const int S = k.g.stride;
+    const long ptotal = (long)((k.toh - 1) * S + 3) * ((k.tow - 1) * S + 3) * NG;
+    if (ptotal > 3 * NT) return launch_wgrad_tail<T, MT, NG, true>(k, s);
+    return launch_wgrad_tail<T, MT, NG, false>(k, s);
 }
 
 template <typename T, int MT>
