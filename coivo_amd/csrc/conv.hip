@@ -902,7 +902,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     // before the MFMAs of tile t and written to LDS after them
     constexpr int DGR = 16 * MT / G;                       // dY granules per pixel row
     constexpr int DIT = (BM * DGR + NT - 1) / NT;
-    constexpr int PPF = 3;
+    constexpr int PPF = TAIL ? 9 : 3;              // stride-2 patches: everything in the prefetch
     const int ptotal = PH * PW * NG;
     u32x4 dyv[DIT], pv[PPF];
 
@@ -1261,9 +1261,7 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
                 static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 512L; }();
                 const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
                 if (wgs <= lone_max && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) {
-                    static const int lone_depth = [] { const char* e = getenv("COLVO_LONE_DEPTH"); return e ? atoi(e) : 2; }();
-                    if (lone_depth == 3) return launch_conv<T, BN, 4, 3>(k, B, s);
-                    return launch_conv<T, BN, 4, 2>(k, B, s);
+                    return launch_conv<T, BN, 4, 2>(k, B, s);     // (a three-chunk ring measured no better)
                 }
             }
             return launch_conv<T, BN, 4>(k, B, s);
