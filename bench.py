@@ -93,6 +93,45 @@ def cpu_baseline(B, H, W, budget_s):
             "sample": f"oracle (pure-torch fp32) full train step, B={B} {W}x{H}, 1 warm-up + {len(times)} timed steps, median"}
 
 
+def depth_l1_vs_oracle(dev, cdt, B, H, W):
+    """BASELINE.json's second metric: mean |depth_hip - depth_oracle| on identical inputs and identical weights (the
+    bench's compute dtype; fp32 mode is pinned to 1e-4 by tests/test_nets_gpu.py)."""
+    from coivo_amd import nn as hnn
+    from coivo_amd import synth
+    from oracle import colvo_spec as S
+    dn_o, _ = S.make_models(0)
+    dn = hnn.DepthNet(compute_dtype=cdt, device=dev)
+    dn.load_state_dict(dn_o.state_dict())
+    b = synth.make_batch(B, H, W, seed=1234)
+    x = torch.cat([b["tgt"], b["ref"]])
+    with torch.no_grad():
+        do = dn_o(x)
+        dh = dn(x.to(dev)).cpu()
+    err = (dh - do).abs()
+    return {"mean_abs": err.mean().item(), "max_abs": err.max().item(), "mean_rel": (err.mean() / do.abs().mean()).item(),
+            "images": int(x.shape[0]), "weights": "spec init, seed 0", "dtype": "bf16" if cdt == torch.bfloat16 else "f32"}
+
+
+def conv_flops_per_step(B, H, W):
+    """Algorithmic conv flops of one training step: forward + input gradient + weight gradient."""
+    from coivo_amd import nn as hnn
+    f, h, w, cin = 0, H, W, 3
+    for c in hnn.ENC_CH:                               # DepthNet runs on 2B images
+        h, w = h // 2, w // 2
+        f += 2 * 9 * h * w * (cin * c + c * c); cin = c
+    for i in range(5, 0, -1):
+        d = hnn.DEC_CH[i - 1]; h, w = h * 2, w * 2
+        skip = hnn.ENC_CH[i - 2] if i >= 2 else 0
+        f += 2 * 9 * h * w * (cin * d + (d + skip) * d); cin = d
+    f += 2 * 9 * h * w * cin
+    f *= 2 * B
+    g, h, w, cin = 0, H, W, 8
+    for c in hnn.POSE_CH:
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        g += 2 * 9 * h * w * cin * c; cin = c
+    return 3 * (f + g * B)
+
+
 def pmc_traffic(workload):
     """HBM bytes per fwd+bwd launch pair from the committed PMC summary (profiles/rN_traffic.json), or None."""
     import glob
@@ -283,7 +322,14 @@ def main():
                "final_loss": final_loss, "hipgraph": use_graph, "roofline": roof}
         if not args.no_roofline_cfg2:
             out["roofline_cfg2"] = roofline_cfg2(dev)
+        fl = conv_flops_per_step(B, H, W)
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        out["mfma_step"] = {"what": "conv flops of the whole step (fwd + dgrad + wgrad, both networks) / step time: a lower "
+                                    "bound of the conv kernels' MFMA rate, the step also holds the loss, Adam and packing",
+                            "flops_per_step": fl, "achieved": fl / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                            "frac": fl / (ms * 1e-3) / 1e12 / peak}
         if not args.no_cpu_baseline and world == 1:
+            out["depth_l1_vs_oracle"] = depth_l1_vs_oracle(dev, cdt, B, H, W)
             out["cpu_baseline"] = cpu_baseline(B, H, W, args.cpu_seconds)
         elif world == 1:
             out["cpu_baseline"] = None
