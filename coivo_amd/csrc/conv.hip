@@ -127,6 +127,33 @@ struct WgradK {
 __device__ __forceinline__ int mdiv(int i, uint32_t m) { return (int)__umulhi((uint32_t)i, m); }
 inline uint32_t mdiv_magic(int d) { return (uint32_t)((0x100000000ULL + (uint32_t)d - 1) / (uint32_t)d); }
 
+// Between the last MFMA of a chain and the first VALU read of its accumulators.  hipcc's own wait states proved too few
+// for v_mfma_f32_16x16x4_f32 on gfx950: with `s_nop 8` + 4 instructions (13 wait states) the first register of the last
+// written accumulator came back stale in a few lanes, non-deterministically; with 16 it never did (found when a change
+// of register allocation moved that read 3 slots earlier).  The accumulators are operands of the asm statement so that
+// every MFMA is ordered before it and every read (including AGPR -> VGPR copies) after it.  Applied to the bf16 MFMAs as
+// well: measured perf-neutral, and their wait states come from the same (gfx950-new) tables.
+template <int N>
+__device__ __forceinline__ void mfma_result_guard(f32x4 (&acc)[N]) {
+#define G_(i) "+v"(acc[i])
+    if constexpr (N == 1) asm volatile("s_nop 15" : G_(0));
+    else if constexpr (N == 2) asm volatile("s_nop 15" : G_(0), G_(1));
+    else if constexpr (N == 3) asm volatile("s_nop 15" : G_(0), G_(1), G_(2));
+    else if constexpr (N == 4) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3));
+    else if constexpr (N == 6) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5));
+    else if constexpr (N == 8) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7));
+    else if constexpr (N == 5) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4));
+    else if constexpr (N == 10)
+        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9));
+    else if constexpr (N == 12)
+        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9), G_(10), G_(11));
+    else if constexpr (N == 20)
+        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9), G_(10), G_(11), G_(12),
+                     G_(13), G_(14), G_(15), G_(16), G_(17), G_(18), G_(19));
+    else static_assert(N == 1, "mfma_result_guard: add a case for this accumulator count");
+#undef G_
+}
+
 __device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 // 16-byte buffer load: 32-bit per-lane byte offset + scalar byte offset; an offset beyond the descriptor's size
 // returns zeros (hardware bounds check), so padding / out-of-image granules need no branch: they get OOB_OFF.
@@ -630,6 +657,7 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
       }
     }
 
+    mfma_result_guard(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
 #ifdef COLVO_ABLATE
     if (ABL(32)) {
         for (int mf = 0; mf < 2; ++mf)
@@ -827,6 +855,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
                                 __uint_as_float(bv[nf][j]), __uint_as_float(av[mf][j]), acc[mf][nf], 0, 0, 0);
             }
         }
+        mfma_result_guard(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
         if (!a.pool2) {
             ep.finish(a, acc, biasv, rout, cur.b * img_out);
         } else {
@@ -1093,6 +1122,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         }
     }
 
+    mfma_result_guard(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
     // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
