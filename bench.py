@@ -174,8 +174,8 @@ def roofline_cfg2(dev):
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic("B=32 640x512 (configs[2])"),
             "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
-            "timing": "hip events on the launch stream directly around each C-ABI call (main kernel + its 1-block finalize "
-                      "kernel), median of 20 launches"}
+            "timing": "hip events on the launch stream directly around each C-ABI call (forward = one-pass loss + unnormalised "
+                      "gradients + finalize, backward = scaling kernel), median of 20 launches"}
 
 
 def main():
@@ -308,7 +308,7 @@ def main():
                 "traffic": pmc_traffic("B=8 320x256 (configs[1])"), "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
                 "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3,
                 "timing": "hip events on the launch stream directly around the fused op's C-ABI calls inside the timed "
-                          "steps (main kernel + 1-block finalize), mean over steps; latency-dominated at this size "
+                          "steps (forward call = one-pass loss + unnormalised gradients + finalize, backward call = scaling kernel), mean over steps; latency-dominated at this size "
                           "(SURVEY.md §8d) -- the roofline is read at configs[2], see roofline_cfg2"}
         out = {"metric": "training frame-pairs/sec at 320x256", "value": value, "unit": "frame-pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,

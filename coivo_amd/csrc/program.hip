@@ -20,7 +20,7 @@ unsigned g_ev_next = 0;
 
 hipEvent_t next_event() {
     if (!g_ev_init) {
-        for (int i = 0; i < NEV; ++i) hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming);
+        for (int i = 0; i < NEV; ++i) (void)hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming);
         g_ev_init = true;
     }
     return g_ev[g_ev_next++ % NEV];

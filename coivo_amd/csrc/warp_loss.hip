@@ -424,6 +424,7 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd_finalize(const float* __re
 }
 
 constexpr int NPART = 14;                   // dt[3], dR[9], da, db
+constexpr int NPART_F = 16;                 // fused pass: + loss sum, valid-pixel count
 
 // --------------------------------------------------------------------------------------------- //
 // backward: "marching wave"                                                                      //
@@ -448,12 +449,15 @@ struct BwdState {
     float H[3][15];
     float HK[3][9];
     float part[NPART];
+    float lacc, lcnt;                       // fused pass only: loss sum and valid count of the pixels this wave owns
 };
 
-template <int K>
+// FUSED: the same pass also accumulates the loss itself (alpha, 1 - alpha in al / l1w), for the one-kernel
+// loss + unnormalised-gradient forward of the training path (colvo_warp_loss_fused).
+template <int K, bool FUSED>
 __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& im, int j, int nrows, int y_first,
                                          int gxcol, int px, bool own_col, float Xh, const float (&wxw)[3], int H,
-                                         int W, float kss, float kl1, float* __restrict__ d_depth_img) {
+                                         int W, float kss, float kl1, float* __restrict__ d_depth_img, float al, float l1w) {
     constexpr int K1 = (K + 1) % 3, K2 = (K + 2) % 3;
     if (j >= nrows) return;                              // wave-uniform
     // (1) consume the taps of row j: warp, its spatial derivatives, LCC
@@ -516,6 +520,7 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
         const int gyw = y_first + j - 1;
         const bool wexists = (gyw >= 0) && (gyw < H) && (gxcol >= 0) && (gxcol < W) && (j >= 2);
         const float wmask = wexists ? st.m[K2] : 0.0f;   // row j-1 = slot (j+2) % 3
+        float lrow = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const SsimTerms s = ssim_terms(st.H[K1][5 * c + 0] + st.H[K2][5 * c + 0] + st.H[K][5 * c + 0],
@@ -533,6 +538,14 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             st.HK[K2][3 * c + 0] = fmaf(wxw[0], dpp_from_left(A), fmaf(wxw[2], dpp_from_right(A), wxw[1] * A));
             st.HK[K2][3 * c + 1] = fmaf(wxw[0], dpp_from_left(Bc), fmaf(wxw[2], dpp_from_right(Bc), wxw[1] * Bc));
             st.HK[K2][3 * c + 2] = fmaf(wxw[0], dpp_from_left(Cc), fmaf(wxw[2], dpp_from_right(Cc), wxw[1] * Cc));
+            if constexpr (FUSED)
+                lrow += al * fminf(fmaxf(ss, 0.0f), 1.0f) + l1w * fabsf(st.Tk[K2][c] - fmaf(g.a, st.Wp[K2][c], g.b));
+        }
+        if constexpr (FUSED) {                           // row j-1 is an output row of this wave for row indices 2 .. nrows-3
+            const bool own1 = own_col && (j - 1 >= 2) && (j - 1 <= nrows - 3) && (gyw < H);
+            const float mo = own1 ? wmask : 0.0f;
+            st.lacc = fmaf(lrow, mo, st.lacc);
+            st.lcnt += mo;
         }
     }
     // (5) pixel row j-2 (slot K1): vertical gather of the coefficient rows j-3, j-2, j-1 -> dJ, then the chain rule.
@@ -586,6 +599,7 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
     }
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
@@ -605,7 +619,8 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     __syncthreads();
     const Geo g = geo_load(s_geo[wave]);
     const Img im = img_make(tgt, ref, depth, b, H, W);
-    const float gscale = grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
+    // fused pass: unnormalised gradients (scaled by dL/dloss / max(3 n_valid, 1) once that is known)
+    const float gscale = FUSED ? 1.0f : grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
     const float kss = gscale * alpha * (-0.5f);
     const float kl1 = gscale * (1.0f - alpha);
 
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     }
 
     BwdState st;
+    st.lacc = 0.0f; st.lcnt = 0.0f;
 #pragma unroll
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
 #pragma unroll
@@ -666,14 +682,96 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     float* ddimg = d_depth + (size_t)b * H * W;
 #pragma unroll 1
     for (int j = 0; j < nrows; j += 3) {
-        bwd_step<0>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
-        bwd_step<1>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
-        bwd_step<2>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg);
+        bwd_step<0, FUSED>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+        bwd_step<1, FUSED>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+        bwd_step<2, FUSED>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
     }
+    constexpr int NP = FUSED ? NPART_F : NPART;
 #pragma unroll
     for (int k = 0; k < NPART; ++k) {
         const float v = wave_sum(live ? st.part[k] : 0.0f);
-        if (lane == 0 && live) partials[(size_t)item * NPART + k] = v;
+        if (lane == 0 && live) partials[(size_t)item * NP + k] = v;
+    }
+    if constexpr (FUSED) {
+        const float la = wave_sum(live ? st.lacc : 0.0f), lc = wave_sum(live ? st.lcnt : 0.0f);
+        if (lane == 0 && live) { partials[(size_t)item * NP + 14] = la; partials[(size_t)item * NP + 15] = lc; }
+    }
+}
+
+// fused forward, second kernel: blocks 0..B-1 fold the 14 gradient sums of one image (still unnormalised) into
+// gpart[b][14]; block B folds the loss sum and the valid count of ALL strips into loss_state.  Fixed orders: deterministic.
+__global__ __launch_bounds__(NT) void k_warp_loss_fused_finalize(const float* __restrict__ partials, int blocks_per_image,
+                                                                 int B, float* __restrict__ gpart,
+                                                                 float* __restrict__ loss_state) {
+    __shared__ float s0[NT], s1[NT];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == B) {
+        const int n = B * blocks_per_image;
+        float a = 0.0f, c = 0.0f;
+        for (int i = tid; i < n; i += NT) { a += partials[(size_t)i * NPART_F + 14]; c += partials[(size_t)i * NPART_F + 15]; }
+        s0[tid] = a; s1[tid] = c;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if (tid < o) { s0[tid] += s0[tid + o]; s1[tid] += s1[tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const float denom = fmaxf(3.0f * s1[0], 1.0f);
+            loss_state[0] = s0[0] / denom;
+            loss_state[1] = 1.0f / denom;
+            loss_state[2] = s1[0];
+            loss_state[3] = 0.0f;
+        }
+        return;
+    }
+    const int b = blockIdx.x;
+    constexpr int ROWS = NT / NPART;  // 18 partial rows per pass
+    const int k = tid % NPART, r = tid / NPART;
+    float acc = 0.0f;
+    if (r < ROWS)
+        for (int i = r; i < blocks_per_image; i += ROWS) acc += partials[((size_t)b * blocks_per_image + i) * NPART_F + k];
+    float* s = s0;                     // [NPART][ROWS] packed
+    if (r < ROWS) s[k * ROWS + r] = acc;
+    __syncthreads();
+    if (tid < NPART) {
+        float t = 0.0f;
+        for (int i = 0; i < ROWS; ++i) t += s[tid * ROWS + i];
+        gpart[b * NPART + tid] = t;
+    }
+}
+
+// fused backward: scale = dL/dloss / max(3 n_valid, 1).  Blocks 0..B-1: pose / LCC gradients of one image from gpart;
+// all blocks: d_depth = scale * d_depth_raw (grid-stride).
+__global__ __launch_bounds__(NT) void k_warp_loss_fused_bwd(const float* __restrict__ loss_state,
+                                                            const float* __restrict__ grad_loss,
+                                                            const float* __restrict__ d_depth_raw,
+                                                            const float* __restrict__ gpart, const float* __restrict__ pose,
+                                                            int B, size_t n, float* __restrict__ d_depth,
+                                                            float* __restrict__ d_pose, float* __restrict__ d_a,
+                                                            float* __restrict__ d_b) {
+    const float scale = grad_loss[0] * loss_state[1];
+    const size_t stride = (size_t)gridDim.x * NT;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) d_depth[i] = scale * d_depth_raw[i];
+    if ((int)blockIdx.x < B && threadIdx.x == 0) {
+        const int b = blockIdx.x;
+        float tot[NPART];
+#pragma unroll
+        for (int k = 0; k < NPART; ++k) tot[k] = scale * gpart[b * NPART + k];
+        const float* p = pose + 6 * b;
+        const float sx = sinf(p[3]), cx = cosf(p[3]), sy = sinf(p[4]), cy = cosf(p[4]), sz = sinf(p[5]), cz = cosf(p[5]);
+        const float* dR = tot + 3;  // row-major 3x3
+        const float drx = dR[1] * (cz * sy * cx + sz * sx) + dR[2] * (-cz * sy * sx + sz * cx)
+                        + dR[4] * (sz * sy * cx - cz * sx) + dR[5] * (-sz * sy * sx - cz * cx)
+                        + dR[7] * (cy * cx) + dR[8] * (-cy * sx);
+        const float dry = dR[0] * (-cz * sy) + dR[1] * (cz * cy * sx) + dR[2] * (cz * cy * cx)
+                        + dR[3] * (-sz * sy) + dR[4] * (sz * cy * sx) + dR[5] * (sz * cy * cx)
+                        + dR[6] * (-cy) + dR[7] * (-sy * sx) + dR[8] * (-sy * cx);
+        const float drz = dR[0] * (-sz * cy) + dR[1] * (-sz * sy * sx - cz * cx) + dR[2] * (-sz * sy * cx + cz * sx)
+                        + dR[3] * (cz * cy) + dR[4] * (cz * sy * sx - sz * cx) + dR[5] * (cz * sy * cx + sz * sx);
+        d_pose[6 * b + 0] = tot[0]; d_pose[6 * b + 1] = tot[1]; d_pose[6 * b + 2] = tot[2];
+        d_pose[6 * b + 3] = drx; d_pose[6 * b + 4] = dry; d_pose[6 * b + 5] = drz;
+        d_a[b] = tot[12];
+        d_b[b] = tot[13];
     }
 }
 
@@ -760,7 +858,7 @@ using namespace colvo;
 
 extern "C" size_t colvo_warp_loss_workspace_floats(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const size_t bwd = (size_t)B * ((W + BCOLS - 1) / BCOLS) * ((H + 3) / 4) * NPART;   // 14 per strip segment (>= 4 rows)
+    const size_t bwd = (size_t)B * ((W + BCOLS - 1) / BCOLS) * ((H + 3) / 4) * NPART_F; // <= 16 per strip segment (>= 4 rows)
     const size_t fwd = (size_t)B * ((W + MCOLS - 1) / MCOLS) * ((H + 3) / 4) * 2;   // 2 per strip segment (>= 4 rows each)
     return bwd > fwd ? bwd : fwd;
 }
@@ -805,12 +903,53 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");
-    hipLaunchKernelGGL(k_warp_loss_bwd_march, dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
+    hipLaunchKernelGGL((k_warp_loss_bwd_march<false>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
                        lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, loss_state, grad_loss, d_depth, workspace);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march");
     hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, nseg * strips_x, pose,
                        d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_finalize");
+    return 0;
+}
+
+// Training path: loss AND its (unnormalised) gradients in ONE pass over the images -- the backward kernel evaluates
+// everything the forward does, so running both costs a second read of every input and ~1/3 more instructions.
+extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const float* depth, const float* pose,
+                                     const float* K, const float* lcc_a, const float* lcc_b, int B, int H, int W,
+                                     float ssim_weight, float* workspace, float* loss_state, float* d_depth_raw,
+                                     float* grad_partials, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(tgt && ref && depth && pose && K && lcc_a && lcc_b && workspace && loss_state && d_depth_raw && grad_partials,
+                    "colvo_warp_loss_fused: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65534, "colvo_warp_loss_fused: bad shape B=%d H=%d W=%d", B, H, W);
+    COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_fused: image too large");
+    hipStream_t s = (hipStream_t)stream;
+    int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
+    if (const char* e = getenv("COLVO_MARCH_ROWS_BWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
+    const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
+    const long long nitems = (long long)B * nseg * strips_x;
+    COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fused: too many strips");
+    hipLaunchKernelGGL((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose,
+                       K, lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, (const float*)nullptr,
+                       (const float*)nullptr, d_depth_raw, workspace);
+    COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<fused>");
+    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(NT), 0, s, workspace, nseg * strips_x, B, grad_partials,
+                       loss_state);
+    COLVO_CHECK_LAUNCH("k_warp_loss_fused_finalize");
+    return 0;
+}
+
+extern "C" int colvo_warp_loss_fused_bwd(const float* loss_state, const float* grad_loss, const float* d_depth_raw,
+                                         const float* grad_partials, const float* pose, int B, int H, int W,
+                                         float* d_depth, float* d_pose, float* d_a, float* d_b, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(loss_state && grad_loss && d_depth_raw && grad_partials && pose && d_depth && d_pose && d_a && d_b,
+                    "colvo_warp_loss_fused_bwd: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65534, "colvo_warp_loss_fused_bwd: bad shape");
+    const size_t n = (size_t)B * H * W;
+    unsigned blocks = (unsigned)std::min<size_t>((n + NT * 4 - 1) / (NT * 4), 4096);
+    if (blocks < (unsigned)B) blocks = (unsigned)B;
+    hipLaunchKernelGGL(k_warp_loss_fused_bwd, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, loss_state, grad_loss, d_depth_raw,
+                       grad_partials, pose, B, n, d_depth, d_pose, d_a, d_b);
+    COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd");
     return 0;
 }
 

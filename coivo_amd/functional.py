@@ -11,7 +11,13 @@ import torch
 
 from . import _lib
 
+import os
+
 SSIM_WEIGHT = 0.85
+# Training calls (any of depth / pose / lcc_a / lcc_b requires grad) compute the loss AND its unnormalised gradients in
+# one pass (colvo_warp_loss_fused); backward then only applies dL/dloss / max(3 n_valid, 1).  COLVO_LOSS_UNFUSED=1 keeps
+# the two-pass form (forward kernel, then a backward kernel that re-evaluates the warp).
+FUSE_TRAINING_PASS = os.environ.get("COLVO_LOSS_UNFUSED") is None
 
 # Optional kernel timing for bench.py: when enabled, every fused-op call is bracketed by HIP events recorded on
 # the stream the kernels are launched on (PyTorch's current stream), immediately around the C-ABI call.
@@ -66,19 +72,41 @@ class _WarpLoss(torch.autograd.Function):
         nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
         ws = torch.empty(nws, device=tgt.device, dtype=torch.float32)
         state = torch.empty(4, device=tgt.device, dtype=torch.float32)
+        ctx.ssim_weight = float(ssim_weight)
+        ctx.fused = FUSE_TRAINING_PASS and any(ctx.needs_input_grad[2:7])
+        if ctx.fused:
+            d_raw = torch.empty_like(depth)
+            gpart = torch.empty(B * 14, device=tgt.device, dtype=torch.float32)
+            _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fused(
+                _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
+                B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw), _lib.ptr(gpart),
+                _lib.stream_ptr())), "colvo_warp_loss_fused")
+            ctx.save_for_backward(pose, state, d_raw, gpart)
+            ctx.shape = (B, H, W)
+            return state[0].clone()
         _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fwd(
             _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
             B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr())), "colvo_warp_loss_fwd")
         ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
-        ctx.ssim_weight = float(ssim_weight)
         return state[0].clone()
 
     @staticmethod
     def backward(ctx, grad_loss):
         lib = _lib.load()
+        g = grad_loss.to(torch.float32).contiguous().reshape(1)
+        if ctx.fused:
+            pose, state, d_raw, gpart = ctx.saved_tensors
+            B, H, W = ctx.shape
+            d_depth = torch.empty_like(d_raw)
+            d_pose = torch.empty_like(pose)
+            d_a = torch.empty(B, 1, device=pose.device, dtype=torch.float32)
+            d_b = torch.empty(B, 1, device=pose.device, dtype=torch.float32)
+            _lib.check(_timed("bwd", lambda: lib.colvo_warp_loss_fused_bwd(
+                _lib.ptr(state), _lib.ptr(g), _lib.ptr(d_raw), _lib.ptr(gpart), _lib.ptr(pose), B, H, W, _lib.ptr(d_depth),
+                _lib.ptr(d_pose), _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr())), "colvo_warp_loss_fused_bwd")
+            return None, None, d_depth, d_pose, None, d_a, d_b, None
         tgt, ref, depth, pose, K, lcc_a, lcc_b, state = ctx.saved_tensors
         B, _, H, W = tgt.shape
-        g = grad_loss.to(torch.float32).contiguous().reshape(1)
         nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
         ws = torch.empty(nws, device=tgt.device, dtype=torch.float32)
         d_depth = torch.empty_like(depth)

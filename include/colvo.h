@@ -63,6 +63,18 @@ int colvo_warp_loss_bwd(const float* tgt, const float* ref, const float* depth, 
                         float* workspace, float* d_depth, float* d_pose, float* d_a, float* d_b,
                         colvo_stream_t stream);
 
+/* Training path: the loss and its UNNORMALISED gradients in one pass (the backward kernel evaluates everything the
+ * forward does).  loss_state as in colvo_warp_loss_fwd; d_depth_raw [B,1,H,W] and grad_partials [B*14] are handed to
+ * colvo_warp_loss_fused_bwd, which applies dL/dloss / max(3 n_valid, 1) and writes the four gradients. */
+int colvo_warp_loss_fused(const float* tgt, const float* ref, const float* depth, const float* pose,
+                          const float* K, const float* lcc_a, const float* lcc_b,
+                          int B, int H, int W, float ssim_weight,
+                          float* workspace, float* loss_state, float* d_depth_raw, float* grad_partials,
+                          colvo_stream_t stream);
+int colvo_warp_loss_fused_bwd(const float* loss_state, const float* grad_loss, const float* d_depth_raw,
+                              const float* grad_partials, const float* pose, int B, int H, int W,
+                              float* d_depth, float* d_pose, float* d_a, float* d_b, colvo_stream_t stream);
+
 /* Un-fused debugging entry (spec: inverse_warp()).  ref [B,C,H,W] -> warped [B,C,H,W], valid [B,1,H,W]. */
 int colvo_inverse_warp(const float* ref, const float* depth, const float* pose, const float* K,
                        int B, int C, int H, int W, float* warped, float* valid, colvo_stream_t stream);

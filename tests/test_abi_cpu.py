@@ -41,8 +41,8 @@ def test_abi_version_and_error_string(lib):
 
 def test_workspace_size_formula(lib):
     # max(backward: 14 partial sums per 60-column strip segment, forward: 2 per 62-column strip segment; >= 4 rows each)
-    assert lib.colvo_warp_loss_workspace_floats(8, 256, 320) == max(8 * 6 * 64 * 14, 8 * 6 * 64 * 2)
-    assert lib.colvo_warp_loss_workspace_floats(2, 33, 47) == max(2 * 1 * 9 * 14, 2 * 1 * 9 * 2)
+    assert lib.colvo_warp_loss_workspace_floats(8, 256, 320) == max(8 * 6 * 64 * 16, 8 * 6 * 64 * 2)   # 16 = 14 gradient sums + loss + count (fused pass)
+    assert lib.colvo_warp_loss_workspace_floats(2, 33, 47) == max(2 * 1 * 9 * 16, 2 * 1 * 9 * 2)
     assert lib.colvo_warp_loss_workspace_floats(0, 10, 10) == 0
 
 

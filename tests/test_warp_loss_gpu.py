@@ -49,6 +49,41 @@ def test_golden_fixture(golden_dir, name):
     _compare(hl, hg, g["loss"], (g["d_depth"], g["d_pose"], g["d_a"], g["d_b"]), name)
 
 
+@pytest.mark.parametrize("name", ["loss_b2_64x96", "loss_b2_33x47_ragged"])
+def test_golden_fixture_two_pass(golden_dir, name, monkeypatch):
+    """The un-fused form (forward kernel, then the backward kernel that re-evaluates the warp) stays covered."""
+    from coivo_amd import functional as Fh
+    monkeypatch.setattr(Fh, "FUSE_TRAINING_PASS", False)
+    g = load_npz(os.path.join(golden_dir, name + ".npz"))
+    t = to_dev(g, ("tgt", "ref", "K", "depth", "pose", "lcc_a", "lcc_b"))
+    hl, hg = _hip_loss_and_grads(t)
+    _compare(hl, hg, g["loss"], (g["d_depth"], g["d_pose"], g["d_a"], g["d_b"]), name + " two-pass")
+
+
+def test_fused_pass_equals_two_pass_and_scales_with_grad_loss(monkeypatch):
+    """One-pass loss+gradient == forward then backward (same partial-sum orders are not guaranteed: tolerance), and the
+    incoming dL/dloss is applied (2.5 x loss -> 2.5 x gradients)."""
+    from coivo_amd import functional as Fh
+    t = to_dev(_case(2, 96, 128, 120, 1.0))
+
+    def run(scale):
+        leaves = [t[k].clone().requires_grad_(True) for k in ("depth", "pose", "lcc_a", "lcc_b")]
+        loss = Fh.photometric_loss(t["tgt"], t["ref"], leaves[0], leaves[1], t["K"], leaves[2], leaves[3])
+        return loss.detach(), torch.autograd.grad(loss * scale, leaves)
+
+    lf, gf = run(1.0)
+    _, gf25 = run(2.5)
+    monkeypatch.setattr(Fh, "FUSE_TRAINING_PASS", False)
+    lu, gu = run(1.0)
+    assert abs(lf.item() - lu.item()) < 1e-6
+    for a, b, c, nm in zip(gf, gu, gf25, ("d_depth", "d_pose", "d_a", "d_b")):
+        # the reduced gradients are cancelling sums: scaling every term (two-pass) or the total (one-pass) moves them by
+        # ~1e-4 of their own size, far inside the 3e-3 bar against the oracle
+        rt, at = (1e-4, 1e-5) if nm == "d_depth" else (1e-3, 1e-3)
+        assert_close_frac(a, b, rtol=rt, atol_scale=at, max_bad_frac=0, what="fused vs two-pass " + nm)
+        assert_close_frac(c, 2.5 * a, rtol=1e-5, atol_scale=1e-6, max_bad_frac=0, what="grad_loss scaling " + nm)
+
+
 def _case(B, H, W, seed, pose_scale=1.0):
     b = synth.make_batch(B, H, W, seed=seed)
     g = torch.Generator().manual_seed(seed + 1)

@@ -64,12 +64,13 @@ for kern in sorted({n for (n, c, g) in fs if "k_warp_loss" in n and "finalize" n
     for g, (px, shape) in zip(grids, shapes):
         v = fs[(kern, "FETCH_SIZE", g)]
         wv = ws.get((kern, "WRITE_SIZE", g), 0.0)
-        bwd = "bwd" in kern
-        alg = (32 if bwd else 28) * px
+        # SURVEY.md §8d bytes: forward 28 B/px, backward (recompute) 32 B/px; the one-pass training kernel does both
+        # jobs (60 B/px by that definition while really reading each input once); its scaling kernel has none
+        alg = (60 if "bwd_march<true>" in kern else 0 if "fused_bwd" in kern else 32 if "bwd" in kern else 28) * px
         out["kernels"].append({"kernel": kern, "workload": shape, "hbm_read_bytes": v * 1024 * cal_f,
                                "hbm_write_bytes": wv * 1024 * cal_w, "hbm_bytes": v * 1024 * cal_f + wv * 1024 * cal_w,
                                "algorithmic_bytes": alg,
-                               "traffic_over_algorithmic": (v * 1024 * cal_f + wv * 1024 * cal_w) / alg,
+                               "traffic_over_algorithmic": ((v * 1024 * cal_f + wv * 1024 * cal_w) / alg) if alg else None,
                                "avg_duration_us_under_pmc": dur.get((kern, g))})
 json.dump(out, open(f"profiles/{R}_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:2500])
