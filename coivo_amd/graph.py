@@ -1,10 +1,13 @@
 """hipGraph-captured DCDP training step (BASELINE configs[4]: "hipGraph-captured train step").
 
-At B=8 the step is ~170 kernel launches of 5-50 us each; the Python / launch path (~2.5 ms) is then longer than
-the GPU work.  Every entry point of libcolvo only enqueues on the given stream (no allocation, no sync, step counter
-and loss state on the device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused loss, backward with
-its weight-gradient side stream (fork/join by events), optional RCCL buckets, fused Adam -- is captured once into a
-hipGraph (torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch.
+Every entry point of libcolvo only enqueues on the given stream (no allocation, no sync, step counter and loss state on
+the device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused loss, backward with its weight-gradient
+side stream (fork/join by events), optional RCCL buckets, fused Adam -- can be captured once into a hipGraph
+(torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch: no host cost at all.
+
+Measured on MI355X (ROCm 7.2) the replay runs the two-stream backward SERIALLY (2.12 ms per step = the no-overlap time),
+while the recorded command lists of coivo_amd/program.py keep the overlap at ~1 ms of host time per step (1.85 ms), so
+bench.py uses those by default and this class is the option for hosts that are otherwise busy.
 
 Inputs live in static device buffers (`frames` = [2B,3,H,W]: target frames then reference frames, `K`); the caller
 writes the next batch into them (or passes tensors to __call__, which copies) and replays.
