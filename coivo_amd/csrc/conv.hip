@@ -1336,10 +1336,11 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     const int chunks = (k.g.C[0] + k.g.C[1]) / CK;
     const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
     // Pixel-range splits: every split adds one fp32 atomic per weight (chip-wide ~1.3 TB/s of atomics), so cap
-    // the atomic traffic at ~12 MB per launch, but keep at least ~256 workgroups in flight and at most ~1024.
+    // the atomic traffic at ~3 MB per launch (re-tuned for the 32-wide co tile: 12 MB 592 us, 6 MB 575, 3 MB 566),
+    // but keep at least ~256 workgroups in flight and at most ~1024.
     const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
     const int per_split = chunks * cot;
-    static const double atomic_budget = [] { const char* e = getenv("COLVO_WGRAD_ATOMIC_MB"); return (e ? atof(e) : 12.0) * 1e6; }();
+    static const double atomic_budget = [] { const char* e = getenv("COLVO_WGRAD_ATOMIC_MB"); return (e ? atof(e) : 3.0) * 1e6; }();
     static const int wg_lo = [] { const char* e = getenv("COLVO_WGRAD_WG_LO"); return e ? atoi(e) : 256; }();
     static const int wg_hi = [] { const char* e = getenv("COLVO_WGRAD_WG_HI"); return e ? atoi(e) : 1024; }();
     int nsplit = (int)(atomic_budget / wbytes);
@@ -1381,8 +1382,11 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
         if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
     for (int i = 0; i < 2; ++i)
         COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "wgrad: channel count %d is not a multiple of %d", k.g.C[i], G);
-    if (k.Cout >= 64) return launch_wgrad_ng<T, 4>(k, ng, s);
-    if (k.Cout >= 32) return launch_wgrad_ng<T, 2>(k, ng, s);
+    // co tile: 32 wide (MT = 2) measured better than 64 on every layer -- twice the (co, chunk) combinations, so half the
+    // pixel-range splits and half the fp32 atomic traffic for the same number of workgroups (wgrad 638 -> 589 us)
+    static const int mt_max = [] { const char* e = getenv("COLVO_WGRAD_MT_MAX"); return e ? atoi(e) : 2; }();   // tuning knob
+    if (k.Cout >= 64 && mt_max >= 4) return launch_wgrad_ng<T, 4>(k, ng, s);
+    if (k.Cout >= 32 && mt_max >= 2) return launch_wgrad_ng<T, 2>(k, ng, s);
     return launch_wgrad_ng<T, 1>(k, ng, s);
 }
 
