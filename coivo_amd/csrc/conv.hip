@@ -1254,7 +1254,8 @@ int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     const size_t p_or_out = std::max((size_t)PH * PW * PIXP, (size_t)BM * (BN + 4) * 4);
     const size_t lds = (size_t)BN * WROW + p_or_out;
     const int ntiles = k.tiles_x * k.tiles_y * B;
-    int gx = 256 * 4;                           // ~4 workgroups per CU, each walking ntiles / gx tiles
+    static const int res_wg_per_cu = [] { const char* e = getenv("COLVO_RES_WG_PER_CU"); return e ? atoi(e) : 4; }();   // tuning knob
+    int gx = 256 * res_wg_per_cu;               // workgroups per CU, each walking ntiles / gx tiles
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
     hipLaunchKernelGGL((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
@@ -1271,9 +1272,10 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
         const long long src_bytes = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * TT<T>::ES;
         const long long out_bytes = (long long)B * k.Ho * k.Wo * k.N * TT<T>::ES / (k.pool2 ? 4 : 1);
         const long long tpi = (long long)k.tiles_x * k.tiles_y;
+        static const long res_min_tiles = [] { const char* e = getenv("COLVO_RES_MIN_TILES"); return e ? atol(e) : 2048L; }();   // tuning knob
         if (k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL && out_bytes < 0x40000000LL &&
             tpi >= 2 && k.tiles_x >= 2 && tpi * tpi * B < 0x100000000LL &&        // magic-division ranges
-            tpi * B >= 2048) {
+            tpi * B >= res_min_tiles) {
             switch (ng) {
                 case 4: return launch_conv_res<T, BN, 4>(k, B, s);
                 case 2: return launch_conv_res<T, BN, 2>(k, B, s);
