@@ -1379,7 +1379,8 @@ int launch_wgrad_ng(const WgradK& k, int ng, hipStream_t s) {
 template <typename T>
 int launch_wgrad_t(const WgradK& k, hipStream_t s) {
     constexpr int G = TT<T>::G;
-    int ng = 4;
+    static const int ng_max = [] { const char* e = getenv("COLVO_WGRAD_NG_MAX"); return e ? atoi(e) : 4; }();   // tuning knob
+    int ng = ng_max;
     for (int i = 0; i < 2; ++i)
         if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
     for (int i = 0; i < 2; ++i)
