@@ -64,6 +64,7 @@ def test_fused_pass_equals_two_pass_and_scales_with_grad_loss(monkeypatch):
     """One-pass loss+gradient == forward then backward (same partial-sum orders are not guaranteed: tolerance), and the
     incoming dL/dloss is applied (2.5 x loss -> 2.5 x gradients)."""
     from coivo_amd import functional as Fh
+    monkeypatch.setattr(Fh, "FUSE_TRAINING_PASS", True)      # whatever COLVO_LOSS_UNFUSED says
     t = to_dev(_case(2, 96, 128, 120, 1.0))
 
     def run(scale):
