@@ -9,7 +9,8 @@ exchange is the sum of parameter gradients.  Design for xGMI (point-to-point lin
     arena crosses a bucket boundary its all-reduce is issued asynchronously (RCCL orders it after the
     kernels already enqueued on the compute stream) while backward keeps running;
   * few, large buckets (default 16 MiB ~ 3 buckets for the 38 MB of gradients): each collective pays the
-    ring latency once and the last, non-overlappable one is the small encoder-stem slice;
+    ring latency once; the last, non-overlappable one is cut down to the final 1 MiB (the encoder stem), the
+    rest of that bucket goes out as soon as its layers are done;
   * optional bf16 transport halves the bytes on the links (BASELINE configs[4]).
 `finish()` makes the compute stream wait for all of them; the 1/world_size average is folded into the
 fused Adam kernel (grad_scale) instead of a separate pass.
@@ -23,12 +24,16 @@ import torch.distributed as dist
 
 
 class _ArenaState:
-    def __init__(self, module, bucket_elems: int):
+    def __init__(self, module, bucket_elems: int, tail_elems: int = 0):
         self.module = module
         n = module.flat_grad.numel()
         # bucket boundaries measured from the END of the arena (backward finishes the tail first)
         bounds = list(range(n, 0, -bucket_elems)) + [0]
-        self.bounds = bounds            # descending: n, n-b, n-2b, ..., 0
+        # The LAST bucket (front of the arena = the first layers, whose gradients finish last) is the only collective
+        # that cannot overlap with backward: keep it small by splitting off the final `tail_elems` when it is larger.
+        if tail_elems and bounds[-2] > 2 * tail_elems:
+            bounds.insert(len(bounds) - 1, tail_elems)
+        self.bounds = bounds            # descending: n, n-b, n-2b, ..., (tail), 0
         self.next = 1                   # index of the next boundary to cross
         self.low = n                    # everything in [low, n) is final
         self.calls = 0
@@ -42,7 +47,7 @@ class GradBuckets:
     """
 
     def __init__(self, modules: Sequence, process_group=None, bucket_bytes: int = 16 << 20,
-                 transport_dtype: Optional[torch.dtype] = None):
+                 transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20):
         if not dist.is_initialized():
             raise RuntimeError("GradBuckets needs an initialised torch.distributed process group")
         self.group = process_group
@@ -51,7 +56,7 @@ class GradBuckets:
         self.states: List[_ArenaState] = []
         self._pending = []
         for m in modules:
-            st = _ArenaState(m, max(1, bucket_bytes // 4))
+            st = _ArenaState(m, max(1, bucket_bytes // 4), max(0, tail_bytes // 4))
             self.states.append(st)
             m.grad_ready_hook = self._make_hook(st)
 
