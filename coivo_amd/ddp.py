@@ -66,17 +66,22 @@ class GradBuckets:
 
     # ---- hook side ----------------------------------------------------------------------------- #
     def _make_hook(self, st: _ArenaState):
-        def hook(module, begin: int, end: int) -> None:
+        def hook(module, begin: int, end: int) -> bool:
+            """Returns True when this call launched a collective (the networks use it to learn where a recorded backward
+            has to be split: only there must the hook run between two segments of the command list)."""
             st.calls += 1
+            launched = False
             if end == st.module.flat_grad.numel() and st.next > 1:
                 raise RuntimeError("GradBuckets: a network ran backward twice in one step after its buckets were "
                                    "already reduced; batch the inputs into one forward (e.g. cat(tgt, ref))")
             if end < st.low:            # not contiguous with the finished suffix: defer to finish()
-                return
+                return False
             st.low = min(st.low, begin)
             while st.next < len(st.bounds) and st.low <= st.bounds[st.next]:
                 self._launch(st, st.bounds[st.next], st.bounds[st.next - 1])
                 st.next += 1
+                launched = True
+            return launched
         return hook
 
     def _launch(self, st: _ArenaState, lo: int, hi: int) -> None:

@@ -214,16 +214,45 @@ class _ArenaModule(nn.Module):
             self._side = torch.cuda.Stream(device=self.flat_param.device, priority=_SIDE_PRIORITY)
         if self.grad_ready_hook is None or not pr.marks:
             pr.run(self._side)
-        else:                       # data parallel: report every finished layer between the segments of the program
-            done = 0
-            for idx, (L, on_side) in pr.marks:
-                pr.run(self._side, done, idx)
-                done = idx
+        else:
+            # Data parallel: the hook of a finished layer may launch a collective, which must be enqueued right after that
+            # layer's kernels.  The first replay splits the program after EVERY layer and notes which hook calls launched
+            # something (a hook that returns None is assumed to); later replays split only there and run the hooks of the
+            # layers in between together, still in order.  A launch at an unexpected place re-arms the learning pass.
+            def call(L, on_side):
                 if on_side:
                     with torch.cuda.stream(self._side):
-                        self.grad_ready_hook(self, L.span[0], L.span[1])
-                else:
-                    self.grad_ready_hook(self, L.span[0], L.span[1])
+                        return self.grad_ready_hook(self, L.span[0], L.span[1])
+                return self.grad_ready_hook(self, L.span[0], L.span[1])
+
+            done = 0
+            flush = getattr(pr, "flush", None)
+            if flush is None or len(flush) != len(pr.marks):
+                learned = []
+                for idx, (L, on_side) in pr.marks:
+                    pr.run(self._side, done, idx)
+                    done = idx
+                    r = call(L, on_side)
+                    learned.append(r is None or bool(r))
+                pr.flush = learned
+            else:
+                pending, ok = [], True
+                for i, (idx, mark) in enumerate(pr.marks):
+                    pending.append(mark)
+                    if flush[i]:
+                        pr.run(self._side, done, idx)
+                        done = idx
+                        for j, (L, on_side) in enumerate(pending):
+                            r = call(L, on_side)
+                            ok = ok and ((r is None or bool(r)) == (j == len(pending) - 1))
+                        pending = []
+                if pending:
+                    pr.run(self._side, done, pr.marks[-1][0])
+                    done = pr.marks[-1][0]
+                    for L, on_side in pending:
+                        ok = ok and not call(L, on_side)
+                if not ok:
+                    pr.flush = None
             pr.run(self._side, done, None)
         return out
 

@@ -69,7 +69,40 @@ def main():
         # Adam's first step is sign-like (+-lr): float-atomic summation order may flip it on ~zero gradients only
         d = (dn.flat_param - dn2.flat_param).abs()
         assert d.max().item() <= 2.5e-4 and (d > 1e-6).float().mean().item() < 5e-3
-        print("DDP_OK", flush=True)
+    # second backward from the same parameters, twice: with the split points learned during the first step (few segments) and
+    # with the learning pass forced again (one segment per layer) -- same gradients, fewer command-list calls
+    from coivo_amd.program import Program
+    calls = [0]
+    orig_run = Program.run
+
+    def counting_run(self, *a, **kw):
+        calls[0] += 1
+        return orig_run(self, *a, **kw)
+
+    Program.run = counting_run
+
+    def ddp_backward():
+        calls[0] = 0
+        opt.zero_grad()
+        hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl])[0].backward()
+        ddp.finish()
+        torch.cuda.synchronize()
+        return dn.flat_grad.clone(), pn.flat_grad.clone(), calls[0]
+
+    ga_dn, ga_pn, n_learned = ddp_backward()
+    for net in (dn, pn):
+        for insts in net._insts.values():
+            for inst in insts:
+                for pr, _ in inst.passes.values():
+                    pr.flush = None
+    gb_dn, gb_pn, n_full = ddp_backward()
+    Program.run = orig_run
+    assert n_learned < n_full, (n_learned, n_full)
+    for a, b, name in ((ga_dn, gb_dn, "DepthNet"), (ga_pn, gb_pn, "PoseNet")):
+        scale = b.abs().max().item()
+        assert (a - b).abs().max().item() < 2e-4 * scale, f"{name}: learned split points changed the all-reduced gradient"
+    if rank == 0:
+        print("DDP_OK", f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
