@@ -79,7 +79,8 @@ def cpu_baseline(B, H, W, budget_s):
     opt = torch.optim.Adam(list(dn.parameters()) + list(pn.parameters()), **S.ADAM_KW)
     b = synth.make_batch(B, H, W, seed=1234)
     t0 = time.perf_counter()
-    S.train_step(dn, pn, opt, b["tgt"], b["ref"], b["K"])          # warm-up (allocations, thread pool)
+    for _ in range(3):                                             # >= 3 warm-ups: allocations, thread pool
+        S.train_step(dn, pn, opt, b["tgt"], b["ref"], b["K"])
     warm = time.perf_counter() - t0
     times = []
     t_start = time.perf_counter()
@@ -90,7 +91,7 @@ def cpu_baseline(B, H, W, budget_s):
     times.sort()
     med = times[len(times) // 2]
     return {"value": B / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (pure-torch fp32) full train step, B={B} {W}x{H}, 1 warm-up + {len(times)} timed steps, median"}
+            "sample": f"oracle (pure-torch fp32) full train step, B={B} {W}x{H}, 3 warm-ups + {len(times)} timed steps, median"}
 
 
 def depth_l1_vs_oracle(dev, cdt, B, H, W):
@@ -158,10 +159,17 @@ def roofline_cfg2(dev):
     pose = rep(b["gt_pose"]).requires_grad_(True)
     a = rep(b["gt_a"]).requires_grad_(True)
     bb = rep(b["gt_b"]).requires_grad_(True)
+    # the training form of the op (nn.DepthNet.forward_pair_split): the depth gradient leaves the op unnormalised together
+    # with two device scalars, and its consumer -- the depth head's backward kernel -- multiplies while it reads it
+    hand, hand_p = Fh.GradHandover(), Fh.GradHandover()
+    depth._colvo_handover = hand
+    pose._colvo_handover = a._colvo_handover = bb._colvo_handover = hand_p
     Fh.enable_timing(True)
     for it in range(25):
         loss = Fh.photometric_loss(tgt, ref, depth, pose, K, a, bb)
-        torch.autograd.grad(loss, [depth, pose, a, bb])
+        g_raw, gp, ga, gb = torch.autograd.grad(loss, [depth, pose, a, bb])
+        hand.take((g_raw,))
+        hand_p.take((gp, ga, gb))
     torch.cuda.synchronize()
     ev = Fh.timing_events()
     tf = sorted(e0.elapsed_time(e1) for e0, e1 in ev["fwd"][5:])
@@ -175,7 +183,9 @@ def roofline_cfg2(dev):
             "traffic": pmc_traffic("B=32 640x512 (configs[2])"),
             "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
             "timing": "hip events on the launch stream directly around each C-ABI call (forward = one-pass loss + unnormalised "
-                      "gradients + finalize, backward = scaling kernel), median of 20 launches"}
+                      "gradients + finalize; backward launches nothing -- all four gradients are handed to their consumers, the "
+                      "depth / pose head backward kernels, unnormalised with two device scalars, as in the training step: "
+                      "bwd_us is the cost of the two event records), median of 20 launches"}
 
 
 def main():
@@ -202,13 +212,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from coivo_amd import _lib as _colvo_lib
-    if not os.path.exists(_colvo_lib.LIB_PATH):       # fresh checkout: build the HIP extension in-tree (rank 0 first)
-        from coivo_amd import build as _colvo_build
-        if local_rank == 0:
-            _colvo_build.build()
-        if world > 1:
-            dist.barrier()
+    from coivo_amd import build as _colvo_build      # fresh checkout / edited kernels: (re)build in-tree, rank 0 first
+    if local_rank == 0:
+        _colvo_build.ensure()
+    if world > 1:
+        dist.barrier()
     from coivo_amd import functional as Fh
     from coivo_amd import nn as hnn
     from coivo_amd import synth
@@ -236,6 +244,7 @@ def main():
     frames = torch.cat([batch["tgt"], batch["ref"]], dim=0)      # one resident buffer: target frames, then reference
     tgt, ref, K = frames[:B], frames[B:], batch["K"]
 
+    one = torch.ones((), device=dev)      # dL/dloss, persistent (no ones_like() fill kernel per step)
     graphed = None
     if args.graph == "on":
         from coivo_amd.graph import GraphedTrainStep
@@ -255,10 +264,10 @@ def main():
         if graphed is not None and not timed:
             return graphed()
         opt.zero_grad()
-        d_t, d_r = dn.forward_pair(frames)
+        d_t, d_r, d_l = dn.forward_pair_split(frames)     # d_l: depth_t again, the loss's own gradient path (nn.py)
         pose, a, b = pn(tgt, ref, d_t, d_r)
-        loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
-        loss.backward()
+        loss = Fh.photometric_loss(tgt, ref, d_l, pose, K, a, b)
+        loss.backward(gradient=one)
         if ddp is not None:
             ddp.finish()
         opt.step()
@@ -275,11 +284,15 @@ def main():
     if not use_graph:
         Fh.enable_timing(rank == 0)     # HIP events around the fused-op launches inside the timed steps
     barrier()
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        step_ev[i].record()
         loss = step(not use_graph)
+    step_ev[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    ev_ms = sorted(step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps))
     if use_graph:
         # kernels inside a replayed graph cannot be bracketed by events: time the fused op in the same process
         # with the same step launched eagerly right after the timed region (not part of `value`)
@@ -308,10 +321,11 @@ def main():
                 "traffic": pmc_traffic("B=8 320x256 (configs[1])"), "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
                 "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3,
                 "timing": "hip events on the launch stream directly around the fused op's C-ABI calls inside the timed "
-                          "steps (forward call = one-pass loss + unnormalised gradients + finalize, backward call = scaling kernel), mean over steps; latency-dominated at this size "
+                          "steps (forward call = one-pass loss + unnormalised gradients + finalize, backward call launches nothing: the gradients are normalised by the depth / pose head backward kernels), mean over steps; latency-dominated at this size "
                           "(SURVEY.md §8d) -- the roofline is read at configs[2], see roofline_cfg2"}
         out = {"metric": "training frame-pairs/sec at 320x256", "value": value, "unit": "frame-pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "ms_per_step_hipevent_median": ev_ms[len(ev_ms) // 2],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU {W}x{H} full DCDP+LCC train step "

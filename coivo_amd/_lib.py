@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -26,12 +26,14 @@ class ConvDesc(C.Structure):
 # name -> (restype, argtypes); lists every symbol include/colvo.h declares
 class Cmd(C.Structure):
     """Mirror of ColvoCmd (include/colvo.h)."""
-    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("desc", ConvDesc), ("p", C.c_void_p * 8),
+    _fields_ = [("op", C.c_int32), ("stream", C.c_int32), ("desc", ConvDesc), ("p", C.c_void_p * 12),
                 ("i", C.c_int32 * 12), ("f", C.c_float * 4)]
 
 
 (CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
- CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN) = range(1, 13)
+ CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN,
+ CMD_DEPTH_HEAD_BWD_PARTS) = range(1, 14)
+NPTR = 12      # pointer slots of a ColvoCmd
 
 SIGNATURES = {
     "colvo_abi_version": (_i, []),
@@ -39,8 +41,9 @@ SIGNATURES = {
     "colvo_warp_loss_workspace_floats": (_sz, [_i, _i, _i]),
     "colvo_warp_loss_fwd": (_i, [_vp] * 7 + [_i, _i, _i, _f, _vp, _vp, _vp]),
     "colvo_warp_loss_bwd": (_i, [_vp] * 7 + [_i, _i, _i, _f] + [_vp] * 8),
-    "colvo_warp_loss_fused": (_i, [_vp] * 7 + [_i, _i, _i, _f] + [_vp] * 5),
+    "colvo_warp_loss_fused": (_i, [_vp] * 7 + [_i, _i, _i, _f] + [_vp] * 6),
     "colvo_warp_loss_fused_bwd": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
+    "colvo_warp_loss_fused_bwd_params": (_i, [_vp] * 4 + [_i] + [_vp] * 4),
     "colvo_inverse_warp": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 3),
     "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -53,9 +56,11 @@ SIGNATURES = {
     "colvo_depth_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_depth_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "colvo_depth_head_wgrad": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "colvo_depth_head_bwd_parts": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _f] + [_vp] * 5),
     "colvo_pose_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
-    "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
+    "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
+    "colvo_zero": (_i, [_vp, _sz, _vp]),
     "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
 }
 
@@ -71,6 +76,12 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built (run `python -m coivo_amd.build`). "
             "coivo_amd has no CPU or PyTorch fallback.")
+    if not os.environ.get("COLVO_LIB_PATH"):
+        from . import build as _build
+        if not _build.is_current():
+            raise RuntimeError(
+                f"{LIB_PATH} was not built from the sources in this tree (coivo_amd/csrc, include/colvo.h or the "
+                "build flags changed): run `python -m coivo_amd.build` (tests, bench.py and smoke() call build.ensure())")
     # torch bundles its own HIP/HSA runtime (soname libamdhip64.so.7, same as /opt/rocm's).  It must be
     # in the process BEFORE libcolvo.so so that our NEEDED entry binds to that copy: the kernels then share
     # torch's HIP context and streams.  Loading /opt/rocm's runtime first puts two HSA runtimes in one

@@ -23,7 +23,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-fno-gpu-rdc", "-DNDEBUG",
          # CDNA4 executes packed f32 (v_pk_*_f32) at the plain-op rate, so SLP packing only adds the
          # v_mov pairs that feed it (measured: fused-loss fwd 112 -> 47 VGPRs, -21 % VALU without it)
-         "-fno-slp-vectorize"]
+         "-fno-slp-vectorize",
+         # MFMA accumulators in VGPRs, never AGPRs: conv.hip's mfma_result_guard() ties them to an asm statement with "+v",
+         # and an AGPR accumulator would be copied out (= read) in front of that statement (profiles/r2_mfma_hazard.md)
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _deps():
@@ -49,6 +52,47 @@ def _compile(src):
     return obj
 
 
+HASHFILE = os.path.join(LIBDIR, "libcolvo.srchash")
+
+
+def source_hash() -> str:
+    """sha256 over every source the library is built from (csrc/*.hip, csrc/*.h, include/colvo.h) and the flags.
+    Stored beside the .so by build(); _lib.load() refuses a library whose hash differs from the tree's (the .so is
+    git-ignored and travels with the tree, so an edited kernel must never run against a stale binary)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(_deps())
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_current() -> bool:
+    try:
+        with open(HASHFILE) as f:
+            return os.path.exists(LIB) and f.read().strip() == source_hash()
+    except OSError:
+        return False
+
+
+def ensure() -> str:
+    """Build unless the in-tree library was built from exactly these sources."""
+    return LIB if is_current() else build()
+
+
+def emit_asm(src_name: str, out: str) -> str:
+    """gfx950 ISA listing of one csrc file with the library's flags (tools/isa_check_mfma.py, tests/test_isa_cpu.py)."""
+    src = os.path.join(CSRC, src_name)
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-fPIC"] + ["--offload-device-only", "-S", src, "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stdout}\n{r.stderr}")
+    return out
+
+
 def build(force: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -57,13 +101,23 @@ def build(force: bool = False) -> str:
     if force:
         for f in glob.glob(os.path.join(OBJDIR, "*.o")):
             os.remove(f)
+    # objects are keyed by the hash of their own inputs (mtimes do not survive a copy of the tree)
+    stamp = os.path.join(OBJDIR, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        for f in glob.glob(os.path.join(OBJDIR, "*.o")):
+            os.remove(f)
+        with open(stamp, "w") as f:
+            f.write(flags_now)
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    if force or _stale(LIB, objs):
+    if force or _stale(LIB, objs) or not is_current():
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(HASHFILE, "w") as f:
+            f.write(source_hash())
     return LIB
 
 

@@ -127,32 +127,77 @@ struct WgradK {
 __device__ __forceinline__ int mdiv(int i, uint32_t m) { return (int)__umulhi((uint32_t)i, m); }
 inline uint32_t mdiv_magic(int d) { return (uint32_t)((0x100000000ULL + (uint32_t)d - 1) / (uint32_t)d); }
 
-// Between the last MFMA of a chain and the first VALU read of its accumulators.  hipcc's own wait states proved too few
-// for v_mfma_f32_16x16x4_f32 on gfx950: with `s_nop 8` + 4 instructions (13 wait states) the first register of the last
-// written accumulator came back stale in a few lanes, non-deterministically; with 16 it never did (found when a change
-// of register allocation moved that read 3 slots earlier).  The accumulators are operands of the asm statement so that
-// every MFMA is ordered before it and every read (including AGPR -> VGPR copies) after it.  Applied to the bf16 MFMAs as
-// well: measured perf-neutral, and their wait states come from the same (gfx950-new) tables.
-template <int N>
+// Accumulator hand-over from the MFMA chain to the epilogue.
+//
+// hipcc's register allocator sometimes ROTATES the accumulators of a chain, i.e. emits MFMAs whose vDst is not their SrcC
+// (`v_mfma a[4:7], .., .., a[8:11]`).  Measured on MI355X (tools/ubench/mfma_hazard.hip, profiles/r2_mfma_hazard.md):
+//   * in-place MFMAs (vDst == SrcC): v_mfma_f32_16x16x4_f32 results are hardware-interlocked against VALU reads (correct
+//     with ZERO wait states); v_mfma_f32_16x16x32_bf16 results need the 7 wait states of LLVM's table -- hipcc is right;
+//   * rotated MFMAs: NOT interlocked; the f32 form needs >= 10, the bf16 form >= 8 wait states in a 2-waves-per-SIMD
+//     micro-benchmark -- hipcc inserts 10 / 7, i.e. no margin / one too few -- and in the real f32 persistent kernel a
+//     read 13 states after a rotated MFMA still came back stale in a few lanes (the round-1 "stale accumulator" bug).
+// A wait-state pad cannot be sized for that, so the chain is closed with one IN-PLACE MFMA per accumulator
+// (acc = 0 * 0 + acc, vDst tied to SrcC by the asm constraint): the SrcC hand-over from a rotated producer is interlocked
+// (ubench ROT 2 / ROT 3), and the terminator's own result is of the safe in-place kind.  All terminators and the 7 + 4
+// wait states the bf16 form needs sit in ONE asm statement whose outputs are the accumulators, so no read can be
+// scheduled in between.  The library is built with -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py): accumulators live
+// in VGPRs, otherwise the "+v" operands would make hipcc copy AGPR -> VGPR (= read the results) in FRONT of this statement.
+// tools/isa_check_mfma.py (tests/test_isa_cpu.py) verifies on the emitted ISA that no rotated MFMA result is read early.
+#define MT_(i) MFMA_TERM_OP " %" #i ", %[z], %[z], %" #i "\n\t"
+#define MG_(i) "+v"(acc[i])
+template <typename T, int N>
 __device__ __forceinline__ void mfma_result_guard(f32x4 (&acc)[N]) {
-#define G_(i) "+v"(acc[i])
-    if constexpr (N == 1) asm volatile("s_nop 15" : G_(0));
-    else if constexpr (N == 2) asm volatile("s_nop 15" : G_(0), G_(1));
-    else if constexpr (N == 3) asm volatile("s_nop 15" : G_(0), G_(1), G_(2));
-    else if constexpr (N == 4) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3));
-    else if constexpr (N == 6) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5));
-    else if constexpr (N == 8) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7));
-    else if constexpr (N == 5) asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4));
-    else if constexpr (N == 10)
-        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9));
-    else if constexpr (N == 12)
-        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9), G_(10), G_(11));
-    else if constexpr (N == 20)
-        asm volatile("s_nop 15" : G_(0), G_(1), G_(2), G_(3), G_(4), G_(5), G_(6), G_(7), G_(8), G_(9), G_(10), G_(11), G_(12),
-                     G_(13), G_(14), G_(15), G_(16), G_(17), G_(18), G_(19));
-    else static_assert(N == 1, "mfma_result_guard: add a case for this accumulator count");
-#undef G_
+    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10 || N == 12 || N == 20,
+                  "mfma_result_guard: add a case for this accumulator count");
+    // "s_nop 1" in front: the zero operand may have been written by the VALU instruction just before (VALU write -> MFMA read)
+#define MFMA_GUARD_BODY()                                                                                                  \
+    if constexpr (N == 1) asm volatile("s_nop 1\n\t" MT_(0) MFMA_TERM_TAIL : MG_(0) : [z] "v"(z));                             \
+    else if constexpr (N == 2) asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MFMA_TERM_TAIL : MG_(0), MG_(1) : [z] "v"(z));             \
+    else if constexpr (N == 3) asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MFMA_TERM_TAIL : MG_(0), MG_(1), MG_(2) : [z] "v"(z)); \
+    else if constexpr (N == 4)                                                                                           \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MFMA_TERM_TAIL : MG_(0), MG_(1), MG_(2), MG_(3) : [z] "v"(z));      \
+    else if constexpr (N == 5)                                                                                           \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MFMA_TERM_TAIL                                            \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4) : [z] "v"(z));                                              \
+    else if constexpr (N == 6)                                                                                           \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MFMA_TERM_TAIL                                     \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5) : [z] "v"(z));                                      \
+    else if constexpr (N == 8)                                                                                           \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MFMA_TERM_TAIL                       \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7) : [z] "v"(z));                      \
+    else if constexpr (N == 10)                                                                                          \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MFMA_TERM_TAIL         \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9) : [z] "v"(z));      \
+    else if constexpr (N == 12)                                                                                          \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
+                     MFMA_TERM_TAIL                                                                                      \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11)   \
+                     : [z] "v"(z));                                                                                      \
+    else                                                                                                                 \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
+                     MT_(12) MT_(13) MT_(14) MT_(15) MT_(16) MT_(17) MT_(18) MT_(19) MFMA_TERM_TAIL                      \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11),  \
+                       MG_(12), MG_(13), MG_(14), MG_(15), MG_(16), MG_(17), MG_(18), MG_(19)                            \
+                     : [z] "v"(z))
+    if constexpr (TT<T>::ES == 4) {
+#define MFMA_TERM_OP "v_mfma_f32_16x16x4_f32"
+#define MFMA_TERM_TAIL "s_nop 3"       /* interlocked in hardware; a token pad for the (unmodelled) asm boundary */
+        const float z = 0.0f;
+        MFMA_GUARD_BODY();
+#undef MFMA_TERM_OP
+#undef MFMA_TERM_TAIL
+    } else {
+#define MFMA_TERM_OP "v_mfma_f32_16x16x32_bf16"
+#define MFMA_TERM_TAIL "s_nop 11"      /* in-place XDL 16x16x32 result -> VALU read: 7 wait states (+4 margin) */
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        MFMA_GUARD_BODY();
+#undef MFMA_TERM_OP
+#undef MFMA_TERM_TAIL
+    }
+#undef MFMA_GUARD_BODY
 }
+#undef MT_
+#undef MG_
 
 __device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
 // 16-byte buffer load: 32-bit per-lane byte offset + scalar byte offset; an offset beyond the descriptor's size
@@ -657,7 +702,7 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
       }
     }
 
-    mfma_result_guard(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
 #ifdef COLVO_ABLATE
     if (ABL(32)) {
         for (int mf = 0; mf < 2; ++mf)
@@ -855,7 +900,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
                                 __uint_as_float(bv[nf][j]), __uint_as_float(av[mf][j]), acc[mf][nf], 0, 0, 0);
             }
         }
-        mfma_result_guard(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
+        mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
         if (!a.pool2) {
             ep.finish(a, acc, biasv, rout, cur.b * img_out);
         } else {
@@ -1122,7 +1167,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         }
     }
 
-    mfma_result_guard(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
     // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)

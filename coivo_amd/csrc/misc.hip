@@ -214,6 +214,23 @@ __global__ __launch_bounds__(NT) void k_depth_head_dpre(const float* __restrict_
     if (i < n) dpre[i] = head_dpre(depth[i], d_depth[i], lo, hi);
 }
 
+// the same with the incoming gradient in parts: first half of the images g0 + sa*sb*graw, second half g1 (any may be null)
+__global__ __launch_bounds__(NT) void k_depth_head_dpre_parts(const float* __restrict__ depth, const float* __restrict__ g0,
+                                                              const float* __restrict__ g1, const float* __restrict__ graw,
+                                                              const float* __restrict__ sa, const float* __restrict__ sb,
+                                                              size_t n_half, float lo, float hi, float* __restrict__ dpre) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= 2 * n_half) return;
+    float g;
+    if (i < n_half) {
+        g = g0 ? g0[i] : 0.0f;
+        if (graw) g = fmaf((sa ? sa[0] : 1.0f) * (sb ? sb[0] : 1.0f), graw[i], g);
+    } else {
+        g = g1 ? g1[i - n_half] : 0.0f;
+    }
+    dpre[i] = head_dpre(depth[i], g, lo, hi);
+}
+
 // dx[y,x,c] = (x[y,x,c] > 0) * sum_taps dpre[y-ky+1, x-kx+1] * w[ky,kx,c]
 template <int ES>
 __global__ __launch_bounds__(NT) void k_depth_head_dgrad(const void* __restrict__ x, const float* __restrict__ w,
@@ -381,10 +398,14 @@ __global__ __launch_bounds__(NT) void k_pose_head_fwd(const void* __restrict__ x
 template <int ES>
 __global__ __launch_bounds__(NT) void k_pose_head_bwd(const void* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ d_pose, const float* __restrict__ d_a,
-                                                      const float* __restrict__ d_b, int HW, int C, float pose_scale,
+                                                      const float* __restrict__ d_b, const float* __restrict__ sa,
+                                                      const float* __restrict__ sb, int HW, int C, float pose_scale,
                                                       float lcc_scale, void* __restrict__ dx, float* __restrict__ dw,
                                                       float* __restrict__ db) {
     const int b = blockIdx.x, tid = threadIdx.x;
+    const float gs = (sa ? sa[0] : 1.0f) * (sb ? sb[0] : 1.0f);
+    pose_scale *= gs;
+    lcc_scale *= gs;
     float go[8];
 #pragma unroll
     for (int j = 0; j < 6; ++j) go[j] = d_pose ? d_pose[b * 6 + j] * pose_scale : 0.0f;
@@ -547,6 +568,31 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
     return 0;
 }
 
+extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float* w, const float* depth, const float* g_first,
+                                          const float* g_second, const float* g_raw, const float* scale_a,
+                                          const float* scale_b, int B, int H, int W, int C, float min_depth, float max_depth,
+                                          float* scratch, void* dx, float* dw, float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && depth && scratch && dx && ((dw == nullptr) == (db == nullptr)),
+                    "colvo_depth_head_bwd_parts: null pointer argument");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_bwd_parts: bad dtype");
+    COLVO_CHECK_ARG(B >= 2 && B % 2 == 0 && B <= 65534 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 &&
+                        max_depth > min_depth,
+                    "colvo_depth_head_bwd_parts: bad shape / range (B = 2*Bh images)");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t HW = (size_t)H * W, n = (size_t)B * HW;
+    const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
+    hipLaunchKernelGGL(k_depth_head_dpre_parts, dim3(nblk(n)), dim3(NT), 0, s, depth, g_first, g_second, g_raw, scale_a,
+                       scale_b, n / 2, lo, hi, scratch);
+    COLVO_CHECK_LAUNCH("k_depth_head_dpre_parts");
+    if (dw) {
+        if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
+    }
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+                                          x, w, scratch, H, W, C, dx));
+    COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
+    return 0;
+}
+
 // The weight / bias gradient alone, from the d(pre) plane colvo_depth_head_bwd left in `scratch` (so that it can run on
 // another stream than the input gradient).
 extern "C" int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw,
@@ -580,12 +626,12 @@ extern "C" int colvo_pose_head_fwd(int dtype, const void* x, const float* w, con
 }
 
 extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a,
-                                   const float* d_b, int B, int HW, int C, float pose_scale, float lcc_scale, void* dx,
-                                   float* dw, float* db, colvo_stream_t stream) {
+                                   const float* d_b, const float* scale_a, const float* scale_b, int B, int HW, int C,
+                                   float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && w && dx && dw && db && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_bwd: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd: bad dtype");
     DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_pose, d_a,
-                                          d_b, HW, C, pose_scale, lcc_scale, dx, dw, db));
+                                          d_b, scale_a, scale_b, HW, C, pose_scale, lcc_scale, dx, dw, db));
     COLVO_CHECK_LAUNCH("k_pose_head_bwd");
     return 0;
 }
@@ -604,5 +650,13 @@ extern "C" int colvo_adam_step(float* param, const float* grad, float* exp_avg, 
     }
     hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
     COLVO_CHECK_LAUNCH("k_inc_step");
+    return 0;
+}
+
+extern "C" int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(ptr || bytes == 0, "colvo_zero: null pointer argument");
+    if (bytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) { set_error("colvo_zero: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }

@@ -8,22 +8,27 @@
 //
 // The host side (coivo_amd/program.py) records the commands once per (network, shape) with persistent activation
 // buffers, patches the few per-call pointers (input images, output, incoming gradients) and replays.
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 using namespace colvo;
 
 namespace {
-constexpr int NEV = 64;
+// FORK / JOIN events: a ring of library-owned host objects.  Forward passes run on the caller's thread and backward
+// passes on autograd's, so creation is once-only (std::call_once) and the cursor is atomic.  An event is re-recorded
+// NEV uses later; by then the wait it fed has long been enqueued (hipStreamWaitEvent captures the record it sees).
+constexpr unsigned NEV = 256;
 hipEvent_t g_ev[NEV];
-bool g_ev_init = false;
-unsigned g_ev_next = 0;
+std::once_flag g_ev_once;
+std::atomic<unsigned> g_ev_next{0};
 
 hipEvent_t next_event() {
-    if (!g_ev_init) {
-        for (int i = 0; i < NEV; ++i) (void)hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming);
-        g_ev_init = true;
-    }
-    return g_ev[g_ev_next++ % NEV];
+    std::call_once(g_ev_once, [] {
+        for (unsigned i = 0; i < NEV; ++i) (void)hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming);
+    });
+    return g_ev[g_ev_next.fetch_add(1, std::memory_order_relaxed) % NEV];
 }
 }  // namespace
 
@@ -63,6 +68,12 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                                           c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[4], (void*)c.p[5],
                                           (float*)c.p[6], (float*)c.p[7], s);
                 break;
+            case COLVO_CMD_DEPTH_HEAD_BWD_PARTS:
+                rc = colvo_depth_head_bwd_parts(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
+                                                (const float*)c.p[4], (const float*)c.p[5], (const float*)c.p[6],
+                                                (const float*)c.p[7], c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1],
+                                                (float*)c.p[8], (void*)c.p[9], nullptr, nullptr, s);
+                break;
             case COLVO_CMD_DEPTH_HEAD_WGRAD:
                 rc = colvo_depth_head_wgrad(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4],
                                             (float*)c.p[2], (float*)c.p[3], s);
@@ -73,8 +84,8 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 break;
             case COLVO_CMD_POSE_HEAD_BWD:
                 rc = colvo_pose_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
-                                         (const float*)c.p[4], c.i[1], c.i[2], c.i[3], c.f[0], c.f[1], (void*)c.p[5],
-                                         (float*)c.p[6], (float*)c.p[7], s);
+                                         (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2],
+                                         c.i[3], c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
                 break;
             case COLVO_CMD_FORK: {       // the side stream continues after everything enqueued so far on the main stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");

@@ -248,6 +248,28 @@ __device__ __forceinline__ float dpp_from_right(float v) {   // lane i <- lane i
 }
 __device__ __forceinline__ float hsum3(float v) { return v + dpp_from_left(v) + dpp_from_right(v); }
 
+// Horizontal 3-sums of N values in ONE asm statement: 2 N v_add_f32_dpp.  Written by hand because hipcc fused only a third
+// of the `v + dpp(v) + dpp(v)` forms into DPP adds and emitted v_mov_b32_dpp + v_add_f32 pairs for the rest (34 of the
+// ~600 instructions of a backward step).  The leading s_nop 1 covers "VALU write -> DPP read of that VGPR: 2 wait states"
+// for all N sources at once (hipcc cannot see into the statement); the second add of each pair reads its DPP source again
+// (old by then) and the partial sum through the plain operand.  r[i] = v[i](lane-1) + v[i] + v[i](lane+1), 0 beyond the wave.
+#define HS_A_(r, v) "v_add_f32_dpp %" #r ", %" #v ", %" #v " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+#define HS_B_(r, v) "v_add_f32_dpp %" #r ", %" #v ", %" #r " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+__device__ __forceinline__ void hsum3x5(float v0, float v1, float v2, float v3, float v4, float& r0, float& r1, float& r2,
+                                        float& r3, float& r4) {
+    asm("s_nop 1\n\t" HS_A_(0, 5) HS_A_(1, 6) HS_A_(2, 7) HS_A_(3, 8) HS_A_(4, 9) HS_B_(0, 5) HS_B_(1, 6) HS_B_(2, 7) HS_B_(3, 8)
+        HS_B_(4, 9)
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4));
+}
+__device__ __forceinline__ void hsum3x3(float v0, float v1, float v2, float& r0, float& r1, float& r2) {
+    asm("s_nop 1\n\t" HS_A_(0, 3) HS_A_(1, 4) HS_A_(2, 5) HS_B_(0, 3) HS_B_(1, 4) HS_B_(2, 5)
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2)
+        : "v"(v0), "v"(v1), "v"(v2));
+}
+#undef HS_A_
+#undef HS_B_
+
 struct MarchState {
     float dv[3], T[3][3];                 // stage A: depth + target of rows j, j+1, j+2 (slot = row % 3)
     float v[3][3][4], wx[3], wy[3], m[3]; // stage B: taps + weights + validity
@@ -298,11 +320,8 @@ __device__ __forceinline__ void march_step(MarchState& st, const Geo& g, const I
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float J = Jc[c], T = Tc[c];
-        st.h[K][5 * c + 0] = hsum3(T);
-        st.h[K][5 * c + 1] = hsum3(J);
-        st.h[K][5 * c + 2] = hsum3(T * T);
-        st.h[K][5 * c + 3] = hsum3(J * J);
-        st.h[K][5 * c + 4] = hsum3(T * J);
+        hsum3x5(T, J, T * T, J * J, T * J, st.h[K][5 * c + 0], st.h[K][5 * c + 1], st.h[K][5 * c + 2], st.h[K][5 * c + 3],
+                st.h[K][5 * c + 4]);
         l1cur[c] = fabsf(T - J);
     }
     {                                                    // output row = slot row j-1 (mprev = 0 until it exists)
@@ -454,7 +473,9 @@ struct BwdState {
 
 // FUSED: the same pass also accumulates the loss itself (alpha, 1 - alpha in al / l1w), for the one-kernel
 // loss + unnormalised-gradient forward of the training path (colvo_warp_loss_fused).
-template <int K, bool FUSED>
+// EDGE: the strip touches the left / right image border (or hangs over it), so the horizontal gather of the window
+// coefficients needs the reflection multiplicities wxw[]; interior strips (9 of 11 at W = 640) take plain 3-sums.
+template <int K, bool FUSED, bool EDGE>
 __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& im, int j, int nrows, int y_first,
                                          int gxcol, int px, bool own_col, float Xh, const float (&wxw)[3], int H,
                                          int W, float kss, float kl1, float* __restrict__ d_depth_img, float al, float l1w) {
@@ -507,11 +528,8 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float J = Jc[c], T = Tc[c];
-        st.H[K][5 * c + 0] = hsum3(T);
-        st.H[K][5 * c + 1] = hsum3(J);
-        st.H[K][5 * c + 2] = hsum3(T * T);
-        st.H[K][5 * c + 3] = hsum3(J * J);
-        st.H[K][5 * c + 4] = hsum3(T * J);
+        hsum3x5(T, J, T * T, J * J, T * J, st.H[K][5 * c + 0], st.H[K][5 * c + 1], st.H[K][5 * c + 2], st.H[K][5 * c + 3],
+                st.H[K][5 * c + 4]);
     }
     // (4) derivative coefficients of window row j-1 (centre = row j-1, this lane's column), gathered horizontally.
     //     No branch on j: before two rows have been seen the zero-initialised H gives S = 1, i.e. zero coefficients,
@@ -535,9 +553,13 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             const float A = live * 2.0f * (s.sx * (s.A2 - s.A1) - S * s.sy * (s.B2 - s.B1)) * inv;
             const float Bc = live * -18.0f * S * (inv * s.B1);
             const float Cc = live * 18.0f * s.A1 * inv;
-            st.HK[K2][3 * c + 0] = fmaf(wxw[0], dpp_from_left(A), fmaf(wxw[2], dpp_from_right(A), wxw[1] * A));
-            st.HK[K2][3 * c + 1] = fmaf(wxw[0], dpp_from_left(Bc), fmaf(wxw[2], dpp_from_right(Bc), wxw[1] * Bc));
-            st.HK[K2][3 * c + 2] = fmaf(wxw[0], dpp_from_left(Cc), fmaf(wxw[2], dpp_from_right(Cc), wxw[1] * Cc));
+            if constexpr (EDGE) {
+                st.HK[K2][3 * c + 0] = fmaf(wxw[0], dpp_from_left(A), fmaf(wxw[2], dpp_from_right(A), wxw[1] * A));
+                st.HK[K2][3 * c + 1] = fmaf(wxw[0], dpp_from_left(Bc), fmaf(wxw[2], dpp_from_right(Bc), wxw[1] * Bc));
+                st.HK[K2][3 * c + 2] = fmaf(wxw[0], dpp_from_left(Cc), fmaf(wxw[2], dpp_from_right(Cc), wxw[1] * Cc));
+            } else {
+                hsum3x3(A, Bc, Cc, st.HK[K2][3 * c + 0], st.HK[K2][3 * c + 1], st.HK[K2][3 * c + 2]);
+            }
             if constexpr (FUSED)
                 lrow += al * fminf(fmaxf(ss, 0.0f), 1.0f) + l1w * fabsf(st.Tk[K2][c] - fmaf(g.a, st.Wp[K2][c], g.b));
         }
@@ -680,11 +702,22 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
         }
     }
     float* ddimg = d_depth + (size_t)b * H * W;
+    // interior strip: every lane's column and both its neighbours are inside the image (all multiplicities are 1)
+    const bool edge = !(x0 >= 3 && x0 + 61 <= W - 2);          // wave-uniform
+    if (edge) {
 #pragma unroll 1
-    for (int j = 0; j < nrows; j += 3) {
-        bwd_step<0, FUSED>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-        bwd_step<1, FUSED>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-        bwd_step<2, FUSED>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+        for (int j = 0; j < nrows; j += 3) {
+            bwd_step<0, FUSED, true>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<1, FUSED, true>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<2, FUSED, true>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+        }
+    } else {
+#pragma unroll 1
+        for (int j = 0; j < nrows; j += 3) {
+            bwd_step<0, FUSED, false>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<1, FUSED, false>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<2, FUSED, false>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+        }
     }
     constexpr int NP = FUSED ? NPART_F : NPART;
 #pragma unroll
@@ -700,8 +733,24 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
 
 // fused forward, second kernel: blocks 0..B-1 fold the 14 gradient sums of one image (still unnormalised) into
 // gpart[b][14]; block B folds the loss sum and the valid count of ALL strips into loss_state.  Fixed orders: deterministic.
+// dR (row-major 3x3 gradient w.r.t. the rotation matrix) -> gradient w.r.t. the Euler angles (R = Rz Ry Rx)
+__device__ __forceinline__ void dR_to_euler(const float* dR, const float* p, float& drx, float& dry, float& drz) {
+    const float sx = sinf(p[3]), cx = cosf(p[3]), sy = sinf(p[4]), cy = cosf(p[4]), sz = sinf(p[5]), cz = cosf(p[5]);
+    drx = dR[1] * (cz * sy * cx + sz * sx) + dR[2] * (-cz * sy * sx + sz * cx)
+        + dR[4] * (sz * sy * cx - cz * sx) + dR[5] * (-sz * sy * sx - cz * cx)
+        + dR[7] * (cy * cx) + dR[8] * (-cy * sx);
+    dry = dR[0] * (-cz * sy) + dR[1] * (cz * cy * sx) + dR[2] * (cz * cy * cx)
+        + dR[3] * (-sz * sy) + dR[4] * (sz * cy * sx) + dR[5] * (sz * cy * cx)
+        + dR[6] * (-cy) + dR[7] * (-sy * sx) + dR[8] * (-sy * cx);
+    drz = dR[0] * (-sz * cy) + dR[1] * (-sz * sy * sx - cz * cx) + dR[2] * (-sz * sy * cx + cz * sx)
+        + dR[3] * (cz * cy) + dR[4] * (cz * sy * sx - sz * cx) + dR[5] * (cz * sy * cx + sz * sx);
+}
+
+// gunit (may be null): the pose / LCC gradients of every image, still UNNORMALISED, already converted to Euler angles, in
+// PoseNet's planar output layout [d_pose B x 6 | d_a B | d_b B] -- for consumers that apply dL/dloss / max(3 n, 1) themselves
 __global__ __launch_bounds__(NT) void k_warp_loss_fused_finalize(const float* __restrict__ partials, int blocks_per_image,
-                                                                 int B, float* __restrict__ gpart,
+                                                                 int B, const float* __restrict__ pose,
+                                                                 float* __restrict__ gpart, float* __restrict__ gunit,
                                                                  float* __restrict__ loss_state) {
     __shared__ float s0[NT], s1[NT];
     const int tid = threadIdx.x;
@@ -737,6 +786,17 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fused_finalize(const float* __
         float t = 0.0f;
         for (int i = 0; i < ROWS; ++i) t += s[tid * ROWS + i];
         gpart[b * NPART + tid] = t;
+        s1[tid] = t;
+    }
+    if (gunit == nullptr) return;
+    __syncthreads();
+    if (tid == 0) {
+        float drx, dry, drz;
+        dR_to_euler(s1 + 3, pose + 6 * b, drx, dry, drz);
+        gunit[6 * b + 0] = s1[0]; gunit[6 * b + 1] = s1[1]; gunit[6 * b + 2] = s1[2];
+        gunit[6 * b + 3] = drx; gunit[6 * b + 4] = dry; gunit[6 * b + 5] = drz;
+        gunit[6 * B + b] = s1[12];
+        gunit[7 * B + b] = s1[13];
     }
 }
 
@@ -773,6 +833,36 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fused_bwd(const float* __restr
         d_a[b] = tot[12];
         d_b[b] = tot[13];
     }
+}
+
+// pose / LCC gradients only (one thread per image): the depth gradient's normalisation is applied by its consumer
+__global__ __launch_bounds__(64) void k_warp_loss_fused_bwd_params(const float* __restrict__ loss_state,
+                                                                   const float* __restrict__ grad_loss,
+                                                                   const float* __restrict__ gpart,
+                                                                   const float* __restrict__ pose, int B,
+                                                                   float* __restrict__ d_pose, float* __restrict__ d_a,
+                                                                   float* __restrict__ d_b) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float scale = grad_loss[0] * loss_state[1];
+    float tot[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) tot[k] = scale * gpart[b * NPART + k];
+    const float* p = pose + 6 * b;
+    const float sx = sinf(p[3]), cx = cosf(p[3]), sy = sinf(p[4]), cy = cosf(p[4]), sz = sinf(p[5]), cz = cosf(p[5]);
+    const float* dR = tot + 3;  // row-major 3x3
+    const float drx = dR[1] * (cz * sy * cx + sz * sx) + dR[2] * (-cz * sy * sx + sz * cx)
+                    + dR[4] * (sz * sy * cx - cz * sx) + dR[5] * (-sz * sy * sx - cz * cx)
+                    + dR[7] * (cy * cx) + dR[8] * (-cy * sx);
+    const float dry = dR[0] * (-cz * sy) + dR[1] * (cz * cy * sx) + dR[2] * (cz * cy * cx)
+                    + dR[3] * (-sz * sy) + dR[4] * (sz * cy * sx) + dR[5] * (sz * cy * cx)
+                    + dR[6] * (-cy) + dR[7] * (-sy * sx) + dR[8] * (-sy * cx);
+    const float drz = dR[0] * (-sz * cy) + dR[1] * (-sz * sy * sx - cz * cx) + dR[2] * (-sz * sy * cx + cz * sx)
+                    + dR[3] * (cz * cy) + dR[4] * (cz * sy * sx - sz * cx) + dR[5] * (cz * sy * cx + sz * sx);
+    d_pose[6 * b + 0] = tot[0]; d_pose[6 * b + 1] = tot[1]; d_pose[6 * b + 2] = tot[2];
+    d_pose[6 * b + 3] = drx; d_pose[6 * b + 4] = dry; d_pose[6 * b + 5] = drz;
+    d_a[b] = tot[12];
+    d_b[b] = tot[13];
 }
 
 // one workgroup per image: fixed-order sum of that image's tile partials, then dR -> d(euler)
@@ -917,7 +1007,7 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
 extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const float* depth, const float* pose,
                                      const float* K, const float* lcc_a, const float* lcc_b, int B, int H, int W,
                                      float ssim_weight, float* workspace, float* loss_state, float* d_depth_raw,
-                                     float* grad_partials, colvo_stream_t stream) {
+                                     float* grad_partials, float* grad_unit, colvo_stream_t stream) {
     COLVO_CHECK_ARG(tgt && ref && depth && pose && K && lcc_a && lcc_b && workspace && loss_state && d_depth_raw && grad_partials,
                     "colvo_warp_loss_fused: null pointer argument");
     COLVO_CHECK_ARG(B >= 1 && H >= 2 && W >= 2 && B <= 65534, "colvo_warp_loss_fused: bad shape B=%d H=%d W=%d", B, H, W);
@@ -932,8 +1022,8 @@ extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const f
                        K, lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, (const float*)nullptr,
                        (const float*)nullptr, d_depth_raw, workspace);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<fused>");
-    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(NT), 0, s, workspace, nseg * strips_x, B, grad_partials,
-                       loss_state);
+    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(NT), 0, s, workspace, nseg * strips_x, B, pose,
+                       grad_partials, grad_unit, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_finalize");
     return 0;
 }
@@ -950,6 +1040,18 @@ extern "C" int colvo_warp_loss_fused_bwd(const float* loss_state, const float* g
     hipLaunchKernelGGL(k_warp_loss_fused_bwd, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, loss_state, grad_loss, d_depth_raw,
                        grad_partials, pose, B, n, d_depth, d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd");
+    return 0;
+}
+
+extern "C" int colvo_warp_loss_fused_bwd_params(const float* loss_state, const float* grad_loss, const float* grad_partials,
+                                                const float* pose, int B, float* d_pose, float* d_a, float* d_b,
+                                                colvo_stream_t stream) {
+    COLVO_CHECK_ARG(loss_state && grad_loss && grad_partials && pose && d_pose && d_a && d_b,
+                    "colvo_warp_loss_fused_bwd_params: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65534, "colvo_warp_loss_fused_bwd_params: bad batch %d", B);
+    hipLaunchKernelGGL(k_warp_loss_fused_bwd_params, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, loss_state, grad_loss,
+                       grad_partials, pose, B, d_pose, d_a, d_b);
+    COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd_params");
     return 0;
 }
 

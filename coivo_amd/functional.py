@@ -44,6 +44,41 @@ def _timed(kind, call):
     return r
 
 
+class GradHandover:
+    """Mailbox between photometric_loss and the producer of one of its arguments (DepthNet.forward_pair_split for `depth`,
+    PoseNet.forward for `pose` / `lcc_a` / `lcc_b`).
+
+    The fused loss kernel yields its gradients UNNORMALISED: 1 / max(3 n_valid, 1) is only known once every strip of every
+    image has reported, and dL/dloss only at backward time.  Applying them costs a pass over d_depth (84 MB at BASELINE
+    configs[2]) and a launch for the pose / LCC gradients -- unless the consumer of those gradients multiplies while it
+    reads them anyway.  A tensor that carries a GradHandover (attribute `_colvo_handover`) promises exactly that:
+    photometric_loss's backward then returns the unnormalised gradient and posts the two device scalars here; the backward
+    node that owns the mailbox picks them up (colvo_depth_head_bwd_parts / colvo_pose_head_bwd).  Such a tensor must reach
+    photometric_loss directly and be used for nothing else (take() refuses a gradient that was summed with others)."""
+
+    def __init__(self):
+        self.scale_a = self.scale_b = None
+        self.raw_ptrs = None
+
+    def post(self, raws, scale_a: torch.Tensor, scale_b: torch.Tensor) -> None:
+        self.raw_ptrs, self.scale_a, self.scale_b = tuple(r.data_ptr() for r in raws), scale_a, scale_b
+
+    def take(self, grads):
+        """-> (scale_a, scale_b) for the incoming gradients `grads` (tuple, in post order); (None, None) when nothing was
+        posted, i.e. the gradients are ordinary ones."""
+        if self.raw_ptrs is None:
+            return None, None
+        ok = len(grads) == len(self.raw_ptrs) and all(g is not None and g.data_ptr() == p for g, p in zip(grads, self.raw_ptrs))
+        if not ok:
+            raise RuntimeError("a tensor reserved for photometric_loss (DepthNet.forward_pair_split's third output, or "
+                               "PoseNet's outputs) was also used elsewhere: its gradient arrived summed with others, which "
+                               "the deferred normalisation cannot undo; route other uses through an ordinary tensor "
+                               "(e.g. `pose * 1`) so that the loss takes its general path")
+        a, b = self.scale_a, self.scale_b
+        self.raw_ptrs = self.scale_a = self.scale_b = None
+        return a, b
+
+
 def _chk(t: torch.Tensor, name: str, shape) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError(f"{name}: coivo_amd ops run on the GPU only (got a {t.device} tensor); "
@@ -57,7 +92,7 @@ def _chk(t: torch.Tensor, name: str, shape) -> torch.Tensor:
 
 class _WarpLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight):
+    def forward(ctx, tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight, handover, pose_handover):
         lib = _lib.load()
         B, C, H, W = tgt.shape
         if C != 3:
@@ -74,21 +109,26 @@ class _WarpLoss(torch.autograd.Function):
         state = torch.empty(4, device=tgt.device, dtype=torch.float32)
         ctx.ssim_weight = float(ssim_weight)
         ctx.fused = FUSE_TRAINING_PASS and any(ctx.needs_input_grad[2:7])
+        ctx.handover = handover if (ctx.fused and ctx.needs_input_grad[2]) else None
+        # the pose / LCC hand-over rides on the depth one (otherwise the general scaling kernel runs anyway)
+        ctx.pose_handover = pose_handover if (ctx.handover is not None and all(ctx.needs_input_grad[i] for i in (3, 5, 6))) else None
         if ctx.fused:
             d_raw = torch.empty_like(depth)
             gpart = torch.empty(B * 14, device=tgt.device, dtype=torch.float32)
+            gunit = torch.empty(B * 8, device=tgt.device, dtype=torch.float32) if ctx.pose_handover is not None else None
             _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fused(
                 _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
-                B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw), _lib.ptr(gpart),
+                B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw), _lib.ptr(gpart), _lib.ptr(gunit),
                 _lib.stream_ptr())), "colvo_warp_loss_fused")
+            ctx.gunit = gunit
             ctx.save_for_backward(pose, state, d_raw, gpart)
             ctx.shape = (B, H, W)
-            return state[0].clone()
+            return state[0]
         _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fwd(
             _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
             B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr())), "colvo_warp_loss_fwd")
         ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
-        return state[0].clone()
+        return state[0]
 
     @staticmethod
     def backward(ctx, grad_loss):
@@ -97,14 +137,30 @@ class _WarpLoss(torch.autograd.Function):
         if ctx.fused:
             pose, state, d_raw, gpart = ctx.saved_tensors
             B, H, W = ctx.shape
-            d_depth = torch.empty_like(d_raw)
+            if ctx.pose_handover is not None:
+                # everything is handed over unnormalised: this backward launches nothing
+                gu = ctx.gunit
+                d_pose, d_a, d_b = gu[:6 * B].view(B, 6), gu[6 * B:7 * B].view(B, 1), gu[7 * B:].view(B, 1)
+                ctx.handover.post((d_raw,), g, state[1:2])
+                ctx.pose_handover.post((d_pose, d_a, d_b), g, state[1:2])
+                if _timing is not None:
+                    _timed("bwd", lambda: 0)
+                return None, None, d_raw, d_pose, None, d_a, d_b, None, None, None
             d_pose = torch.empty_like(pose)
             d_a = torch.empty(B, 1, device=pose.device, dtype=torch.float32)
             d_b = torch.empty(B, 1, device=pose.device, dtype=torch.float32)
+            if ctx.handover is not None:
+                # deferred normalisation: the consumer of d_depth (DepthNet's head backward) applies dL/dloss / max(3n, 1)
+                _lib.check(_timed("bwd", lambda: lib.colvo_warp_loss_fused_bwd_params(
+                    _lib.ptr(state), _lib.ptr(g), _lib.ptr(gpart), _lib.ptr(pose), B, _lib.ptr(d_pose), _lib.ptr(d_a),
+                    _lib.ptr(d_b), _lib.stream_ptr())), "colvo_warp_loss_fused_bwd_params")
+                ctx.handover.post((d_raw,), g, state[1:2])
+                return None, None, d_raw, d_pose, None, d_a, d_b, None, None, None
+            d_depth = torch.empty_like(d_raw)
             _lib.check(_timed("bwd", lambda: lib.colvo_warp_loss_fused_bwd(
                 _lib.ptr(state), _lib.ptr(g), _lib.ptr(d_raw), _lib.ptr(gpart), _lib.ptr(pose), B, H, W, _lib.ptr(d_depth),
                 _lib.ptr(d_pose), _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr())), "colvo_warp_loss_fused_bwd")
-            return None, None, d_depth, d_pose, None, d_a, d_b, None
+            return None, None, d_depth, d_pose, None, d_a, d_b, None, None, None
         tgt, ref, depth, pose, K, lcc_a, lcc_b, state = ctx.saved_tensors
         B, _, H, W = tgt.shape
         nws = lib.colvo_warp_loss_workspace_floats(B, H, W)
@@ -117,12 +173,18 @@ class _WarpLoss(torch.autograd.Function):
             _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
             B, H, W, ctx.ssim_weight, _lib.ptr(state), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(d_depth), _lib.ptr(d_pose),
             _lib.ptr(d_a), _lib.ptr(d_b), _lib.stream_ptr())), "colvo_warp_loss_bwd")
-        return None, None, d_depth, d_pose, None, d_a, d_b, None
+        return None, None, d_depth, d_pose, None, d_a, d_b, None, None, None
 
 
 def photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
-    """Masked mean of alpha*(1-SSIM)/2 + (1-alpha)*|I_t - (a*warp(I_r)+b)| -> scalar (spec: photometric_loss)."""
-    return _WarpLoss.apply(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight)
+    """Masked mean of alpha*(1-SSIM)/2 + (1-alpha)*|I_t - (a*warp(I_r)+b)| -> scalar (spec: photometric_loss).
+
+    When `depth` is the tensor DepthNet.forward_pair_split reserves for this loss (it carries a GradHandover), the
+    normalisation of its gradient is left to DepthNet's head backward instead of a separate pass over d_depth."""
+    hp = getattr(pose, "_colvo_handover", None)
+    if hp is not None and not (getattr(lcc_a, "_colvo_handover", None) is hp and getattr(lcc_b, "_colvo_handover", None) is hp):
+        hp = None                      # pose, lcc_a and lcc_b must come from ONE PoseNet call
+    return _WarpLoss.apply(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight, getattr(depth, "_colvo_handover", None), hp)
 
 
 def inverse_warp(ref, depth, pose, K):

@@ -30,6 +30,7 @@ class GraphedTrainStep:
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
         self.loss = torch.zeros((), device=dev)
+        self._one = torch.ones((), device=dev)      # dL/dloss: a persistent scalar instead of a ones_like() fill per step
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._warmup = warmup
 
@@ -37,11 +38,11 @@ class GraphedTrainStep:
     def _step(self) -> torch.Tensor:
         B = self.B
         self.opt.zero_grad()
-        d_t, d_r = self.depth_net.forward_pair(self.frames)
+        d_t, d_r, d_l = self.depth_net.forward_pair_split(self.frames)
         tgt, ref = self.frames[:B], self.frames[B:]
         pose, a, b = self.pose_net(tgt, ref, d_t, d_r)
-        loss = photometric_loss(tgt, ref, d_t, pose, self.K, a, b, ssim_weight=self.ssim_weight)
-        loss.backward()
+        loss = photometric_loss(tgt, ref, d_l, pose, self.K, a, b, ssim_weight=self.ssim_weight)
+        loss.backward(gradient=self._one)
         if self.ddp is not None:
             self.ddp.finish()
         self.opt.step()
@@ -85,4 +86,7 @@ class GraphedTrainStep:
         if K is not None:
             self.K.copy_(K, non_blocking=True)
         self.graph.replay()
+        # the captured Adam step rewrote the master weights: an eager forward afterwards must re-pack its operand copies
+        self.depth_net.mark_params_changed()
+        self.pose_net.mark_params_changed()
         return self.loss

@@ -130,14 +130,14 @@ class _ArenaModule(nn.Module):
         """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
         layers = self._layers()
         if any(L.weight.grad is None or L.bias.grad is None for L in layers):
-            self.flat_grad.zero_()
+            ops.zero_(self.flat_grad)
             for L in layers:
                 L.weight.grad = L._gw_view
                 L.bias.grad = L.g_bias
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # arena semantics: grads stay attached
         if self.flat_grad is not None:
-            self.flat_grad.zero_()
+            ops.zero_(self.flat_grad)          # one hipMemsetAsync, no torch fill kernel
             self.attach_grads()
 
     def mark_params_changed(self) -> None:
@@ -372,7 +372,21 @@ class DepthNet(_ArenaModule):
         small launches on the critical path between the PoseNet and the DepthNet backward)."""
         if frames.dim() != 4 or frames.shape[0] % 2:
             raise ValueError("forward_pair: expected [2B,3,H,W]")
-        return _DepthNetPairFn.apply(self, frames, self._trigger())
+        return _DepthNetPairFn.apply(self, frames, self._trigger(), None)[:2]
+
+    def forward_pair_split(self, frames: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """forward_pair with a third output: the target-frame depth AGAIN, as the tensor to hand to photometric_loss (and
+        to nothing else).  It aliases depth_t, but being an output of its own the backward node receives the loss
+        gradient separately from PoseNet's: no autograd add, no concatenation, and -- through the GradHandover it carries --
+        no normalisation pass: the fused loss returns its unnormalised depth gradient plus two device scalars and the
+        head backward applies them while it reads the gradient (functional.GradHandover)."""
+        if frames.dim() != 4 or frames.shape[0] % 2:
+            raise ValueError("forward_pair_split: expected [2B,3,H,W]")
+        from .functional import GradHandover
+        hand = GradHandover()
+        d_t, d_r, d_l = _DepthNetPairFn.apply(self, frames, self._trigger(), hand)
+        d_l._colvo_handover = hand
+        return d_t, d_r, d_l
 
     # ---- whole-network forward / backward ---------------------------------------------------- #
     def _plan(self, B, H, W):
@@ -427,12 +441,23 @@ class DepthNet(_ArenaModule):
         A = self._run_pass(inst, "fwd", {"img": img, "depth": depth}, body)
         return depth, (A, P, inst)
 
-    def _backward_impl(self, saved, depth: torch.Tensor, d_depth: torch.Tensor) -> None:
+    def _backward_impl(self, saved, depth: torch.Tensor, d_depth: Optional[torch.Tensor], parts=None) -> None:
+        """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b): the gradient of the first / second
+        half of the images and an unnormalised addend for the first half (ops.depth_head_bwd_parts), each may be None."""
         A, P, inst = saved
         self.attach_grads()
         B, _, H, W = depth.shape
         dev = depth.device
-        d_depth = d_depth.contiguous()
+        if parts is None:
+            d_depth = d_depth.contiguous()
+            ext = {"depth": depth, "d_depth": d_depth}
+            which = "bwd"
+        else:
+            parts = tuple(None if t is None else t.contiguous() for t in parts)
+            names = ("g_first", "g_second", "g_raw", "scale_a", "scale_b")
+            ext = {"depth": depth}
+            ext.update({n: t for n, t in zip(names, parts) if t is not None})
+            which = "bwd:" + ",".join(n for n, t in zip(names, parts) if t is not None)
 
         def body():
             self._bwd_begin()
@@ -452,7 +477,10 @@ class DepthNet(_ArenaModule):
             g = torch.empty_like(x1)
             scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
             # head: d(pre) + input gradient on the main stream, its weight gradient beside it like every other layer's
-            ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
+            if parts is None:
+                ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
+            else:
+                ops.depth_head_bwd_parts(x1, self.head.w_master, depth, *parts, scratch, g)
             self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias),
                             x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
@@ -476,7 +504,7 @@ class DepthNet(_ArenaModule):
                     g = dgrad(f"enc{i}a", 0, g_a, src, dx=d_skip[i - 1], accumulate=True)
             self._bwd_end()
 
-        self._run_pass(inst, "bwd", {"depth": depth, "d_depth": d_depth}, body)
+        self._run_pass(inst, which, ext, body)
 
 
 class _DepthNetFn(torch.autograd.Function):
@@ -498,27 +526,29 @@ class _DepthNetFn(torch.autograd.Function):
 
 
 class _DepthNetPairFn(torch.autograd.Function):
+    """depth of [target frames | reference frames] as THREE outputs of one node: depth_t, depth_r and depth_t once more
+    for the loss (forward_pair_split).  The backward receives the three gradients separately and hands them to the head's
+    backward kernel as they are (no zero-fill, cat or add kernels in between)."""
+
     @staticmethod
-    def forward(ctx, net: DepthNet, frames, trigger):
+    def forward(ctx, net: DepthNet, frames, trigger, handover):
         depth, saved = net._forward_impl(frames)
-        ctx.net, ctx.saved = net, saved
+        ctx.net, ctx.saved, ctx.handover = net, saved, handover
         ctx.lease = _Lease(saved[2])
         ctx.save_for_backward(depth)
         B = frames.shape[0] // 2
-        return depth[:B], depth[B:]
+        return depth[:B], depth[B:], depth[:B]
 
     @staticmethod
-    def backward(ctx, g_t, g_r):
+    def backward(ctx, g_t, g_r, g_l):
         (depth,) = ctx.saved_tensors
-        B = depth.shape[0] // 2
-        if g_t is None:
-            g_t = torch.zeros_like(depth[:B])
-        if g_r is None:
-            g_r = torch.zeros_like(depth[B:])
-        ctx.net._backward_impl(ctx.saved, depth, torch.cat([g_t, g_r], dim=0))
+        sa = sb = None
+        if ctx.handover is not None:
+            sa, sb = ctx.handover.take((g_l,))     # unnormalised loss gradient + its two device scale factors
+        ctx.net._backward_impl(ctx.saved, depth, None, parts=(g_t, g_r, g_l, sa, sb))
         ctx.saved = None
         ctx.lease.release()
-        return None, None, None
+        return None, None, None, None
 
 
 class PoseNet(_ArenaModule):
@@ -536,7 +566,13 @@ class PoseNet(_ArenaModule):
         self._build_arena(torch.device(device))
 
     def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):
-        return _PoseNetFn.apply(self, tgt, ref, tgt_depth, ref_depth, self._trigger())
+        from .functional import GradHandover
+        hand = GradHandover()
+        pose, a, b = _PoseNetFn.apply(self, tgt, ref, tgt_depth, ref_depth, self._trigger(), hand)
+        # handed DIRECTLY to photometric_loss, the three outputs get their gradients unnormalised plus two device scalars
+        # which the head's backward kernel applies (functional.GradHandover); any other use takes the ordinary path
+        pose._colvo_handover = a._colvo_handover = b._colvo_handover = hand
+        return pose, a, b
 
     def _forward_impl(self, tgt, ref, d_t, d_r):
         B, _, H, W = tgt.shape
@@ -577,11 +613,11 @@ class PoseNet(_ArenaModule):
         A = self._run_pass(inst, "fwd", ext, body)
         return out, (A, P, (B, H, W), has_depth, inst)
 
-    def _backward_impl(self, saved, d_pose, d_a, d_b):
+    def _backward_impl(self, saved, d_pose, d_a, d_b, scale_a=None, scale_b=None):
         A, P, (B, H, W), has_depth, inst = saved
         self.attach_grads()
         dev = self.flat_param.device
-        grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b}
+        grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}
         grads = {k: v.contiguous() for k, v in grads.items() if v is not None}
         d_t = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
         d_r = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
@@ -591,7 +627,7 @@ class PoseNet(_ArenaModule):
             x = A[7]
             g = torch.empty_like(x)
             ops.pose_head_bwd(x, self.pred.w_master, grads.get("d_pose"), grads.get("d_a"), grads.get("d_b"),
-                              g, self.pred.g_master, self.pred.g_bias)
+                              g, self.pred.g_master, self.pred.g_bias, grads.get("scale_a"), grads.get("scale_b"))
             self._layer_done(self.pred)
             for i in range(7, 0, -1):
                 L = getattr(self, f"conv{i}")
@@ -617,9 +653,9 @@ class PoseNet(_ArenaModule):
 
 class _PoseNetFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net: PoseNet, tgt, ref, d_t, d_r, trigger):
+    def forward(ctx, net: PoseNet, tgt, ref, d_t, d_r, trigger, handover):
         out, saved = net._forward_impl(tgt, ref, d_t, d_r)
-        ctx.net, ctx.saved = net, saved
+        ctx.net, ctx.saved, ctx.handover = net, saved, handover
         ctx.lease = _Lease(saved[4])
         B = tgt.shape[0]
         # three contiguous views of the planar head output: no slicing kernels forward or backward
@@ -627,17 +663,17 @@ class _PoseNetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_pose, d_a, d_b):
-        d_t, d_r = ctx.net._backward_impl(ctx.saved, d_pose, d_a, d_b)
+        sa, sb = ctx.handover.take((d_pose, d_a, d_b)) if ctx.handover is not None else (None, None)
+        d_t, d_r = ctx.net._backward_impl(ctx.saved, d_pose, d_a, d_b, sa, sb)
         ctx.saved = None
         ctx.lease.release()
-        return None, None, None, d_t, d_r, None
+        return None, None, None, d_t, d_r, None, None
 
 
 def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85):
     """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss."""
     from .functional import photometric_loss
-    B = tgt.shape[0]
-    d_t, d_r = depth_net.forward_pair(torch.cat([tgt, ref], dim=0))
+    d_t, d_r, d_l = depth_net.forward_pair_split(torch.cat([tgt, ref], dim=0))
     pose, a, b = pose_net(tgt, ref, d_t, d_r)
-    loss = photometric_loss(tgt, ref, d_t, pose, K, a, b, ssim_weight=ssim_weight)
+    loss = photometric_loss(tgt, ref, d_l, pose, K, a, b, ssim_weight=ssim_weight)     # d_l aliases d_t (its own grad path)
     return loss, d_t, d_r, pose, a, b

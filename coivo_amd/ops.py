@@ -157,6 +157,31 @@ def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
                                         _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_bwd")
 
 
+def depth_head_bwd_parts(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx) -> None:
+    """depth_head_bwd with the incoming gradient in parts (DCDP step, depth of 2*Bh images): first half
+    g_first + scale_a[0]*scale_b[0]*g_raw, second half g_second; any part may be None.  Weight gradient: depth_head_wgrad."""
+    _need_cuda(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx)
+    B, H, W, Cc = x.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_DEPTH_HEAD_BWD_PARTS, None, (x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx),
+                       (dt_code(x.dtype), B, H, W, Cc), (MIN_DEPTH, MAX_DEPTH))
+    lib = _lib.load()
+    _lib.check(lib.colvo_depth_head_bwd_parts(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(depth), _lib.ptr(g_first),
+                                              _lib.ptr(g_second), _lib.ptr(g_raw), _lib.ptr(scale_a), _lib.ptr(scale_b),
+                                              B, H, W, Cc, MIN_DEPTH, MAX_DEPTH, _lib.ptr(scratch), _lib.ptr(dx), 0, 0,
+                                              _lib.stream_ptr()), "colvo_depth_head_bwd_parts")
+
+
+def zero_(t: torch.Tensor) -> None:
+    """Zero a contiguous device tensor with one hipMemsetAsync on the current stream."""
+    _need_cuda(t)
+    if not t.is_contiguous():
+        raise ValueError("zero_: tensor must be contiguous")
+    lib = _lib.load()
+    _lib.check(lib.colvo_zero(_lib.ptr(t), t.numel() * t.element_size(), _lib.stream_ptr()), "colvo_zero")
+
+
 def depth_head_wgrad(x, dpre, dw, db) -> None:
     """Weight / bias gradient of the depth head from the d(pre) plane depth_head_bwd(dw=None, db=None) left in scratch."""
     _need_cuda(x, dpre, dw, db)
@@ -182,18 +207,20 @@ def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: tor
                                        POSE_SCALE, LCC_SCALE, _lib.ptr(out), _lib.stream_ptr()), "colvo_pose_head_fwd")
 
 
-def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db) -> None:
-    """d_pose [B,6] / d_a [B,1] / d_b [B,1] contiguous or None (= zero)."""
-    _need_cuda(x, w, d_pose, d_a, d_b, dx, dw, db)
+def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a=None, scale_b=None) -> None:
+    """d_pose [B,6] / d_a [B,1] / d_b [B,1] contiguous or None (= zero); scale_a, scale_b: device scalars multiplied into
+    all three (None = 1)."""
+    _need_cuda(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a, scale_b)
     B, H, W, Cc = x.shape
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_POSE_HEAD_BWD, None, (x, w, d_pose, d_a, d_b, dx, dw, db),
+        return rec.add(_lib.CMD_POSE_HEAD_BWD, None, (x, w, d_pose, d_a, d_b, dx, dw, db, scale_a, scale_b),
                        (dt_code(x.dtype), B, H * W, Cc), (POSE_SCALE, LCC_SCALE))
     lib = _lib.load()
     _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_pose), _lib.ptr(d_a),
-                                       _lib.ptr(d_b), B, H * W, Cc, POSE_SCALE, LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw),
-                                       _lib.ptr(db), _lib.stream_ptr()), "colvo_pose_head_bwd")
+                                       _lib.ptr(d_b), _lib.ptr(scale_a), _lib.ptr(scale_b), B, H * W, Cc, POSE_SCALE,
+                                       LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.stream_ptr()),
+               "colvo_pose_head_bwd")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:

@@ -88,7 +88,7 @@ class Program:
             raise RuntimeError("two externals of a Program share one address")
         self._slots = {name: [] for name in self._ext}
         for ci in range(n):
-            for k in range(8):
+            for k in range(_lib.NPTR):
                 name = by_ptr.get(self._arr[ci].p[k])
                 if name is not None:
                     self._slots[name].append((ci, k))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 2
+#define COLVO_ABI_VERSION 3
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -65,15 +65,23 @@ int colvo_warp_loss_bwd(const float* tgt, const float* ref, const float* depth, 
 
 /* Training path: the loss and its UNNORMALISED gradients in one pass (the backward kernel evaluates everything the
  * forward does).  loss_state as in colvo_warp_loss_fwd; d_depth_raw [B,1,H,W] and grad_partials [B*14] are handed to
- * colvo_warp_loss_fused_bwd, which applies dL/dloss / max(3 n_valid, 1) and writes the four gradients. */
+ * colvo_warp_loss_fused_bwd, which applies dL/dloss / max(3 n_valid, 1) and writes the four gradients.
+ * grad_unit (8*B floats, may be NULL) receives the unnormalised pose / LCC gradients in PoseNet's planar output layout
+ * [d_pose B x 6 | d_a B | d_b B] for a consumer that applies the two scale factors itself (colvo_pose_head_bwd). */
 int colvo_warp_loss_fused(const float* tgt, const float* ref, const float* depth, const float* pose,
                           const float* K, const float* lcc_a, const float* lcc_b,
                           int B, int H, int W, float ssim_weight,
                           float* workspace, float* loss_state, float* d_depth_raw, float* grad_partials,
-                          colvo_stream_t stream);
+                          float* grad_unit, colvo_stream_t stream);
 int colvo_warp_loss_fused_bwd(const float* loss_state, const float* grad_loss, const float* d_depth_raw,
                               const float* grad_partials, const float* pose, int B, int H, int W,
                               float* d_depth, float* d_pose, float* d_a, float* d_b, colvo_stream_t stream);
+/* The same without the pass over d_depth: only d_pose [B,6], d_a [B], d_b [B].  For callers that hand d_depth_raw and
+ * the two scale factors (grad_loss[0], loss_state[1]) to the consumer of the depth gradient instead
+ * (colvo_depth_head_bwd_parts): the normalisation is then applied where d_depth is read anyway. */
+int colvo_warp_loss_fused_bwd_params(const float* loss_state, const float* grad_loss, const float* grad_partials,
+                                     const float* pose, int B, float* d_pose, float* d_a, float* d_b,
+                                     colvo_stream_t stream);
 
 /* Un-fused debugging entry (spec: inverse_warp()).  ref [B,C,H,W] -> warped [B,C,H,W], valid [B,1,H,W]. */
 int colvo_inverse_warp(const float* ref, const float* depth, const float* pose, const float* K,
@@ -154,15 +162,25 @@ int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* 
                          void* dx, float* dw, float* db, colvo_stream_t stream);
 int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C,
                            float* dw, float* db, colvo_stream_t stream);
+/* colvo_depth_head_bwd with the incoming gradient given in parts (the DCDP step: DepthNet ran on B = 2*Bh images, target
+ * frames first): d_depth[b] = g_first[b] + scale_a[0]*scale_b[0]*g_raw[b] for b < Bh, g_second[b-Bh] for b >= Bh.
+ * g_first, g_second, g_raw: [Bh,1,H,W] each, any of them may be NULL (= zero); scale_a, scale_b: device scalars, NULL = 1
+ * (the fused loss hands over d_depth_raw with grad_loss and loss_state + 1).  No concatenated / summed copy is made. */
+int colvo_depth_head_bwd_parts(int dtype, const void* x, const float* w, const float* depth, const float* g_first,
+                               const float* g_second, const float* g_raw, const float* scale_a, const float* scale_b,
+                               int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
+                               void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.
  * out (8*B floats) is PLANAR: [ pose B x 6 | lcc_a B | lcc_b B ] so the three results are contiguous views;
  * backward takes the three gradients separately (each may be NULL = zero). */
 int colvo_pose_head_fwd(int dtype, const void* x, const float* w, const float* bias, int B, int HW, int C,
                         float pose_scale, float lcc_scale, float* out, colvo_stream_t stream);
+/* scale_a, scale_b: device scalars multiplied into the three incoming gradients (NULL = 1): the fused loss hands its
+ * gradients over unnormalised together with dL/dloss and 1/max(3 n_valid, 1). */
 int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a,
-                        const float* d_b, int B, int HW, int C, float pose_scale, float lcc_scale,
-                        void* dx, float* dw, float* db, colvo_stream_t stream);
+                        const float* d_b, const float* scale_a, const float* scale_b, int B, int HW, int C,
+                        float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * a8  Adam over the flat parameter arena (torch.optim.Adam semantics, no weight decay)         *
@@ -172,6 +190,8 @@ int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d
 int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     int32_t* step_count, colvo_stream_t stream);
+/* Zero `bytes` bytes of device memory on `stream` (the gradient arenas, once per step). */
+int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * Command lists: ONE call enqueues a recorded sequence of the entry points above (a network's  *
@@ -188,16 +208,17 @@ enum {
     COLVO_CMD_DEPTH_HEAD_BWD,    /* i: dtype B H W C; f: min max; p: x w depth d_depth scratch dx dw db */
     COLVO_CMD_DEPTH_HEAD_WGRAD,  /* i: dtype B H W C; p: x dpre dw db */
     COLVO_CMD_POSE_HEAD_FWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w bias out */
-    COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db */
+    COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db scale_a scale_b */
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
-    COLVO_CMD_JOIN               /* main stream waits for the side stream's work so far */
+    COLVO_CMD_JOIN,              /* main stream waits for the side stream's work so far */
+    COLVO_CMD_DEPTH_HEAD_BWD_PARTS /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx */
 };
 
 typedef struct ColvoCmd {
     int32_t op;                  /* COLVO_CMD_* */
     int32_t stream;              /* 0 = main, 1 = side */
     ColvoConvDesc desc;          /* conv commands */
-    const void* p[8];            /* pointer arguments in the order listed above (device memory, caller-owned) */
+    const void* p[12];           /* pointer arguments in the order listed above (device memory, caller-owned) */
     int32_t i[12];               /* integer arguments in the order listed above */
     float f[4];
 } ColvoCmd;

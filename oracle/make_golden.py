@@ -41,20 +41,44 @@ def loss_case(name, B, H, W, seed, jitter=True):
     print(name, "loss", loss.item(), "valid", valid.mean().item())
 
 
+GRAD_SAMPLE = 4096
+
+
+def grad_digest(g: torch.Tensor):
+    """What the fixtures keep of one parameter gradient: a fixed strided sample of <= GRAD_SAMPLE elements (the whole
+    tensor when it is that small) and [sum, L2 norm, max |.|] over ALL elements in float64."""
+    f = g.detach().flatten()
+    stride = max(1, -(-f.numel() // GRAD_SAMPLE))
+    d = f.double()
+    return f[::stride][:GRAD_SAMPLE].clone(), torch.stack([d.sum(), d.norm(), d.abs().max()])
+
+
 def net_case(name, B, H, W, seed):
-    """Seeds + expected network outputs (weights are regenerated from the seed, not stored)."""
+    """Seeds + expected network outputs (weights are regenerated from the seed, not stored) + a digest of EVERY
+    parameter gradient of the coupled step, from the fp32 oracle (gs32_<net>.<param>: strided sample) and from the same
+    step evaluated in fp64 (gs64_: sample, gn64_: sum / norm / max) -- the fp64 values are the yardstick the GPU test
+    measures both the HIP path and the fp32 oracle against (SPEC.md §7)."""
     b = synth.make_batch(B, H, W, seed=seed)
     dn, pn = S.make_models(seed=seed)
     loss, d_t, d_r, pose, a, bb = S.dcdp_forward(dn, pn, b["tgt"], b["ref"], b["K"])
     loss.backward()
+    dn64, pn64 = S.make_models(seed=seed, dtype=torch.float64)
+    loss64 = S.dcdp_forward(dn64, pn64, b["tgt"].double(), b["ref"].double(), b["K"].double())[0]
+    loss64.backward()
+    digests = {}
+    for tag, net, net64 in (("depth", dn, dn64), ("pose", pn, pn64)):
+        for (pname, p), (_, p64) in zip(net.named_parameters(), net64.named_parameters()):
+            digests[f"gs32_{tag}.{pname}"] = grad_digest(p.grad)[0].numpy()
+            smp, nrm = grad_digest(p64.grad)
+            digests[f"gs64_{tag}.{pname}"] = smp.numpy()
+            digests[f"gn64_{tag}.{pname}"] = nrm.numpy()
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         B=B, H=H, W=W, seed=seed,
-        loss=np.float32(loss.item()), depth_t=d_t.detach().numpy(), depth_r=d_r.detach().numpy(),
-        pose=pose.detach().numpy(), lcc_a=a.detach().numpy(), lcc_b=bb.detach().numpy(),
-        g_head_w=dn.head.weight.grad.numpy(), g_enc1a_w=dn.enc1a.weight.grad.numpy(),
-        g_pred_w=pn.pred.weight.grad.numpy(), g_conv1_b=pn.conv1.bias.grad.numpy())
-    print(name, "loss", loss.item())
+        loss=np.float32(loss.item()), loss64=np.float64(loss64.item()), depth_t=d_t.detach().numpy(),
+        depth_r=d_r.detach().numpy(), pose=pose.detach().numpy(), lcc_a=a.detach().numpy(), lcc_b=bb.detach().numpy(),
+        **digests)
+    print(name, "loss", loss.item(), "fp64", loss64.item(), "gradient digests", len(digests) // 3)
 
 
 if __name__ == "__main__":

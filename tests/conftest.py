@@ -21,8 +21,8 @@ def golden_dir():
 
 @pytest.fixture(scope="session", autouse=True)
 def _ensure_library_built():
-    """The in-tree libcolvo.so travels with the tree, but a fresh checkout has none: build it (hipcc cross-compiles
-    without a GPU, seconds when objects are cached)."""
-    from coivo_amd import _lib, build
-    if not os.path.exists(_lib.LIB_PATH):
-        build.build()
+    """The in-tree libcolvo.so travels with the tree, but a fresh checkout has none and an edited kernel must not run
+    against a stale binary: (re)build unless the library's recorded source hash matches the tree (hipcc cross-compiles
+    without a GPU)."""
+    from coivo_amd import build
+    build.ensure()

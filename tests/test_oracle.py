@@ -169,10 +169,18 @@ def test_golden_net(golden_dir, name):
     assert np.abs(d_r.detach().numpy() - g["depth_r"]).max() < 1e-5
     assert np.abs(pose.detach().numpy() - g["pose"]).max() < 1e-6
     loss.backward()
-    for got, k in ((dn.head.weight.grad, "g_head_w"), (dn.enc1a.weight.grad, "g_enc1a_w"),
-                   (pn.pred.weight.grad, "g_pred_w"), (pn.conv1.bias.grad, "g_conv1_b")):
-        ref = torch.from_numpy(g[k])
-        assert torch.allclose(got, ref, rtol=1e-3, atol=1e-5 * max(1.0, ref.abs().max().item())), k
+    # every parameter gradient against the fixture's digest (pins the oracle against drift; multi-threaded reductions
+    # move the last bits, hence the small tolerance)
+    from oracle.make_golden import grad_digest
+    n = 0
+    for tag, net in (("depth", dn), ("pose", pn)):
+        for pname, p in net.named_parameters():
+            smp, _ = grad_digest(p.grad)
+            ref = torch.from_numpy(g[f"gs32_{tag}.{pname}"])
+            scale = float(g[f"gn64_{tag}.{pname}"][2])
+            assert (smp - ref).abs().max().item() <= 2e-4 * scale + 1e-12, (tag, pname)
+            n += 1
+    assert n == 58
 
 
 def test_synth_is_deterministic_and_in_range():

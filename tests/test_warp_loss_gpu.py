@@ -182,3 +182,28 @@ def test_rejects_cpu_tensors_and_bad_shapes():
     d = to_dev(t)
     with pytest.raises(ValueError):
         Fh.photometric_loss(d["tgt"], d["ref"], d["depth"][:, :, :8], d["pose"], d["K"], d["lcc_a"], d["lcc_b"])
+
+
+def test_deferred_normalisation_handover():
+    """The training form (DepthNet.forward_pair_split): photometric_loss returns the depth gradient UNNORMALISED and posts
+    dL/dloss and 1/max(3 n_valid, 1) as device scalars; raw * scales must be the oracle's gradient, pose / LCC gradients
+    arrive normalised, and a gradient that does not come straight from the loss is refused."""
+    from coivo_amd import functional as Fh
+    t = to_dev(_case(2, 96, 128, 121, 1.0))
+    ol, og = _oracle_loss_and_grads({k: v.cpu() for k, v in t.items()})
+    leaves = [t[k].clone().requires_grad_(True) for k in ("depth", "pose", "lcc_a", "lcc_b")]
+    hand = Fh.GradHandover()
+    leaves[0]._colvo_handover = hand
+    loss = Fh.photometric_loss(t["tgt"], t["ref"], leaves[0], leaves[1], t["K"], leaves[2], leaves[3])
+    up = torch.full((), 2.5, device=loss.device)
+    graw, gp, ga, gb = torch.autograd.grad(loss, leaves, grad_outputs=up)
+    sa, sb = hand.take((graw,))
+    assert sa is not None and sb is not None and hand.take((None,)) == (None, None)
+    assert abs(sa.item() - 2.5) < 1e-7
+    d_depth = graw * (sa * sb)
+    _compare(loss, (d_depth / 2.5, gp / 2.5, ga / 2.5, gb / 2.5), ol, og, "deferred")
+    # the mailbox refuses a gradient that is not the tensor the loss handed over
+    loss = Fh.photometric_loss(t["tgt"], t["ref"], leaves[0], leaves[1], t["K"], leaves[2], leaves[3])
+    graw = torch.autograd.grad(loss, leaves)[0]
+    with pytest.raises(RuntimeError):
+        hand.take((graw + 0.0,))

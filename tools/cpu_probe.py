@@ -23,10 +23,10 @@ def main():
 
     def step():
         opt.zero_grad()
-        d_t, d_r = dn.forward_pair(frames)
+        d_t, d_r, d_l = dn.forward_pair_split(frames)
         tgt, ref = frames[:B], frames[B:]
         pose, a, b = pn(tgt, ref, d_t, d_r)
-        loss = Fh.photometric_loss(tgt, ref, d_t, pose, K, a, b)
+        loss = Fh.photometric_loss(tgt, ref, d_l, pose, K, a, b)
         loss.backward()
         opt.step()
 

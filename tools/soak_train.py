@@ -29,9 +29,9 @@ def run(dtype, steps, B=4, H=128, W=160):
     out = []
     for it in range(steps + 1):
         opt.zero_grad()
-        d_t, d_r = dn.forward_pair(frames)
+        d_t, d_r, d_l = dn.forward_pair_split(frames)
         pose, a, bb = pn(frames[:B], frames[B:], d_t, d_r)
-        loss = Fh.photometric_loss(frames[:B], frames[B:], d_t, pose, b["K"], a, bb)
+        loss = Fh.photometric_loss(frames[:B], frames[B:], d_l, pose, b["K"], a, bb)
         loss.backward()
         opt.step()
         if it % 50 == 0:
