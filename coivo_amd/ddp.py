@@ -100,6 +100,10 @@ class GradBuckets:
     def finish(self) -> None:
         """Issue whatever has not been reduced yet and wait (stream-wise) for every bucket."""
         for st in self.states:
+            join = getattr(st.module, "join_side", None)
+            if join is not None:
+                join()                          # weight gradients whose join the network deferred (nn._ArenaModule)
+        for st in self.states:
             while st.next < len(st.bounds):     # layers that reported out of order / never reported
                 self._launch(st, st.bounds[st.next], st.bounds[st.next - 1])
                 st.next += 1

@@ -78,6 +78,12 @@ class _ArenaModule(nn.Module):
         self.use_programs = os.environ.get("COLVO_NO_PROGRAM") is None
         self._rec: Optional[Program] = None
         self.overlap_wgrad = os.environ.get("COLVO_NO_OVERLAP") is None
+        # defer_join: the main stream does not wait for this network's weight gradients at the end of ITS backward node but
+        # at the end of the whole backward pass (an autograd-engine callback), so the nodes that follow are enqueued in
+        # between.  PoseNet's backward sits on the critical path in front of DepthNet's: only its input-gradient chain has
+        # to finish before DepthNet's backward may start; its weight gradients then run beside DepthNet's kernels.
+        self.defer_join = os.environ.get("COLVO_NO_DEFER_JOIN") is None
+        self._join_pending = False
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
 
     # ---- arena ------------------------------------------------------------------------------- #
@@ -136,6 +142,7 @@ class _ArenaModule(nn.Module):
                 L.bias.grad = L.g_bias
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # arena semantics: grads stay attached
+        self.join_side()
         if self.flat_grad is not None:
             ops.zero_(self.flat_grad)          # one hipMemsetAsync, no torch fill kernel
             self.attach_grads()
@@ -254,6 +261,8 @@ class _ArenaModule(nn.Module):
                 if not ok:
                     pr.flush = None
             pr.run(self._side, done, None)
+        if getattr(pr, "deferred_join", False):
+            self._queue_join()
         return out
 
     # ---- backward scheduling: weight gradients on a side stream, concurrent with the input gradients ------ #
@@ -293,10 +302,36 @@ class _ArenaModule(nn.Module):
 
     def _bwd_end(self) -> None:
         if self.overlap_wgrad and self._side_used:
-            if self._rec is not None:
+            if self.defer_join:
+                if self._rec is not None:
+                    self._rec.deferred_join = True
+                self._queue_join()
+            elif self._rec is not None:
                 self._rec.join()
             else:
                 self._main.wait_stream(self._side)
+
+    def _queue_join(self) -> None:
+        """Join the side stream when the running backward pass ends (falls back to joining now outside the engine)."""
+        if self._join_pending:
+            return
+        self._join_pending = True
+        main = torch.cuda.current_stream()
+
+        def _final_join():
+            if self._join_pending and self._side is not None:
+                main.wait_stream(self._side)
+            self._join_pending = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_final_join)
+        except RuntimeError:              # not inside a backward pass (a backward body driven by hand)
+            _final_join()
+
+    def join_side(self) -> None:
+        """Make the current stream wait for the weight gradients still running on this network's side stream."""
+        if self._join_pending and self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._join_pending = False
 
     def _layer_done(self, L: ConvParams) -> None:
         if self._rec is not None:
@@ -561,8 +596,9 @@ class PoseNet(_ArenaModule):
             setattr(self, f"conv{i}", ConvParams(cin, c, 3))
             cin = c
         self.pred = ConvParams(cin, 8, 1)
-        # 7 tiny layers: driven from Python the fork/join bookkeeping costs more than it hides; recorded it is free
-        self.overlap_wgrad = self.overlap_wgrad and self.use_programs and os.environ.get("COLVO_POSE_OVERLAP") is not None
+        # 7 tiny layers: driven from Python the fork/join bookkeeping costs more than it hides; recorded it is free.
+        # With a deferred join (FusedAdam) only the input-gradient chain stays in front of DepthNet's backward.
+        self.overlap_wgrad = self.overlap_wgrad and self.use_programs and os.environ.get("COLVO_NO_POSE_OVERLAP") is None
         self._build_arena(torch.device(device))
 
     def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):

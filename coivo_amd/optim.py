@@ -37,6 +37,7 @@ class FusedAdam:
     @torch.no_grad()
     def step(self) -> None:
         for m, st in zip(self.modules, self.state):
+            m.join_side()
             m.attach_grads()
             ops.adam_step(m.flat_param, m.flat_grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=self.lr,
                           beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
