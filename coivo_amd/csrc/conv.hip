@@ -236,7 +236,7 @@ __device__ __forceinline__ void stage_patch(const Gather& g, int s, int c0, int 
 
 // Epilogue of one output tile from the fp32 staging tile in LDS: bias, ReLU, 2x2 sum-pool, producer's ReLU mask,
 // accumulate, convert, 16-byte coalesced stores.
-template <typename T, int BN>
+template <typename T, int BN, int NTH = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut, int b, int oy0, int ox0, int n0, int tid) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int OUTP = BN + 4;
@@ -244,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut,
     const int Hout = a.pool2 ? (a.Ho >> 1) : a.Ho, Wout = a.pool2 ? (a.Wo >> 1) : a.Wo;
     const int eh = a.pool2 ? (a.toh >> 1) : a.toh, ew = a.pool2 ? (a.tow >> 1) : a.tow;
     const int ey0 = a.pool2 ? (oy0 >> 1) : oy0, ex0 = a.pool2 ? (ox0 >> 1) : ox0;
-    for (int i = tid; i < eh * ew * GPR; i += NT) {
+    for (int i = tid; i < eh * ew * GPR; i += NTH) {
         const int q = i / GPR, gch = i - q * GPR;
         const int qy = q / ew, qx = q - qy * ew;
         const int gy = ey0 + qy, gx = ex0 + qx;
@@ -431,8 +431,11 @@ struct Epi {
 // NCH > 0: the chunk count is a compile-time constant and the K loop is fully unrolled -- in straight-line code hipcc counts
 // the outstanding loads exactly, so the register ring really keeps DEPTH chunks in flight (with a loop it drains to
 // vmcnt(0) at every other store phase).
-template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0>
-__global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void k_conv3x3(const ConvK a) {
+// NTH: threads per workgroup.  256 = 4 waves = 128 output pixels; 512 = 8 waves = 256 output pixels x BN channels (the
+// "wide" form: per MFMA it stages half the bytes of the 128 x 32 tile -- the mid layers are bound by the bytes a CU can
+// keep in flight, profiles/r2_conv_pmc.json -- and reads 0.75 instead of 1 KB of LDS).
+template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0, int NTH = 256>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2)) void k_conv3x3(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G;
     constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
     // issued back to back) BEFORE the MFMAs of chunk k and written to LDS after them, so global latency hides
     // under the matrix work instead of being paid once per 16-byte granule.
     constexpr int WTOT = BN * NGR;                         // real weight granules per chunk
-    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int WIT = (WTOT + NTH - 1) / NTH;
     // patch granules per thread that are prefetched: 3 cover every stride-1 patch (<= 10 x 18 pixels x 4 granules); the
     // stride-2 instantiations take 9 (17 x 33 x 4 = 2244 granules) so that nothing is left to the synchronous tail loop
     constexpr int PPF = TAIL ? 9 : 3;
@@ -498,16 +501,16 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
         const int n = tid / NGR, gi = tid - n * NGR;
         const int tap = gi / NG, cg = gi - tap * NG;
         woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+        woffL = ((WIT - 1) * NTH + tid < WTOT) ? woff0 : OOB_OFF;
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
+        const int i = it * NTH + tid;
         const int n = i / NGR;
         wlds[it] = i * 16 + n * (WROW - NGR * 16);
     }
     if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
-        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NTH) {
             const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
             st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
         }
@@ -536,12 +539,12 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
     int poff0[PPF], poff1[PPF];
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
-        poff0[it] = patch_off(0, it * NT + tid);
+        poff0[it] = patch_off(0, it * NTH + tid);
         poff1[it] = OOB_OFF;
     }
     if (a.g.C[1] > 0) {
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) poff1[it] = patch_off(1, it * NT + tid);
+        for (int it = 0; it < PPF; ++it) poff1[it] = patch_off(1, it * NTH + tid);
     }
 
     auto chunk_src = [&](int k, int& sidx, int& c0) { sidx = (k < nch0) ? 0 : 1; c0 = (k - (sidx ? nch0 : 0)) * CK; };
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
         const int so = dead ? 0 : k * CK * ES;
 #pragma unroll
         for (int it = 0; it < WIT; ++it)                  // branch-free, zero-filled
-            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NTH / NG) * tapB) | dead, so);
     };
 #ifdef COLVO_ABLATE
 #pragma unroll
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
     auto store_w = [&](const u32x4 (&w)[WIT]) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
+            if (WTOT % NTH == 0 || it < WIT - 1 || it * NTH + tid < WTOT) st16(sW + wlds[it], w[it]);
     };
     auto patch_granule = [&](int sidx, int c0, int i) -> u32x4 {      // only for the tail of large (stride-2) patches
         return sidx == 0 ? bld16(rimg0, patch_off(0, i), c0 * ES) : bld16(rimg1, patch_off(1, i), c0 * ES);
@@ -585,20 +588,20 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
     auto store_p = [&](int k, const u32x4 (&pvv)[PPF]) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
+            const int i = it * NTH + tid;
             if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
         if constexpr (TAIL) {
             int sidx, c0;
             chunk_src(k, sidx, c0);
-            for (int base = PPF * NT; base < ptotal; base += 3 * NT) {
+            for (int base = PPF * NTH; base < ptotal; base += 3 * NTH) {
                 u32x4 t[3];
 #pragma unroll
-                for (int u = 0; u < 3; ++u) t[u] = patch_granule(sidx, c0, base + u * NT + tid);
+                for (int u = 0; u < 3; ++u) t[u] = patch_granule(sidx, c0, base + u * NTH + tid);
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int i = base + u * NT + tid;
+                    const int i = base + u * NTH + tid;
                     if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, t[u]); }
                 }
             }
@@ -733,7 +736,261 @@ __global__ __launch_bounds__(NT, (BN <= 32 && DEPTH == 1 && !TAIL) ? 4 : 2) void
         for (int nf = 0; nf < NF; ++nf)
             *reinterpret_cast<f32x4*>(&sOut[(wave * 32 + mf * 16 + l15) * OUTP + nf * 16 + 4 * kg]) = acc[mf][nf];
     __syncthreads();
-    conv_epilogue<T, BN>(a, sOut, b, oy0, ox0, n0, tid);
+    conv_epilogue<T, BN, NTH>(a, sOut, b, oy0, ox0, n0, tid);
+}
+
+// --------------------------------------------------------------------------------------------- //
+// forward / input-gradient kernel, persistent multi-chunk form                                   //
+// --------------------------------------------------------------------------------------------- //
+// k_conv3x3 with a tile loop around the chunk loop.  A one-tile workgroup pays 0.5 us of set-up, 1-1.8 us for the first
+// (un-hidden) stage and ~1 us of epilogue around 2-8 chunks of ~1.4 us, and a grid of 1.25 x the resident slots costs
+// two rounds.  Here the grid is the number of resident slots (a multiple of the n-tile count, so a workgroup keeps ITS
+// output-channel tile: weight offsets and bias are set up once); a workgroup walks the pixel tiles t0, t0 + step, ...
+// and the register prefetch runs THROUGH the tile boundary: chunk 0 of the next tile is in flight during the last
+// chunk's MFMAs and the epilogue stores.  Same LDS layout, staging and MFMA phase as k_conv3x3<.., DEPTH 1>.
+template <typename T, int BN, int NG, bool TAIL>
+__global__ __launch_bounds__(NT, (BN <= 32 && !TAIL) ? 3 : 2) void k_conv3x3_p(const ConvK a, int ntiles, int ntn, uint32_t m_tpi,
+                                                                             uint32_t m_tx) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int CK = NG * G;
+    constexpr int NGR = 9 * NG;
+    constexpr int STEPS = (NGR + 3) / 4;
+    constexpr int WROW = wrow_bytes(STEPS * 4);
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int NF = BN / 16;
+    constexpr int OUTP = BN + 4;
+    constexpr int WTOT = BN * NGR;
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = TAIL ? 9 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int nt = blockIdx.x % ntn;                        // this workgroup's output-channel tile (fixed)
+    const int n0 = nt * BN;
+    const int tstep = gridDim.x / ntn;                      // the host makes gridDim.x a multiple of ntn
+    const int S = a.g.stride;
+    const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
+    const int npix = a.toh * a.tow;
+    const int ptotal = PH * PW * NG;
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
+
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
+    }
+
+    // ---- tile-invariant set-up: weight offsets / LDS slots, bias, the patch granules of this thread ----
+    const int tapB = a.Ctot * ES;
+    int woff0, woffL, wlds[WIT];
+    {
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+    }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NT + tid;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    if constexpr (STEPS * 4 != NGR) {
+        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
+        }
+    }
+    // this thread's patch granules: granule it*256 + tid = pixel it*(256/NG) + tid/NG, channel granule tid % NG -- the LDS
+    // slot advances by a constant per `it` and the channel granule does not depend on it at all
+    int pyx[PPF];                                           // (py << 16 | px) inside the patch (py = 0x3fff: none)
+    const int pcg16 = (tid & (NG - 1)) * 16;
+    const int plds0 = (tid / NG) * PIXP + pcg16;
+    constexpr int PLDS_STEP = (NT / NG) * PIXP;
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        pyx[it] = (i < ptotal) ? ((py << 16) | px) : (0x3fff << 16);
+    }
+    // descriptors over the WHOLE tensors (host guarantees < 1 GiB each): image and channel chunk go into the scalar offset
+    const int nimg = ntiles / tiles_per_img;
+    const int img0 = a.g.Hs[0] * a.g.Ws[0] * a.g.C[0] * ES, img1 = a.g.Hs[1] * a.g.Ws[1] * a.g.C[1] * ES;
+    const int img_out = a.Ho * a.Wo * a.N * ES;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rimg0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, nimg * img0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rimg1 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.g.src[1] ? a.g.src[1] : a.g.src[0]), 0, a.g.C[1] > 0 ? nimg * img1 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, nimg * img_out, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? nimg * img_out : 0, 0x00020000);
+    u32x4 biasv[NF];
+    {
+        const __amdgpu_buffer_rsrc_t rbias =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);
+    }
+
+    struct TileO { int b, oy0, ox0; };
+    auto tile_origin = [&](int tile) -> TileO {             // wave-uniform; magic divisions (host checks the ranges)
+        const int t = __builtin_amdgcn_readfirstlane(tile);
+        const int b = mdiv(t, m_tpi), tr_ = t - b * tiles_per_img;
+        const int ty = mdiv(tr_, m_tx), tx = tr_ - ty * a.tiles_x;
+        return TileO{b, ty * a.toh, tx * a.tow};
+    };
+    // per-tile byte offsets of this thread's patch granules inside an image of source 0 / 1 (OOB_OFF: padding)
+    int poff0[PPF], poff1[PPF];
+    auto tile_offsets = [&](const TileO& o) {
+        const int iy0 = o.oy0 * S - 1, ix0 = o.ox0 * S - 1;
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+            const int Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
+            const int sh = (mode != MODE_DIRECT) ? 1 : 0, par = (mode == MODE_DILATE) ? 1 : 0;
+#pragma unroll
+            for (int it = 0; it < PPF; ++it) {
+                const int vy = iy0 + (pyx[it] >> 16), vx = ix0 + (pyx[it] & 0xffff);
+                const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi) && (((vy | vx) & par) == 0);
+                const int off = (inb && Cs > 0) ? (((vy >> sh) * Ws + (vx >> sh)) * Cs * ES + pcg16) : OOB_OFF;
+                if (sidx == 0) poff0[it] = off; else poff1[it] = off;
+            }
+        }
+    };
+    u32x4 wv[WIT], pv[PPF];
+    auto load_w = [&](int k, int dead) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+    };
+    auto load_p = [&](int k, int bimg, int dead) {          // chunk k of the tile whose offsets are in poff0 / poff1
+        const int sidx = (k < nch0) ? 0 : 1;
+        const int c0 = (k - (sidx ? nch0 : 0)) * CK;
+        if (sidx == 0) {
+            const int so = bimg * img0 + c0 * ES;
+#pragma unroll
+            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg0, poff0[it] | dead, so);
+        } else {
+            const int so = bimg * img1 + c0 * ES;
+#pragma unroll
+            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, poff1[it] | dead, so);
+        }
+    };
+    auto store_wp = [&]() {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
+#pragma unroll
+        for (int it = 0; it < PPF; ++it)
+            if ((pyx[it] >> 16) != 0x3fff) st16(sP + plds0 + it * PLDS_STEP, pv[it]);
+    };
+
+    int tile = blockIdx.x / ntn;
+    if (tile >= ntiles) return;                             // (the host never launches such a workgroup)
+    TileO cur = tile_origin(tile);
+    tile_offsets(cur);
+    load_w(0, 0);
+    load_p(0, cur.b, 0);
+    for (; tile < ntiles; tile += tstep) {
+        const int next = tile + tstep;
+        const bool has_next = next < ntiles;                // wave-uniform
+        const TileO nxt = tile_origin(has_next ? next : 0);
+        f32x4 acc[2][NF];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Epi<T, NF> ep;
+        for (int k = 0; k < nch; ++k) {
+            __syncthreads();                                // the previous MFMA phase / pool2 epilogue has finished with LDS
+            store_wp();
+            __syncthreads();
+            // next stage into registers: chunk k+1 of this tile, or chunk 0 of the next one (through the tile boundary)
+            const bool last = (k + 1 == nch);
+            if (last) {
+                if (!a.pool2) {                             // mask / accumulate operands of THIS tile: in flight during its last MFMAs
+                    ep.offsets(a, cur.oy0, cur.ox0, n0, wave, l15, kg);   // (issued BEFORE the next tile's loads: vmcnt retires in
+                    ep.prefetch(a, rout, rmask, cur.b * img_out);         //  order, the epilogue must not wait for those)
+                }
+                if (has_next) tile_offsets(nxt);
+                const int dead = has_next ? 0 : OOB_OFF;
+                load_w(0, dead);
+                load_p(0, nxt.b, dead);
+            } else {
+                load_w(k + 1, 0);
+                load_p(k + 1, cur.b, 0);
+            }
+            // MFMA phase (fragments of k-group m+1 are read before the MFMAs of k-group m are issued)
+            {
+                u32x4 av[2][2], bv[2][NF];
+                auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
+                    const int gi = 4 * m + kg;
+                    int tap = gi / NG;
+                    const int cg = gi - tap * NG;
+                    tap = min(tap, 8);
+                    const int ky = tap / 3, kx = tap - 3 * ky;
+                    const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
+                };
+                read_frags(0, av[0], bv[0]);
+#pragma unroll
+                for (int m = 0; m < STEPS; ++m) {
+                    const int c = m & 1;
+                    if (m + 1 < STEPS) read_frags(m + 1, av[c ^ 1], bv[c ^ 1]);
+                    if constexpr (ES == 2) {
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf)
+                                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, bv[c][nf]), __builtin_bit_cast(bf16x8, av[c][mf]), acc[mf][nf], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                                for (int nf = 0; nf < NF; ++nf)
+                                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        __uint_as_float(bv[c][nf][j]), __uint_as_float(av[c][mf][j]), acc[mf][nf], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
+        if (!a.pool2) {
+            ep.finish(a, acc, biasv, rout, cur.b * img_out);
+        } else {
+            __syncthreads();                                // every wave is done reading LDS: it becomes the fp32 output tile
+            float* sOut = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf)
+                    *reinterpret_cast<f32x4*>(&sOut[(wave * 32 + mf * 16 + l15) * OUTP + nf * 16 + 4 * kg]) = acc[mf][nf];
+            __syncthreads();
+            conv_epilogue<T, BN>(a, sOut, cur.b, cur.oy0, cur.ox0, n0, tid);
+            if constexpr (STEPS * 4 != NGR) {               // sOut overlays the weight slab: restore its zero padding granules
+                __syncthreads();
+                for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+                    const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+                    st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
+                }
+            }
+        }
+        cur = nxt;
+    }
 }
 
 // --------------------------------------------------------------------------------------------- //
@@ -1200,7 +1457,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
 struct Tile { int toh, tow; };
 
 // choose the tile region (<=128 pixels) that wastes the fewest fragment rows; ties: least staged patch
-Tile pick_tile(int Ho, int Wo, int stride, bool even) {
+Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128) {
     Tile best{even ? 2 : 1, even ? 2 : 1};
     double best_cost = 1e30;
     const int step = even ? 2 : 1;
@@ -1218,19 +1475,19 @@ Tile pick_tile(int Ho, int Wo, int stride, bool even) {
     return best;
 }
 
-template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0>
+template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0, int NTH = 256>
 int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
     size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
-    const size_t eplds = (size_t)BM * (BN + 4) * 4;
+    const size_t eplds = (size_t)(NTH / 2) * (BN + 4) * 4;
     if (eplds > lds) lds = eplds;
     COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;   // per instantiation
     if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
@@ -1249,7 +1506,7 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
         hipMemsetAsync(tbuf, 0, nwg * 8 * sizeof(long long), s);
         ka.trace = tbuf;
     }
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>), grid, dim3(NT), lds, s, ka);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, ka);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     if (tracing && (++tcount % atoi(getenv("COLVO_TRACE"))) == 0) {     // every n-th launch: print the phase statistics
         hipStreamSynchronize(s);
@@ -1273,15 +1530,33 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     }
     return 0;
 #endif
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH>), grid, dim3(NT), lds, s, k);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
 }
+
+template <typename T, int BN, int NG, bool TAIL> int launch_conv_p_tail(const ConvK& k, int B, hipStream_t s);
+inline bool persistent_ok(const ConvK& k, int B, int es);
 
 template <typename T, int BN, int NG, int DEPTH = 1>
 int launch_conv(const ConvK& k, int B, hipStream_t s) {
     const int S = k.g.stride;
     const long ptotal = (long)((k.toh - 1) * S + 3) * ((k.tow - 1) * S + 3) * NG;
+    if constexpr (DEPTH == 1) {
+        // persistent multi-chunk form whenever the walk is long enough to pay (>= COLVO_P_MIN_WALK tiles per workgroup)
+        // off by default: measured 5-25 % SLOWER than the one-tile form on the DepthNet layers at B = 16 (3 instead of 4 resident
+        // workgroups per CU at 162 VGPRs; gpurun_out/r2_bench_conv_p*.log) -- kept for larger batches / further tuning
+        static const int p_on = [] { const char* e = getenv("COLVO_PERSIST"); return e ? atoi(e) : 0; }();
+        static const double p_min_walk = [] { const char* e = getenv("COLVO_P_MIN_WALK"); return e ? atof(e) : 1.2; }();
+        if (p_on && persistent_ok(k, B, TT<T>::ES)) {
+            const bool tail = ptotal > 3 * NT;
+            const long ntiles = (long)k.tiles_x * k.tiles_y * B, ntn = (k.N + BN - 1) / BN;
+            const int by_regs = (BN <= 32 && !tail) ? 3 : 2;
+            const double walk = (double)ntiles * ntn / (256.0 * by_regs);
+            if (walk >= p_min_walk)
+                return tail ? launch_conv_p_tail<T, BN, NG, true>(k, B, s) : launch_conv_p_tail<T, BN, NG, false>(k, B, s);
+        }
+    }
     if (ptotal > 3 * NT) return launch_conv_tail<T, BN, NG, (DEPTH > 2 ? 2 : DEPTH), true>(k, B, s);   // depth 3 would spill
     if constexpr (DEPTH >= 2) {
         const int nch = (k.g.C[0] + k.g.C[1]) / (NG * TT<T>::G);
@@ -1289,6 +1564,54 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
         if (nch == 16) return launch_conv_tail<T, BN, NG, DEPTH, false, 16>(k, B, s);
     }
     return launch_conv_tail<T, BN, NG, DEPTH, false>(k, B, s);
+}
+
+// persistent multi-chunk kernel: grid = resident slots rounded to a multiple of the n-tile count
+template <typename T, int BN, int NG, bool TAIL>
+int launch_conv_p_tail(const ConvK& k, int B, hipStream_t s) {
+    constexpr int STEPS = (9 * NG + 3) / 4;
+    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
+    const int S = k.g.stride;
+    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
+    const size_t eplds = (size_t)BM * (BN + 4) * 4;
+    if (eplds > lds) lds = eplds;
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_p<T, BN, NG, TAIL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = 160 * 1024;
+    }
+    const int ntiles = k.tiles_x * k.tiles_y * B;
+    const int ntn = (k.N + BN - 1) / BN;
+    // resident workgroups per CU: registers (launch bounds: 3 for the narrow stride-1 form, else 2) and LDS
+    const int by_regs = (BN <= 32 && !TAIL) ? 3 : 2;
+    int per_cu = (int)std::min<size_t>((size_t)by_regs, (160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    static const int p_wg_per_cu = [] { const char* e = getenv("COLVO_P_WG_PER_CU"); return e ? atoi(e) : 0; }();   // tuning knob
+    if (p_wg_per_cu > 0) per_cu = p_wg_per_cu;
+    long slots = 256L * per_cu;
+    long tiles_par = std::max(1L, std::min((long)ntiles, slots / ntn));      // pixel tiles in flight
+    // even out the walk: every workgroup gets ceil(ntiles / tiles_par) or one fewer
+    const long walk = (ntiles + tiles_par - 1) / tiles_par;
+    tiles_par = (ntiles + walk - 1) / walk;
+    dim3 grid((unsigned)(tiles_par * ntn), 1, 1);
+    hipLaunchKernelGGL((k_conv3x3_p<T, BN, NG, TAIL>), grid, dim3(NT), lds, s, k, ntiles, ntn,
+                       mdiv_magic(k.tiles_x * k.tiles_y), mdiv_magic(k.tiles_x));
+    COLVO_CHECK_LAUNCH("k_conv3x3_p");
+    return 0;
+}
+
+// can the persistent kernels address this problem?  (32-bit buffer offsets over whole tensors, magic-division ranges)
+inline bool persistent_ok(const ConvK& k, int B, int es) {
+    const long long s0 = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * es;
+    const long long s1 = (long long)B * k.g.Hs[1] * k.g.Ws[1] * k.g.C[1] * es;
+    const long long so = (long long)B * k.Ho * k.Wo * k.N * es / (k.pool2 ? 4 : 1);
+    const long long tpi = (long long)k.tiles_x * k.tiles_y;
+    return s0 < 0x40000000LL && s1 < 0x40000000LL && so < 0x40000000LL && tpi >= 2 && k.tiles_x >= 2 &&
+           tpi * tpi * B < 0x100000000LL && tpi * B < 65536;
 }
 
 template <typename T, int BN, int NG>
@@ -1347,14 +1670,52 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
     }
 }
 
+inline void set_tile(ConvK& k, const Tile& t) {
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (k.Wo + t.tow - 1) / t.tow; k.tiles_y = (k.Ho + t.toh - 1) / t.toh;
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * k.g.stride + 3);
+}
+
+template <typename T, int BN>
+int launch_conv_wide(const ConvK& k, int B, int ng, hipStream_t s) {
+    switch (ng) {
+        case 4: return launch_conv_tail<T, BN, 4, 1, false, 0, 512>(k, B, s);
+        case 2: return launch_conv_tail<T, BN, 2, 1, false, 0, 512>(k, B, s);
+        default: return launch_conv_tail<T, BN, 1, 1, false, 0, 512>(k, B, s);
+    }
+}
+
+// `even`: tile extents must be even (2x2 sum-pool epilogue)
 template <typename T>
-int launch_conv_t(const ConvK& k, int B, hipStream_t s) {
+int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     constexpr int G = TT<T>::G;
     int ng = 4;
     for (int i = 0; i < 2; ++i)
         if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
     for (int i = 0; i < 2; ++i)
         COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "conv: channel count %d is not a multiple of %d", k.g.C[i], G);
+    // Wide form (512 threads, 256 pixels x BN channels): multi-chunk stride-1 layers whose 256-pixel grid still covers the
+    // chip.  Per MFMA it stages 100 (BN 64) / 136 (BN 32) bytes instead of 208, and the CUs' bytes in flight are what bounds
+    // these layers.
+    {
+        // off by default: at B = 16 the 256-pixel grids are 1-1.25 workgroups per CU and measured 10-20 % slower (up3 18.9 ->
+        // 21.7 us; gpurun_out/r2_bench_conv_w*.log); the form pays once the grid covers the chip several times (configs[2])
+        static const int wide_on = [] { const char* e = getenv("COLVO_WIDE"); return e ? atoi(e) : 0; }();                 // tuning knob
+        static const long wide_min_wgs = [] { const char* e = getenv("COLVO_WIDE_MIN_WGS"); return e ? atol(e) : 192L; }();   // tuning knob
+        static const int wide_min_chunks = [] { const char* e = getenv("COLVO_WIDE_MIN_CHUNKS"); return e ? atoi(e) : 2; }();
+        const int nch = (k.g.C[0] + k.g.C[1]) / (ng * G);
+        if (wide_on && k.g.stride == 1 && k.N >= 32 && nch >= wide_min_chunks) {
+            const Tile tw = pick_tile(k.Ho, k.Wo, 1, even, 256);
+            const long patch = (long)(tw.toh + 2) * (tw.tow + 2) * ng;
+            const int bn = k.N >= 64 ? 64 : 32;
+            const long wgs = (long)((k.Ho + tw.toh - 1) / tw.toh) * ((k.Wo + tw.tow - 1) / tw.tow) * B * ((k.N + bn - 1) / bn);
+            if (patch <= 3 * 512 && tw.toh * tw.tow > 128 && wgs >= wide_min_wgs) {
+                set_tile(k, tw);
+                return bn == 64 ? launch_conv_wide<T, 64>(k, B, ng, s) : launch_conv_wide<T, 32>(k, B, ng, s);
+            }
+        }
+    }
+    set_tile(k, pick_tile(k.Ho, k.Wo, k.g.stride, even));
     // Output-channel tile: 64 wide by default; when that grid would leave CUs idle (deep, low-resolution layers at small
     // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
     const long tiles = (long)k.tiles_x * k.tiles_y * B;
@@ -1478,12 +1839,8 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
     k.Ho = d->Ho; k.Wo = d->Wo;
     k.w = (const char*)w_fwd; k.Ctot = d->C0 + d->C1; k.N = d->Cout;
     k.bias = bias; k.relu = d->relu; k.out = (char*)y; k.mask = nullptr; k.accumulate = 0; k.pool2 = 0;
-    const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
-    k.toh = t.toh; k.tow = t.tow;
-    k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
-    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * d->stride + 3);
-    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
-                                 : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
+    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
+                                 : launch_conv_t<bf16_t>(k, d->B, false, (hipStream_t)stream);
 }
 
 extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy, const void* w_bwd,
@@ -1508,12 +1865,8 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     k.w = (const char*)w_bwd + (size_t)coff * 9 * d->Cout * es; k.Ctot = d->Cout; k.N = Csrc;
     k.bias = nullptr; k.relu = 0; k.out = (char*)dx; k.mask = (const char*)relu_mask;
     k.accumulate = accumulate; k.pool2 = up;
-    const Tile t = pick_tile(d->Hi, d->Wi, 1, up != 0);
-    k.toh = t.toh; k.tow = t.tow;
-    k.tiles_x = (d->Wi + t.tow - 1) / t.tow; k.tiles_y = (d->Hi + t.toh - 1) / t.toh;
-    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 2);
-    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, (hipStream_t)stream)
-                                 : launch_conv_t<bf16_t>(k, d->B, (hipStream_t)stream);
+    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, up != 0, (hipStream_t)stream)
+                                 : launch_conv_t<bf16_t>(k, d->B, up != 0, (hipStream_t)stream);
 }
 
 extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,

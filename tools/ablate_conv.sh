@@ -8,7 +8,7 @@
 #   bash tools/ablate_conv.sh run [B]          (on the GPU box)
 set -e
 cd "$(dirname "$0")/.."
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DNDEBUG -fno-slp-vectorize -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -DNDEBUG -fno-slp-vectorize -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
 if [ "$1" = build ]; then
     python -m coivo_amd.build >/dev/null
     /opt/rocm/bin/hipcc $FLAGS -DCOLVO_ABLATE -c coivo_amd/csrc/conv.hip -o coivo_amd/lib/obj/conv_abl.o

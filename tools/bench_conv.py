@@ -27,8 +27,8 @@ def layers(B, H, W):
     return out
 
 
-def timeit(fn, n=30):
-    for _ in range(5):
+def timeit(fn, n=int(os.environ.get("CONV_BENCH_ITERS", "30"))):
+    for _ in range(5 if n >= 10 else 1):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -70,6 +70,10 @@ def main():
         shape = "%d+%d->%d @%dx%d s%d%s" % (c0, c1, cout, d.Ho, d.Wo, stride, " up" if up else "")
         print(f"{name:8s} {shape:28s} {gf:7.2f} | {tf:8.1f} {gf / tf:6.1f} | {td:8.1f} {gd / td:6.1f} | {tw:8.1f} {gf / tw:6.1f}")
     print(f"totals: fwd {tot[0]:.0f} us  dgrad {tot[1]:.0f} us  wgrad {tot[2]:.0f} us")
+    gtot = 159.0    # GFLOP per pass of the DepthNet stack at B=16, 256x320 (sum of the GFLOP column; dgrad without enc1a's)
+    if B == 16 and not fwdonly:
+        print("MFMA rate per pass (of 2500 TFLOP/s dense bf16): fwd %.1f %%  dgrad %.1f %%  wgrad %.1f %%" %
+              tuple(100.0 * gtot / t / 1e3 / 2500.0 * 1e3 for t in tot))
 
 
 if __name__ == "__main__":

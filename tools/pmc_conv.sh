@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC counters of the conv kernels on the DepthNet layer shapes (tools/bench_conv.py), one rocprofv3 pass per group:
+#   bash tools/pmc_conv.sh <tag>      -> gpurun_out/pmc_conv_<tag>/{sq1,sq2,tcp,tcc}/...   then tools/pmc_conv_summary.py
+set -e
+TAG=${1:-r2}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc_conv_$TAG
+rm -rf $OUT && mkdir -p $OUT
+export CONV_BENCH_ITERS=4
+run() { # name counters...
+  n=$1; shift
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 tools/bench_conv.py 16 bf16 > $OUT/$n.log 2>&1
+}
+run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS
+run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_LDS_DATA_FIFO_FULL
+run tcp TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
+run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
+echo done
