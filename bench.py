@@ -188,29 +188,46 @@ def roofline_cfg2(dev):
                       "bwd_us is the cost of the two event records), median of 20 launches"}
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def plan_distributed(args, env):
+    """Everything the multi-process launch derives from the command line and the torchrun environment, as plain data
+    (tests/test_bench_cpu.py walks the RCCL branch up to -- not including -- init_process_group without a GPU)."""
+    rank = int(env.get("RANK", "0"))
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    world = int(env.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU fallback")
     if args.rehearse_on_one_gpu:
         local_rank = 0
+    plan = {"rank": rank, "local_rank": local_rank, "world": world, "device": ("cuda", local_rank), "backend": None,
+            "init_kwargs": None, "master_addr": env.get("MASTER_ADDR", "127.0.0.1"), "seed": 1234 + rank,
+            "global_batch": world * args.batch_per_gpu,
+            "grad_transport": (args.grad_transport if world > 1 else None)}
+    if world > 1:
+        plan["backend"] = "gloo" if args.rehearse_on_one_gpu else "nccl"      # "nccl" IS RCCL on ROCm
+        plan["init_kwargs"] = {"rank": rank, "world_size": world}
+        if plan["backend"] == "nccl":
+            plan["init_kwargs"]["device_id"] = plan["device"]
+    return plan
+
+
+def main():
+    args = parse()
+    plan = plan_distributed(args, os.environ)
+    rank, local_rank, world = plan["rank"], plan["local_rank"], plan["world"]
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda is not available); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device(*plan["device"])
 
     import torch.distributed as dist
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", plan["master_addr"])
+        kw = dict(plan["init_kwargs"])
+        if "device_id" in kw:
+            kw["device_id"] = dev
+        dist.init_process_group(plan["backend"], **kw)
 
     from coivo_amd import build as _colvo_build      # fresh checkout / edited kernels: (re)build in-tree, rank 0 first
     if local_rank == 0:

@@ -45,6 +45,13 @@ SIGNATURES = {
     "colvo_warp_loss_fused_bwd": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
     "colvo_warp_loss_fused_bwd_params": (_i, [_vp] * 4 + [_i] + [_vp] * 4),
     "colvo_inverse_warp": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 3),
+    "colvo_geo_loss_workspace_floats": (_sz, [_i, _i, _i]),
+    "colvo_geo_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _i] + [_vp] * 3),
+    "colvo_geo_loss_bwd": (_i, [_vp] * 4 + [_i, _i, _i] + [_vp] * 7),
+    "colvo_smooth_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "colvo_smooth_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "colvo_avgpool2_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "colvo_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),

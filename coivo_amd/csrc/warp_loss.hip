@@ -941,6 +941,278 @@ __global__ __launch_bounds__(NT) void k_inverse_warp(const float* __restrict__ r
 }
 
 
+// --------------------------------------------------------------------------------------------- //
+// geometric consistency (spec: oracle/colvo_spec.py geometric_consistency_loss)  //
+// --------------------------------------------------------------------------------------------- //
+// Concept: /root/reference/README.md:1 ("Considering Geometric and Photometric Consistency"), :7 ("alignment of geometric
+// projections between consecutive frames").  Pixel-local (no window), so one thread per target pixel: project with the
+// fused kernel's own project_px / make_taps_safe, sample the reference frame's depth with the same four taps, compare
+// with the projected depth.  It is NOT folded into the marching photometric kernel: that kernel sits at the 256-VGPR cap
+// (2 waves / SIMD), and this term adds 4 taps, 3 live values per rolling row and a scatter.
+// Bound: HBM, 4 (depth_t) + 4 (depth_r, gathered) bytes read per pixel forward; backward the same + 4 written (d_depth_t)
+// + 16 of float atomics (d_depth_r: the four taps; order-dependent in the last bits).
+constexpr int GEO_NP = 12;                  // dt[3], dR[9]
+
+struct GeoPix {
+    float diff, m;                          // |a - b| / (a + b) (0 where invalid), validity
+    float ga, gb;                           // d diff / d a, d diff / d b   (a = D_proj, b = D_samp)
+    Proj p;
+    Taps t;
+    float d00, d01, d10, d11;
+};
+
+__device__ __forceinline__ GeoPix geo_pixel(const Geo& g, const float* __restrict__ dt_img, const float* __restrict__ dr_img,
+                                            int u, int v, int H, int W) {
+    GeoPix o;
+    const float d = dt_img[(size_t)v * W + u];
+    o.p = project_px(g, d, u, v, H, W);
+    o.t = make_taps_safe(o.p, H, W);
+    const char* r = reinterpret_cast<const char*>(dr_img);
+    o.d00 = *reinterpret_cast<const float*>(r + o.t.o00); o.d01 = *reinterpret_cast<const float*>(r + o.t.o01);
+    o.d10 = *reinterpret_cast<const float*>(r + o.t.o10); o.d11 = *reinterpret_cast<const float*>(r + o.t.o11);
+    const float ux = 1.0f - o.t.wx, uy = 1.0f - o.t.wy;
+    const float top = fmaf(o.d01, o.t.wx, o.d00 * ux), bot = fmaf(o.d11, o.t.wx, o.d10 * ux);
+    const float b = fmaf(bot, o.t.wy, top * uy);
+    const float a = o.p.Pz;
+    o.m = o.p.valid ? 1.0f : 0.0f;
+    const float den = o.p.valid ? (a + b) : 1.0f;
+    const float inv = 1.0f / den;
+    const float df = a - b;
+    o.diff = o.m * fabsf(df) * inv;
+    const float sg = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
+    // d/da |a-b|/(a+b) = sg 2b / (a+b)^2 ;  d/db = -sg 2a / (a+b)^2
+    o.ga = o.m * sg * 2.0f * b * inv * inv;
+    o.gb = -o.m * sg * 2.0f * a * inv * inv;
+    return o;
+}
+
+// forward: per-block partial {sum diff, sum mask}
+__global__ __launch_bounds__(NT) void k_geo_loss_fwd(const float* __restrict__ depth_t, const float* __restrict__ depth_r,
+                                                     const float* __restrict__ pose, const float* __restrict__ K, int H, int W,
+                                                     float* __restrict__ partials) {
+    __shared__ float s_geo[GEO_N + 4];
+    __shared__ float red[4][2];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) geo_compute(pose, K, nullptr, nullptr, b, s_geo);
+    __syncthreads();
+    const Geo g = geo_load(s_geo);
+    const size_t plane = (size_t)H * W;
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    float sd = 0.0f, sm = 0.0f;
+    if (o < plane) {
+        const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
+        const GeoPix q = geo_pixel(g, depth_t + (size_t)b * plane, depth_r + (size_t)b * plane, u, v, H, W);
+        sd = q.diff; sm = q.m;
+    }
+    sd = wave_sum(sd); sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sd; red[threadIdx.x >> 6][1] = sm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        partials[2 * blk] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partials[2 * blk + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_geo_loss_finalize(const float* __restrict__ partials, int nblk, float* __restrict__ loss_state) {
+    __shared__ float s0[NT], s1[NT];
+    float a = 0.0f, c = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += NT) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float denom = fmaxf(s1[0], 1.0f);
+        loss_state[0] = s0[0] / denom;
+        loss_state[1] = 1.0f / denom;
+        loss_state[2] = s1[0];
+        loss_state[3] = 0.0f;
+    }
+}
+
+// backward (recomputes the forward): d_depth_t written, d_depth_r accumulated with float atomics (zeroed by the caller),
+// per-block partials of dt[3], dR[9]
+__global__ __launch_bounds__(NT) void k_geo_loss_bwd(const float* __restrict__ depth_t, const float* __restrict__ depth_r,
+                                                     const float* __restrict__ pose, const float* __restrict__ K, int H, int W,
+                                                     const float* __restrict__ loss_state, const float* __restrict__ grad_loss,
+                                                     float* __restrict__ d_depth_t, float* __restrict__ d_depth_r,
+                                                     float* __restrict__ partials) {
+    __shared__ float s_geo[GEO_N + 4];
+    __shared__ float red[4][GEO_NP];
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) geo_compute(pose, K, nullptr, nullptr, b, s_geo);
+    __syncthreads();
+    const Geo g = geo_load(s_geo);
+    const float scale = grad_loss[0] * loss_state[1];
+    const size_t plane = (size_t)H * W;
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    float part[GEO_NP];
+#pragma unroll
+    for (int k = 0; k < GEO_NP; ++k) part[k] = 0.0f;
+    if (o < plane) {
+        const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
+        const GeoPix q = geo_pixel(g, depth_t + (size_t)b * plane, depth_r + (size_t)b * plane, u, v, H, W);
+        const float ga = scale * q.ga, gb = scale * q.gb;          // zero where invalid
+        // sampled depth -> its four taps (scatter) and the sample position
+        const float ux = 1.0f - q.t.wx, uy = 1.0f - q.t.wy;
+        if (q.p.valid) {
+            char* r = reinterpret_cast<char*>(d_depth_r + (size_t)b * plane);
+            atomicAdd(reinterpret_cast<float*>(r + q.t.o00), gb * ux * uy);
+            atomicAdd(reinterpret_cast<float*>(r + q.t.o01), gb * q.t.wx * uy);
+            atomicAdd(reinterpret_cast<float*>(r + q.t.o10), gb * ux * q.t.wy);
+            atomicAdd(reinterpret_cast<float*>(r + q.t.o11), gb * q.t.wx * q.t.wy);
+        }
+        const float gx = gb * fmaf(q.t.wy, q.d11 - q.d10, uy * (q.d01 - q.d00));
+        const float gy = gb * fmaf(q.t.wx, q.d11 - q.d01, ux * (q.d10 - q.d00));
+        const float iz = q.p.valid ? 1.0f / q.p.Pz : 1.0f;
+        const float dPx = gx * g.fx * iz;
+        const float dPy = gy * g.fy * iz;
+        const float dPz = ga - (dPx * q.p.Px + dPy * q.p.Py) * iz;
+        const float d = depth_t[(size_t)b * plane + o];
+        const float rx_ = g.r00 * q.p.Xh + g.r01 * q.p.Yh + g.r02;
+        const float ry_ = g.r10 * q.p.Xh + g.r11 * q.p.Yh + g.r12;
+        const float rz_ = g.r20 * q.p.Xh + g.r21 * q.p.Yh + g.r22;
+        d_depth_t[(size_t)b * plane + o] = dPx * rx_ + dPy * ry_ + dPz * rz_;
+        const float cX = q.p.Xh * d, cY = q.p.Yh * d, cZ = d;
+        part[0] = dPx; part[1] = dPy; part[2] = dPz;
+        part[3] = dPx * cX; part[4] = dPx * cY; part[5] = dPx * cZ;
+        part[6] = dPy * cX; part[7] = dPy * cY; part[8] = dPy * cZ;
+        part[9] = dPz * cX; part[10] = dPz * cY; part[11] = dPz * cZ;
+    }
+#pragma unroll
+    for (int k = 0; k < GEO_NP; ++k) {
+        const float t = wave_sum(part[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < GEO_NP) {
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        partials[blk * GEO_NP + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// one workgroup per image: fixed-order sum of the block partials, then dR -> d(euler)
+__global__ __launch_bounds__(NT) void k_geo_loss_bwd_finalize(const float* __restrict__ partials, int blocks_per_image,
+                                                              const float* __restrict__ pose, float* __restrict__ d_pose) {
+    __shared__ float s[GEO_NP][NT / GEO_NP + 1];
+    __shared__ float tot[GEO_NP];
+    const int b = blockIdx.x;
+    constexpr int ROWS = NT / GEO_NP;   // 21
+    const int k = threadIdx.x % GEO_NP, r = threadIdx.x / GEO_NP;
+    float acc = 0.0f;
+    if (r < ROWS)
+        for (int i = r; i < blocks_per_image; i += ROWS) acc += partials[((size_t)b * blocks_per_image + i) * GEO_NP + k];
+    if (r < ROWS) s[k][r] = acc;
+    __syncthreads();
+    if (threadIdx.x < GEO_NP) {
+        float t = 0.0f;
+        for (int i = 0; i < ROWS; ++i) t += s[threadIdx.x][i];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float drx, dry, drz;
+        dR_to_euler(tot + 3, pose + 6 * b, drx, dry, drz);
+        d_pose[6 * b + 0] = tot[0]; d_pose[6 * b + 1] = tot[1]; d_pose[6 * b + 2] = tot[2];
+        d_pose[6 * b + 3] = drx; d_pose[6 * b + 4] = dry; d_pose[6 * b + 5] = drz;
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
+// edge-aware smoothness (spec: smoothness_loss) and 2x2 average pooling for the  //
+// multi-scale photometric term (spec: downsample2 / multiscale_photometric_loss)                 //
+// --------------------------------------------------------------------------------------------- //
+// weight of the neighbour pair (p, q): exp(-mean_c |I[p] - I[q]|)
+__device__ __forceinline__ float edge_w(const float* __restrict__ img, size_t plane, size_t p, size_t q) {
+    const float s = fabsf(img[p] - img[q]) + fabsf(img[plane + p] - img[plane + q]) + fabsf(img[2 * plane + p] - img[2 * plane + q]);
+    return expf(-s * (1.0f / 3.0f));
+}
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// forward: every pixel owns its right and its lower neighbour pair; per-block partial {Sx, Sy}
+__global__ __launch_bounds__(NT) void k_smooth_fwd(const float* __restrict__ depth, const float* __restrict__ img, int H, int W,
+                                                   float* __restrict__ partials) {
+    __shared__ float red[4][2];
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    float sx = 0.0f, sy = 0.0f;
+    if (o < plane) {
+        const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
+        const float* dp = depth + (size_t)b * plane;
+        const float* ip = img + (size_t)b * 3 * plane;
+        const float d0 = 1.0f / dp[o];
+        if (u + 1 < W) sx = fabsf(1.0f / dp[o + 1] - d0) * edge_w(ip, plane, o, o + 1);
+        if (v + 1 < H) sy = fabsf(1.0f / dp[o + W] - d0) * edge_w(ip, plane, o, o + W);
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        partials[2 * blk] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partials[2 * blk + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_smooth_finalize(const float* __restrict__ partials, int nblk, float inv_nx, float inv_ny,
+                                                        float* __restrict__ loss) {
+    __shared__ float s0[NT], s1[NT];
+    float a = 0.0f, c = 0.0f;
+    for (int i = threadIdx.x; i < nblk; i += NT) { a += partials[2 * i]; c += partials[2 * i + 1]; }
+    s0[threadIdx.x] = a; s1[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s0[threadIdx.x] += s0[threadIdx.x + o]; s1[threadIdx.x] += s1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s0[0] * inv_nx + s1[0] * inv_ny;
+}
+
+// backward, gather form (deterministic): a pixel collects from its up to four incident pairs
+__global__ __launch_bounds__(NT) void k_smooth_bwd(const float* __restrict__ depth, const float* __restrict__ img, int H, int W,
+                                                   float inv_nx, float inv_ny, const float* __restrict__ grad_loss,
+                                                   float* __restrict__ d_depth) {
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (o >= plane) return;
+    const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
+    const float* dp = depth + (size_t)b * plane;
+    const float* ip = img + (size_t)b * 3 * plane;
+    const float dep = dp[o];
+    const float d0 = 1.0f / dep;
+    float gd = 0.0f;                      // d loss / d disp[o]
+    if (u + 1 < W) gd -= sgnf(1.0f / dp[o + 1] - d0) * edge_w(ip, plane, o, o + 1) * inv_nx;
+    if (u >= 1) gd += sgnf(d0 - 1.0f / dp[o - 1]) * edge_w(ip, plane, o - 1, o) * inv_nx;
+    if (v + 1 < H) gd -= sgnf(1.0f / dp[o + W] - d0) * edge_w(ip, plane, o, o + W) * inv_ny;
+    if (v >= 1) gd += sgnf(d0 - 1.0f / dp[o - W]) * edge_w(ip, plane, o - W, o) * inv_ny;
+    d_depth[(size_t)b * plane + o] = grad_loss[0] * gd * (-d0 * d0);
+}
+
+__global__ __launch_bounds__(NT) void k_avgpool2_fwd(const float* __restrict__ x, int Ho, int Wo, float* __restrict__ y) {
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (o >= (size_t)Ho * Wo) return;
+    const int v = (int)(o / Wo), u = (int)(o - (size_t)v * Wo);
+    const float* xp = x + (size_t)blockIdx.y * 4 * Ho * Wo + (size_t)(2 * v) * (2 * Wo) + 2 * u;
+    const float2 r0 = *reinterpret_cast<const float2*>(xp), r1 = *reinterpret_cast<const float2*>(xp + 2 * Wo);
+    y[(size_t)blockIdx.y * Ho * Wo + o] = 0.25f * ((r0.x + r0.y) + (r1.x + r1.y));
+}
+
+__global__ __launch_bounds__(NT) void k_avgpool2_bwd(const float* __restrict__ dy, int Ho, int Wo, float* __restrict__ dx) {
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (o >= (size_t)Ho * Wo) return;
+    const int v = (int)(o / Wo), u = (int)(o - (size_t)v * Wo);
+    const float g = 0.25f * dy[(size_t)blockIdx.y * Ho * Wo + o];
+    float* xp = dx + (size_t)blockIdx.y * 4 * Ho * Wo + (size_t)(2 * v) * (2 * Wo) + 2 * u;
+    *reinterpret_cast<float2*>(xp) = make_float2(g, g);
+    *reinterpret_cast<float2*>(xp + 2 * Wo) = make_float2(g, g);
+}
+
+
 }  // namespace
 }  // namespace colvo
 
@@ -1064,5 +1336,87 @@ extern "C" int colvo_inverse_warp(const float* ref, const float* depth, const fl
     dim3 grid((unsigned)((plane + NT - 1) / NT), B);
     hipLaunchKernelGGL(k_inverse_warp, grid, dim3(NT), 0, s, ref, depth, pose, K, C, H, W, warped, valid);
     COLVO_CHECK_LAUNCH("k_inverse_warp");
+    return 0;
+}
+
+// ---- SURVEY.md §8f-1 / §8f-2 entry points ------------------------------------------------------------------------- //
+extern "C" size_t colvo_geo_loss_workspace_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * (((size_t)H * W + NT - 1) / NT) * GEO_NP;
+}
+
+extern "C" int colvo_geo_loss_fwd(const float* depth_t, const float* depth_r, const float* pose, const float* K, int B, int H,
+                                  int W, float* workspace, float* loss_state, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(depth_t && depth_r && pose && K && workspace && loss_state, "colvo_geo_loss_fwd: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_geo_loss_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
+    hipLaunchKernelGGL(k_geo_loss_fwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, workspace);
+    COLVO_CHECK_LAUNCH("k_geo_loss_fwd");
+    hipLaunchKernelGGL(k_geo_loss_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), loss_state);
+    COLVO_CHECK_LAUNCH("k_geo_loss_finalize");
+    return 0;
+}
+
+extern "C" int colvo_geo_loss_bwd(const float* depth_t, const float* depth_r, const float* pose, const float* K, int B, int H,
+                                  int W, const float* loss_state, const float* grad_loss, float* workspace, float* d_depth_t,
+                                  float* d_depth_r, float* d_pose, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(depth_t && depth_r && pose && K && loss_state && grad_loss && workspace && d_depth_t && d_depth_r && d_pose,
+                    "colvo_geo_loss_bwd: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_geo_loss_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_depth_r, 0, (size_t)B * H * W * sizeof(float), s);
+    if (e != hipSuccess) { set_error("colvo_geo_loss_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+    const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
+    hipLaunchKernelGGL(k_geo_loss_bwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, loss_state, grad_loss,
+                       d_depth_t, d_depth_r, workspace);
+    COLVO_CHECK_LAUNCH("k_geo_loss_bwd");
+    hipLaunchKernelGGL(k_geo_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, (int)nb, pose, d_pose);
+    COLVO_CHECK_LAUNCH("k_geo_loss_bwd_finalize");
+    return 0;
+}
+
+extern "C" int colvo_smooth_loss_fwd(const float* depth, const float* img, int B, int H, int W, float* workspace, float* loss,
+                                     colvo_stream_t stream) {
+    COLVO_CHECK_ARG(depth && img && workspace && loss, "colvo_smooth_loss_fwd: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_smooth_loss_fwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
+    hipLaunchKernelGGL(k_smooth_fwd, dim3(nb, B), dim3(NT), 0, s, depth, img, H, W, workspace);
+    COLVO_CHECK_LAUNCH("k_smooth_fwd");
+    hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), 1.0f / ((float)B * H * (W - 1)),
+                       1.0f / ((float)B * (H - 1) * W), loss);
+    COLVO_CHECK_LAUNCH("k_smooth_finalize");
+    return 0;
+}
+
+extern "C" int colvo_smooth_loss_bwd(const float* depth, const float* img, int B, int H, int W, const float* grad_loss,
+                                     float* d_depth, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(depth && img && grad_loss && d_depth, "colvo_smooth_loss_bwd: null pointer argument");
+    COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_smooth_loss_bwd: bad shape");
+    const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
+    hipLaunchKernelGGL(k_smooth_bwd, dim3(nb, B), dim3(NT), 0, (hipStream_t)stream, depth, img, H, W,
+                       1.0f / ((float)B * H * (W - 1)), 1.0f / ((float)B * (H - 1) * W), grad_loss, d_depth);
+    COLVO_CHECK_LAUNCH("k_smooth_bwd");
+    return 0;
+}
+
+extern "C" int colvo_avgpool2_fwd(const float* x, int planes, int H, int W, float* y, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && y, "colvo_avgpool2_fwd: null pointer argument");
+    COLVO_CHECK_ARG(planes >= 1 && planes <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "colvo_avgpool2_fwd: H, W must be even");
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(k_avgpool2_fwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
+                       x, Ho, Wo, y);
+    COLVO_CHECK_LAUNCH("k_avgpool2_fwd");
+    return 0;
+}
+
+extern "C" int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, float* dx, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(dy && dx, "colvo_avgpool2_bwd: null pointer argument");
+    COLVO_CHECK_ARG(planes >= 1 && planes <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "colvo_avgpool2_bwd: H, W must be even");
+    const int Ho = H / 2, Wo = W / 2;
+    hipLaunchKernelGGL(k_avgpool2_bwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
+                       dy, Ho, Wo, dx);
+    COLVO_CHECK_LAUNCH("k_avgpool2_bwd");
     return 0;
 }

@@ -37,6 +37,7 @@ class _ArenaState:
         self.next = 1                   # index of the next boundary to cross
         self.low = n                    # everything in [low, n) is final
         self.calls = 0
+        self.staging = None             # persistent transport-dtype copy of the arena (reduced-precision transport only)
 
 
 class GradBuckets:
@@ -57,6 +58,11 @@ class GradBuckets:
         self._pending = []
         for m in modules:
             st = _ArenaState(m, max(1, bucket_bytes // 4), max(0, tail_bytes // 4))
+            if transport_dtype is not None and transport_dtype != m.flat_grad.dtype:
+                # ONE persistent staging arena per network: nothing is allocated inside the hooks (they run on the
+                # weight-gradient side stream; a per-call temporary would be consumed by the collective's stream and by the
+                # main stream's copy-back, with the caching allocator free to hand it out again in between)
+                st.staging = torch.empty(m.flat_grad.numel(), device=m.flat_grad.device, dtype=transport_dtype)
             self.states.append(st)
             m.grad_ready_hook = self._make_hook(st)
 
@@ -88,8 +94,9 @@ class GradBuckets:
         if hi <= lo:
             return
         sl = st.module.flat_grad[lo:hi]
-        if self.transport_dtype is not None and self.transport_dtype != sl.dtype:
-            buf = sl.to(self.transport_dtype)
+        if st.staging is not None:
+            buf = st.staging[lo:hi]
+            buf.copy_(sl)                # conversion on the stream the hook runs on; the collective is ordered after it
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append((work, sl, buf))
         else:

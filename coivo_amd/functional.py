@@ -187,6 +187,145 @@ def photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, ssim_weight: flo
     return _WarpLoss.apply(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight, getattr(depth, "_colvo_handover", None), hp)
 
 
+# ---------------------------------------------------------------------------------------------------------------------- #
+# the widened objective (spec: geometric_consistency_loss, smoothness_loss,                      #
+# multiscale_photometric_loss, dcdp_full_loss).  Optional -- BASELINE.json's metric is the plain photometric step.        #
+# ---------------------------------------------------------------------------------------------------------------------- #
+GEO_WEIGHT, SMOOTH_WEIGHT, NUM_SCALES = 0.5, 0.1, 3
+
+
+class _GeoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth_t, depth_r, pose, K):
+        lib = _lib.load()
+        B, _, H, W = depth_t.shape
+        depth_t = _chk(depth_t, "tgt_depth", (B, 1, H, W))
+        depth_r = _chk(depth_r, "ref_depth", (B, 1, H, W))
+        pose = _chk(pose, "pose", (B, 6))
+        K = _chk(K, "K", (B, 3, 3))
+        ws = torch.empty(lib.colvo_geo_loss_workspace_floats(B, H, W), device=depth_t.device, dtype=torch.float32)
+        state = torch.empty(4, device=depth_t.device, dtype=torch.float32)
+        _lib.check(lib.colvo_geo_loss_fwd(_lib.ptr(depth_t), _lib.ptr(depth_r), _lib.ptr(pose), _lib.ptr(K), B, H, W,
+                                          _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr()), "colvo_geo_loss_fwd")
+        ctx.save_for_backward(depth_t, depth_r, pose, K, state)
+        return state[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        depth_t, depth_r, pose, K, state = ctx.saved_tensors
+        B, _, H, W = depth_t.shape
+        g = grad_loss.to(torch.float32).contiguous().reshape(1)
+        ws = torch.empty(lib.colvo_geo_loss_workspace_floats(B, H, W), device=depth_t.device, dtype=torch.float32)
+        d_t, d_r, d_pose = torch.empty_like(depth_t), torch.empty_like(depth_r), torch.empty_like(pose)
+        _lib.check(lib.colvo_geo_loss_bwd(_lib.ptr(depth_t), _lib.ptr(depth_r), _lib.ptr(pose), _lib.ptr(K), B, H, W,
+                                          _lib.ptr(state), _lib.ptr(g), _lib.ptr(ws), _lib.ptr(d_t), _lib.ptr(d_r),
+                                          _lib.ptr(d_pose), _lib.stream_ptr()), "colvo_geo_loss_bwd")
+        return d_t, d_r, d_pose, None
+
+
+def geometric_consistency_loss(tgt_depth, ref_depth, pose, K) -> torch.Tensor:
+    """Masked mean of |D_proj - D_samp| / (D_proj + D_samp) -> scalar (spec: geometric_consistency_loss; README.md:1, :7).
+    Gradient reaches tgt_depth, ref_depth (float atomics: order-dependent in the last bits) and pose."""
+    return _GeoLoss.apply(tgt_depth, ref_depth, pose, K)
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, img):
+        lib = _lib.load()
+        B, _, H, W = depth.shape
+        depth = _chk(depth, "depth", (B, 1, H, W))
+        img = _chk(img, "img", (B, 3, H, W))
+        ws = torch.empty(2 * B * ((H * W + 255) // 256), device=depth.device, dtype=torch.float32)
+        loss = torch.empty(1, device=depth.device, dtype=torch.float32)
+        _lib.check(lib.colvo_smooth_loss_fwd(_lib.ptr(depth), _lib.ptr(img), B, H, W, _lib.ptr(ws), _lib.ptr(loss),
+                                             _lib.stream_ptr()), "colvo_smooth_loss_fwd")
+        ctx.save_for_backward(depth, img)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        depth, img = ctx.saved_tensors
+        B, _, H, W = depth.shape
+        g = grad_loss.to(torch.float32).contiguous().reshape(1)
+        d_depth = torch.empty_like(depth)
+        _lib.check(lib.colvo_smooth_loss_bwd(_lib.ptr(depth), _lib.ptr(img), B, H, W, _lib.ptr(g), _lib.ptr(d_depth),
+                                             _lib.stream_ptr()), "colvo_smooth_loss_bwd")
+        return d_depth, None
+
+
+def smoothness_loss(depth, img) -> torch.Tensor:
+    """Edge-aware first-order smoothness of 1/depth -> scalar (spec: smoothness_loss)."""
+    return _SmoothLoss.apply(depth, img)
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+            raise RuntimeError("downsample2: expects a float32 CUDA tensor [B,C,H,W] (no CPU fallback)")
+        B, C, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError("downsample2: H and W must be even")
+        x = x.contiguous()
+        y = torch.empty(B, C, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        _lib.check(lib.colvo_avgpool2_fwd(_lib.ptr(x), B * C, H, W, _lib.ptr(y), _lib.stream_ptr()), "colvo_avgpool2_fwd")
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        B, C, H, W = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, C, H, W, device=dy.device, dtype=torch.float32)
+        _lib.check(lib.colvo_avgpool2_bwd(_lib.ptr(dy), B * C, H, W, _lib.ptr(dx), _lib.stream_ptr()), "colvo_avgpool2_bwd")
+        return dx
+
+
+def downsample2(x: torch.Tensor) -> torch.Tensor:
+    """2x2 average pooling (spec: downsample2)."""
+    return _AvgPool2.apply(x)
+
+
+def scale_intrinsics(K: torch.Tensor) -> torch.Tensor:
+    """Intrinsics of the 2x2-pooled image (spec: scale_intrinsics; pixel centres on integers)."""
+    K2 = K.clone()
+    K2[:, 0, 0] = K[:, 0, 0] * 0.5
+    K2[:, 1, 1] = K[:, 1, 1] * 0.5
+    K2[:, 0, 2] = (K[:, 0, 2] - 0.5) * 0.5
+    K2[:, 1, 2] = (K[:, 1, 2] - 0.5) * 0.5
+    return K2
+
+
+def multiscale_photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, num_scales: int = NUM_SCALES,
+                                ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
+    """Mean over scales of the fused photometric loss on 2x2-pooled frames / depth (spec: multiscale_photometric_loss).
+    Every scale is one launch of the same fused kernel (algorithmic bytes 60 * pixels / 4^s)."""
+    total = photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight=ssim_weight)
+    for _ in range(1, num_scales):
+        with torch.no_grad():
+            tgt, ref, K = downsample2(tgt), downsample2(ref), scale_intrinsics(K)
+        depth = downsample2(depth)
+        total = total + photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight=ssim_weight)
+    return total / num_scales
+
+
+def dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, *, geo_weight: float = GEO_WEIGHT,
+                   smooth_weight: float = SMOOTH_WEIGHT, num_scales: int = NUM_SCALES,
+                   ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
+    """Multi-scale photometric + geo_weight * geometric consistency + smooth_weight * smoothness (spec: dcdp_full_loss)."""
+    loss = multiscale_photometric_loss(tgt, ref, d_t, pose, K, lcc_a, lcc_b, num_scales=num_scales, ssim_weight=ssim_weight)
+    if geo_weight:
+        loss = loss + geo_weight * geometric_consistency_loss(d_t, d_r, pose, K)
+    if smooth_weight:
+        loss = loss + smooth_weight * smoothness_loss(d_t, tgt)
+    return loss
+
+
 def inverse_warp(ref, depth, pose, K):
     """Un-fused debugging entry (spec: inverse_warp) -> (warped [B,C,H,W], valid [B,1,H,W]); no autograd."""
     lib = _lib.load()

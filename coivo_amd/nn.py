@@ -348,6 +348,19 @@ class _ArenaModule(nn.Module):
         return t
 
 
+def _dealias(tensors):
+    """Externals of a recorded pass are matched by address: two per-call tensors that alias (pose_net(x, x); autograd
+    handing one tensor as two gradients) would be indistinguishable, so later duplicates get a private copy."""
+    seen, out = set(), []
+    for t in tensors:
+        if t is not None and t.data_ptr() in seen:
+            t = t.clone()
+        if t is not None:
+            seen.add(t.data_ptr())
+        out.append(t)
+    return out
+
+
 class _PassInst:
     """The recorded passes of one network at one shape, with the activation buffers they refer to.  `busy` from a
     forward that may still get a backward until that backward ran (or its autograd context died): a second forward
@@ -488,7 +501,7 @@ class DepthNet(_ArenaModule):
             ext = {"depth": depth, "d_depth": d_depth}
             which = "bwd"
         else:
-            parts = tuple(None if t is None else t.contiguous() for t in parts)
+            parts = tuple(_dealias([None if t is None else t.contiguous() for t in parts]))
             names = ("g_first", "g_second", "g_raw", "scale_a", "scale_b")
             ext = {"depth": depth}
             ext.update({n: t for n, t in zip(names, parts) if t is not None})
@@ -623,7 +636,7 @@ class PoseNet(_ArenaModule):
         self._prepare_weights()
         dt = self.compute_dtype
         has_depth = d_t is not None
-        srcs = [tgt.contiguous(), ref.contiguous()] + ([d_t.contiguous(), d_r.contiguous()] if has_depth else [])
+        srcs = _dealias([tgt.contiguous(), ref.contiguous()] + ([d_t.contiguous(), d_r.contiguous()] if has_depth else []))
         key = (B, H, W, dt)
         P = self._plans.get(key)
         if P is None:
@@ -655,6 +668,7 @@ class PoseNet(_ArenaModule):
         dev = self.flat_param.device
         grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}
         grads = {k: v.contiguous() for k, v in grads.items() if v is not None}
+        grads = dict(zip(grads.keys(), _dealias(list(grads.values()))))
         d_t = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
         d_r = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
 
@@ -706,9 +720,17 @@ class _PoseNetFn(torch.autograd.Function):
         return None, None, None, d_t, d_r, None, None
 
 
-def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85):
-    """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss."""
-    from .functional import photometric_loss
+def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85, full_loss: bool = False):
+    """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss
+    (full_loss: the widened objective dcdp_full_loss -- multi-scale photometric + geometric consistency + smoothness)."""
+    from .functional import dcdp_full_loss, photometric_loss
+    if full_loss:
+        # several consumers of the depth and pose tensors: ordinary autograd accumulation (no gradient hand-over)
+        d_t, d_r = depth_net.forward_pair(torch.cat([tgt, ref], dim=0))
+        pose, a, b = pose_net(tgt, ref, d_t, d_r)
+        pose, a, b = pose * 1.0, a * 1.0, b * 1.0        # plain tensors: the loss takes its general path
+        loss = dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, a, b, ssim_weight=ssim_weight)
+        return loss, d_t, d_r, pose, a, b
     d_t, d_r, d_l = depth_net.forward_pair_split(torch.cat([tgt, ref], dim=0))
     pose, a, b = pose_net(tgt, ref, d_t, d_r)
     loss = photometric_loss(tgt, ref, d_l, pose, K, a, b, ssim_weight=ssim_weight)     # d_l aliases d_t (its own grad path)

@@ -83,6 +83,33 @@ int colvo_warp_loss_fused_bwd_params(const float* loss_state, const float* grad_
                                      const float* pose, int B, float* d_pose, float* d_a, float* d_b,
                                      colvo_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------- *
+ * SURVEY.md §8f-1  geometric consistency (README.md:1 "Considering Geometric and Photometric   *
+ *   Consistency", :7 "alignment of geometric projections").  spec: geometric_consistency_loss. *
+ * ------------------------------------------------------------------------------------------- */
+/* depth_t, depth_r [B,1,H,W]; pose [B,6]; K [B,3,3].  loss_state[4] = { loss, 1/max(n_valid,1), n_valid, 0 }.
+ * workspace: colvo_geo_loss_workspace_floats(B,H,W) floats.  Backward recomputes the forward; d_depth_r is zeroed by the
+ * call and accumulated with float atomics (the four taps of every sample). */
+size_t colvo_geo_loss_workspace_floats(int B, int H, int W);
+int colvo_geo_loss_fwd(const float* depth_t, const float* depth_r, const float* pose, const float* K,
+                       int B, int H, int W, float* workspace, float* loss_state, colvo_stream_t stream);
+int colvo_geo_loss_bwd(const float* depth_t, const float* depth_r, const float* pose, const float* K,
+                       int B, int H, int W, const float* loss_state, const float* grad_loss, float* workspace,
+                       float* d_depth_t, float* d_depth_r, float* d_pose, colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * SURVEY.md §8f-2  edge-aware smoothness of the inverse depth (spec: smoothness_loss) and the  *
+ *   2x2 average pooling of the multi-scale photometric term (spec: downsample2).               *
+ * ------------------------------------------------------------------------------------------- */
+/* depth [B,1,H,W], img [B,3,H,W]; workspace: 2 * B * ceil(H*W/256) floats; loss: one device float. */
+int colvo_smooth_loss_fwd(const float* depth, const float* img, int B, int H, int W, float* workspace, float* loss,
+                          colvo_stream_t stream);
+int colvo_smooth_loss_bwd(const float* depth, const float* img, int B, int H, int W, const float* grad_loss,
+                          float* d_depth, colvo_stream_t stream);
+/* x [planes,H,W] -> y [planes,H/2,W/2] (mean of each 2x2 block), and its gradient dy -> dx (H, W: the INPUT extent). */
+int colvo_avgpool2_fwd(const float* x, int planes, int H, int W, float* y, colvo_stream_t stream);
+int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, float* dx, colvo_stream_t stream);
+
 /* Un-fused debugging entry (spec: inverse_warp()).  ref [B,C,H,W] -> warped [B,C,H,W], valid [B,1,H,W]. */
 int colvo_inverse_warp(const float* ref, const float* depth, const float* pose, const float* K,
                        int B, int C, int H, int W, float* warped, float* valid, colvo_stream_t stream);

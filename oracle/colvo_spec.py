@@ -205,6 +205,101 @@ def photometric_loss(tgt: torch.Tensor, ref: torch.Tensor, depth: torch.Tensor, 
 
 
 # --------------------------------------------------------------------------- #
+# §8f-1: geometric consistency (README.md:1 "Considering Geometric and         #
+#        Photometric Consistency", :7 "loss function constraints ... alignment #
+#        of geometric projections between consecutive frames")                 #
+# --------------------------------------------------------------------------- #
+GEO_WEIGHT = 0.5         # weight of the geometric-consistency term in the widened DCDP loss
+SMOOTH_WEIGHT = 0.1      # weight of the edge-aware smoothness term
+NUM_SCALES = 3           # scales of the multi-scale photometric term (full, 1/2, 1/4)
+
+
+def geometric_consistency_loss(tgt_depth: torch.Tensor, ref_depth: torch.Tensor, pose: torch.Tensor,
+                               K: torch.Tensor) -> torch.Tensor:
+    """Masked mean of |D_proj - D_samp| / (D_proj + D_samp) -> scalar.
+
+    Every target pixel is back-projected with `tgt_depth`, moved by `pose` and projected into the reference frame
+    (project()).  D_proj is the z of that point in the reference camera; D_samp is the reference frame's OWN depth
+    prediction, bilinearly sampled where the point lands (bilinear_sample(), same border / validity rule as the
+    image warp).  Both depth maps and the pose receive gradient: through D_proj (depth, pose), through the sample
+    position (depth, pose) and through the sampled taps (ref_depth).  tgt_depth, ref_depth [B,1,H,W]; pose [B,6]."""
+    B, _, H, W = tgt_depth.shape
+    x, y, valid = project(tgt_depth, pose, K)
+    fx, fy = K[:, 0, 0].view(B, 1, 1), K[:, 1, 1].view(B, 1, 1)
+    cx, cy = K[:, 0, 2].view(B, 1, 1), K[:, 1, 2].view(B, 1, 1)
+    dt, dev = tgt_depth.dtype, tgt_depth.device
+    u = torch.arange(W, dtype=dt, device=dev).view(1, 1, W)
+    v = torch.arange(H, dtype=dt, device=dev).view(1, H, 1)
+    d = tgt_depth[:, 0]
+    T = pose_vec2mat(pose)
+    R, t = T[:, :, :3], T[:, :, 3]
+    X, Y = (u - cx) / fx * d, (v - cy) / fy * d
+    d_proj = (R[:, 2, 0].view(B, 1, 1) * X + R[:, 2, 1].view(B, 1, 1) * Y + R[:, 2, 2].view(B, 1, 1) * d
+              + t[:, 2].view(B, 1, 1))
+    d_samp = bilinear_sample(ref_depth, x, y, valid)[:, 0]
+    m = valid.to(dt)
+    num = (d_proj - d_samp).abs()
+    den = torch.where(valid, d_proj + d_samp, torch.ones_like(d_proj))
+    return (num / den * m).sum() / m.sum().clamp(min=1.0)
+
+
+# --------------------------------------------------------------------------- #
+# §8f-2: edge-aware smoothness and the multi-scale photometric term           #
+#        ([ASSUMED] convention of the method family, SPEC.md §8)              #
+# --------------------------------------------------------------------------- #
+def smoothness_loss(depth: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
+    """Edge-aware first-order smoothness of the inverse depth -> scalar.
+
+    mean_x |disp[x+1] - disp[x]| * exp(-mean_c |I[x+1] - I[x]|)  +  the same along y,  disp = 1 / depth;
+    each mean runs over all neighbour pairs of the batch.  depth [B,1,H,W] (> 0), img [B,3,H,W] (no gradient)."""
+    disp = 1.0 / depth
+    ddx = (disp[..., :, 1:] - disp[..., :, :-1]).abs()
+    ddy = (disp[..., 1:, :] - disp[..., :-1, :]).abs()
+    wx = torch.exp(-(img[..., :, 1:] - img[..., :, :-1]).abs().mean(dim=1, keepdim=True))
+    wy = torch.exp(-(img[..., 1:, :] - img[..., :-1, :]).abs().mean(dim=1, keepdim=True))
+    return (ddx * wx).mean() + (ddy * wy).mean()
+
+
+def downsample2(x: torch.Tensor) -> torch.Tensor:
+    """2x2 average pooling (H, W even)."""
+    return F.avg_pool2d(x, 2, 2)
+
+
+def scale_intrinsics(K: torch.Tensor) -> torch.Tensor:
+    """Intrinsics of the 2x2-average-pooled image (pixel centres on integers: u = 2 u' + 1/2)."""
+    K2 = K.clone()
+    K2[:, 0, 0] = K[:, 0, 0] * 0.5
+    K2[:, 1, 1] = K[:, 1, 1] * 0.5
+    K2[:, 0, 2] = (K[:, 0, 2] - 0.5) * 0.5
+    K2[:, 1, 2] = (K[:, 1, 2] - 0.5) * 0.5
+    return K2
+
+
+def multiscale_photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, num_scales: int = NUM_SCALES,
+                                ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
+    """Mean over `num_scales` scales of photometric_loss on 2x2-average-pooled frames, depth and scaled intrinsics
+    (scale 0 = full resolution).  H, W divisible by 2^(num_scales-1)."""
+    total = photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight=ssim_weight)
+    for _ in range(1, num_scales):
+        tgt, ref, depth, K = downsample2(tgt), downsample2(ref), downsample2(depth), scale_intrinsics(K)
+        total = total + photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight=ssim_weight)
+    return total / num_scales
+
+
+def dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, *, geo_weight: float = GEO_WEIGHT,
+                   smooth_weight: float = SMOOTH_WEIGHT, num_scales: int = NUM_SCALES,
+                   ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
+    """The widened DCDP objective: multi-scale photometric + geo_weight * geometric consistency
+    + smooth_weight * edge-aware smoothness of the target depth."""
+    loss = multiscale_photometric_loss(tgt, ref, d_t, pose, K, lcc_a, lcc_b, num_scales=num_scales, ssim_weight=ssim_weight)
+    if geo_weight:
+        loss = loss + geo_weight * geometric_consistency_loss(d_t, d_r, pose, K)
+    if smooth_weight:
+        loss = loss + smooth_weight * smoothness_loss(d_t, tgt)
+    return loss
+
+
+# --------------------------------------------------------------------------- #
 # a1: DepthNet (encoder-decoder), a2: PoseNet (DCDP coupling + LCC head)      #
 # --------------------------------------------------------------------------- #
 def disp_to_depth(sig: torch.Tensor) -> torch.Tensor:
@@ -307,8 +402,10 @@ class PoseNet(nn.Module):
 # the DCDP + LCC training step                                                #
 # --------------------------------------------------------------------------- #
 def dcdp_forward(depth_net: nn.Module, pose_net: nn.Module, tgt, ref, K, *,
-                 ssim_weight: float = SSIM_WEIGHT):
-    """One coupled forward:  depth of both frames -> pose + LCC -> photometric loss.
+                 ssim_weight: float = SSIM_WEIGHT, full_loss: bool = False):
+    """One coupled forward:  depth of both frames -> pose + LCC -> photometric loss
+    (full_loss: the widened objective dcdp_full_loss instead -- multi-scale photometric + geometric consistency
+    + smoothness; the round-1 hot path and BASELINE.json's metric use the plain photometric loss).
 
     Returns (loss, tgt_depth, ref_depth, pose, lcc_a, lcc_b).
     """
@@ -316,7 +413,10 @@ def dcdp_forward(depth_net: nn.Module, pose_net: nn.Module, tgt, ref, K, *,
     d = depth_net(torch.cat([tgt, ref], dim=0))
     d_t, d_r = d[:B], d[B:]
     pose, a, b = pose_net(tgt, ref, d_t, d_r)
-    loss = photometric_loss(tgt, ref, d_t, pose, K, a, b, ssim_weight=ssim_weight)
+    if full_loss:
+        loss = dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, a, b, ssim_weight=ssim_weight)
+    else:
+        loss = photometric_loss(tgt, ref, d_t, pose, K, a, b, ssim_weight=ssim_weight)
     return loss, d_t, d_r, pose, a, b
 
 

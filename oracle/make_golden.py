@@ -81,6 +81,36 @@ def net_case(name, B, H, W, seed):
     print(name, "loss", loss.item(), "fp64", loss64.item(), "gradient digests", len(digests) // 3)
 
 
+def terms_case(name, B, H, W, seed):
+    """Inputs + values + gradients of the widened-objective terms (SPEC.md §6b): geometric consistency, smoothness,
+    multi-scale photometric."""
+    b = synth.make_batch(B, H, W, seed=seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    d_t = (b["gt_depth"] * (1 + 0.05 * torch.randn(B, 1, H, W, generator=g))).clamp(0.2, 9.0)
+    d_r = (b["gt_depth"] * (1 + 0.05 * torch.randn(B, 1, H, W, generator=g))).clamp(0.2, 9.0)
+    pose = b["gt_pose"] + 0.005 * torch.randn(B, 6, generator=g)
+    a, bb = b["gt_a"].clone(), b["gt_b"].clone()
+    lt, lr, lp, la, lb = (t.clone().requires_grad_(True) for t in (d_t, d_r, pose, a, bb))
+    geo = S.geometric_consistency_loss(lt, lr, lp, b["K"])
+    ggeo = torch.autograd.grad(geo, (lt, lr, lp))
+    sm = S.smoothness_loss(lt, b["tgt"])
+    gsm = torch.autograd.grad(sm, lt)[0]
+    ms = S.multiscale_photometric_loss(b["tgt"], b["ref"], lt, lp, b["K"], la, lb)
+    gms = torch.autograd.grad(ms, (lt, lp, la, lb))
+    full = S.dcdp_full_loss(b["tgt"], b["ref"], lt, lr, lp, b["K"], la, lb)
+    gfull = torch.autograd.grad(full, (lt, lr, lp, la, lb))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        tgt=b["tgt"].numpy(), ref=b["ref"].numpy(), K=b["K"].numpy(), depth_t=d_t.numpy(), depth_r=d_r.numpy(),
+        pose=pose.numpy(), lcc_a=a.numpy(), lcc_b=bb.numpy(),
+        geo=np.float32(geo.item()), geo_d_t=ggeo[0].numpy(), geo_d_r=ggeo[1].numpy(), geo_d_pose=ggeo[2].numpy(),
+        smooth=np.float32(sm.item()), smooth_d_t=gsm.numpy(),
+        ms=np.float32(ms.item()), ms_d_t=gms[0].numpy(), ms_d_pose=gms[1].numpy(), ms_d_a=gms[2].numpy(), ms_d_b=gms[3].numpy(),
+        full=np.float32(full.item()), full_d_t=gfull[0].numpy(), full_d_r=gfull[1].numpy(), full_d_pose=gfull[2].numpy(),
+        full_d_a=gfull[3].numpy(), full_d_b=gfull[4].numpy())
+    print(name, "geo", geo.item(), "smooth", sm.item(), "ms", ms.item(), "full", full.item())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # one thread: bit-stable reductions
@@ -88,5 +118,6 @@ if __name__ == "__main__":
     loss_case("loss_b2_64x96", 2, 64, 96, seed=12)
     loss_case("loss_b1_256x320", 1, 256, 320, seed=13)
     loss_case("loss_b2_33x47_ragged", 2, 33, 47, seed=14)   # not tile-aligned
+    terms_case("terms_b2_48x64", 2, 48, 64, seed=15)
     net_case("net_b2_64x96", 2, 64, 96, seed=21)
     net_case("net_b1_32x64", 1, 32, 64, seed=22)

@@ -118,6 +118,53 @@ def test_loss_gradcheck_fp64():
     assert torch.autograd.gradcheck(f, (depth, pose, a, bb), eps=1e-6, atol=1e-5, rtol=1e-3, nondet_tol=0)
 
 
+def test_geometric_consistency_known_answers_and_gradcheck():
+    """Identity pose + identical depth maps -> 0; a uniform 10 % depth mismatch -> |1 - 1.1| / 2.1; fp64 gradcheck."""
+    B, H, W = 2, 16, 20
+    b = synth.make_batch(B, H, W, seed=8, dtype=torch.float64)
+    pose0 = torch.zeros(B, 6, dtype=torch.float64)
+    d = b["gt_depth"]
+    assert S.geometric_consistency_loss(d, d, pose0, b["K"]).item() < 1e-12
+    const = torch.full_like(d, 2.0)
+    v = S.geometric_consistency_loss(const, 1.1 * const, pose0, b["K"]).item()
+    assert abs(v - 0.1 / 2.1) < 1e-12
+    dt = (d * 1.03).clone().requires_grad_(True)
+    dr = (d * 0.98).clone().requires_grad_(True)
+    pose = (b["gt_pose"] * 0.5).clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a, c, p: S.geometric_consistency_loss(a, c, p, b["K"]), (dt, dr, pose),
+                                    eps=1e-6, atol=1e-6, rtol=1e-3, nondet_tol=0)
+
+
+def test_smoothness_known_answers_and_gradcheck():
+    """Constant depth -> 0; a linear disparity ramp on a flat image -> its slope; edges in the image damp the penalty."""
+    B, H, W = 1, 8, 12
+    img = torch.full((B, 3, H, W), 0.5, dtype=torch.float64)
+    assert S.smoothness_loss(torch.full((B, 1, H, W), 3.0, dtype=torch.float64), img).item() == 0.0
+    disp = (1.0 + 0.01 * torch.arange(W, dtype=torch.float64)).view(1, 1, 1, W).expand(B, 1, H, W)
+    assert abs(S.smoothness_loss(1.0 / disp, img).item() - 0.01) < 1e-12
+    edgy = img.clone(); edgy[..., ::2] = 1.0
+    assert S.smoothness_loss(1.0 / disp, edgy).item() < 0.01 * 0.62
+    b = synth.make_batch(B, H, W, seed=9, dtype=torch.float64)
+    d = b["gt_depth"].clone().requires_grad_(True)
+    assert torch.autograd.gradcheck(lambda a: S.smoothness_loss(a, b["tgt"]), (d,), eps=1e-6, atol=1e-7, rtol=1e-3)
+
+
+def test_multiscale_and_full_loss():
+    """Scale 0 alone is the plain loss; pooled intrinsics keep a fronto-parallel translation consistent across scales;
+    the widened objective has gradients into both depth maps."""
+    B, H, W = 1, 32, 48
+    b = synth.make_batch(B, H, W, seed=10)
+    args = (b["tgt"], b["ref"], b["gt_depth"], b["gt_pose"], b["K"], b["gt_a"], b["gt_b"])
+    assert torch.equal(S.multiscale_photometric_loss(*args, num_scales=1), S.photometric_loss(*args))
+    assert S.multiscale_photometric_loss(*args, num_scales=3).item() > 0
+    K2 = S.scale_intrinsics(b["K"])
+    assert torch.allclose(K2[:, 0, 2], (b["K"][:, 0, 2] - 0.5) / 2) and torch.allclose(K2[:, 0, 0], b["K"][:, 0, 0] / 2)
+    d_t = b["gt_depth"].clone().requires_grad_(True)
+    d_r = (b["gt_depth"] * 1.02).clone().requires_grad_(True)
+    S.dcdp_full_loss(b["tgt"], b["ref"], d_t, d_r, b["gt_pose"], b["K"], b["gt_a"], b["gt_b"]).backward()
+    assert d_t.grad.abs().max() > 0 and d_r.grad.abs().max() > 0
+
+
 def test_depthnet_posenet_shapes_and_ranges():
     dn, pn = S.make_models(0)
     b = synth.make_batch(2, 32, 64, seed=6)
@@ -155,6 +202,24 @@ def test_golden_loss(golden_dir, name):
     for gr, k in zip(grads, ("d_depth", "d_pose", "d_a", "d_b")):
         ref = t[k]
         assert torch.allclose(gr, ref, rtol=1e-4, atol=1e-6 * max(1.0, ref.abs().max().item())), k
+
+
+@pytest.mark.parametrize("name", ["terms_b2_48x64"])
+def test_golden_terms(golden_dir, name):
+    """Golden replay of the widened-objective terms (oracle/make_golden.py terms_case)."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    t = {k: torch.from_numpy(np.asarray(g[k])) for k in g.files}
+    dt, dr, pose = (t[k].clone().requires_grad_(True) for k in ("depth_t", "depth_r", "pose"))
+    geo = S.geometric_consistency_loss(dt, dr, pose, t["K"])
+    assert abs(geo.item() - float(g["geo"])) < 1e-6
+    gg = torch.autograd.grad(geo, (dt, dr, pose))
+    for got, k in zip(gg, ("geo_d_t", "geo_d_r", "geo_d_pose")):
+        assert torch.allclose(got, t[k], rtol=1e-4, atol=1e-6 * max(1.0, t[k].abs().max().item())), k
+    sm = S.smoothness_loss(dt, t["tgt"])
+    assert abs(sm.item() - float(g["smooth"])) < 1e-7
+    assert torch.allclose(torch.autograd.grad(sm, dt)[0], t["smooth_d_t"], rtol=1e-4, atol=1e-8)
+    ms = S.multiscale_photometric_loss(t["tgt"], t["ref"], dt, pose, t["K"], t["lcc_a"], t["lcc_b"])
+    assert abs(ms.item() - float(g["ms"])) < 1e-6
 
 
 @pytest.mark.parametrize("name", ["net_b2_64x96", "net_b1_32x64"])

@@ -92,3 +92,22 @@ def test_no_grad_forward_releases_its_instance_and_dtype_switch_rerecords():
     dn.compute_dtype = torch.float32
     y4 = dn(x).detach()
     assert torch.equal(y4, y2)
+
+
+def test_aliasing_arguments_record_and_replay():
+    """pose_net(x, x): the two frame arguments share one address; the recorded pass must not confuse them, and a later
+    call with distinct frames must patch both."""
+    from coivo_amd import nn as hnn
+    from oracle import colvo_spec as S
+    _, pn_o = S.make_models(3)
+    pn = hnn.PoseNet()
+    pn.load_state_dict(pn_o.state_dict())
+    b = synth.make_batch(2, 64, 96, seed=3)
+    x, y = b["tgt"].to(dev()), b["ref"].to(dev())
+    with torch.no_grad():
+        po = pn_o(b["tgt"], b["tgt"])[0]
+        ph = pn(x, x)[0]
+        assert (ph.cpu() - po).abs().max().item() < 1e-6
+        po2 = pn_o(b["tgt"], b["ref"])[0]
+        ph2 = pn(x, y)[0]
+        assert (ph2.cpu() - po2).abs().max().item() < 1e-6

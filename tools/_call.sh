@@ -1,7 +1,4 @@
+set -x
 mkdir -p gpurun_out
-export COLVO_NO_PERSIST=1
-for W in 0 1; do
-  echo "######## COLVO_WIDE=$W" 
-  COLVO_WIDE=$W bash tools/ablate_conv.sh run 16
-done > gpurun_out/r2_ablate_conv.log 2>&1
-tail -3 gpurun_out/r2_ablate_conv.log
+timeout -k 10 900 python -m pytest tests/test_terms_gpu.py tests/test_warp_loss_gpu.py -q -m gpu > gpurun_out/r2_tests_9.log 2>&1
+tail -30 gpurun_out/r2_tests_9.log
