@@ -23,10 +23,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
          "-fno-gpu-rdc", "-DNDEBUG",
          # CDNA4 executes packed f32 (v_pk_*_f32) at the plain-op rate, so SLP packing only adds the
          # v_mov pairs that feed it (measured: fused-loss fwd 112 -> 47 VGPRs, -21 % VALU without it)
-         "-fno-slp-vectorize",
-         # MFMA accumulators in VGPRs, never AGPRs: conv.hip's mfma_result_guard() ties them to an asm statement with "+v",
-         # and an AGPR accumulator would be copied out (= read) in front of that statement (profiles/r2_mfma_hazard.md)
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-fno-slp-vectorize"]
+# per-file extras.  conv.hip: MFMA accumulators in VGPRs, never AGPRs -- its mfma_result_guard() ties them to an asm
+# statement with "+v", and an AGPR accumulator would be copied out (= read) in front of that statement
+# (profiles/r2_mfma_hazard.md).  wgrad.hip keeps AGPR accumulators (faster pixel loop) and ties them with "+a".
+FILE_FLAGS = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _deps():
@@ -43,7 +44,7 @@ def _stale(out, srcs):
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if _stale(obj, [src] + _deps()):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -66,7 +67,7 @@ def source_hash() -> str:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -86,7 +87,7 @@ def ensure() -> str:
 def emit_asm(src_name: str, out: str) -> str:
     """gfx950 ISA listing of one csrc file with the library's flags (tools/isa_check_mfma.py, tests/test_isa_cpu.py)."""
     src = os.path.join(CSRC, src_name)
-    cmd = [HIPCC] + [f for f in FLAGS if f != "-fPIC"] + ["--offload-device-only", "-S", src, "-o", out]
+    cmd = [HIPCC] + [f for f in FLAGS if f != "-fPIC"] + FILE_FLAGS.get(src_name, []) + ["--offload-device-only", "-S", src, "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -103,7 +104,7 @@ def build(force: bool = False) -> str:
             os.remove(f)
     # objects are keyed by the hash of their own inputs (mtimes do not survive a copy of the tree)
     stamp = os.path.join(OBJDIR, "flags.txt")
-    flags_now = " ".join(FLAGS)
+    flags_now = " ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))
     if not os.path.exists(stamp) or open(stamp).read() != flags_now:
         for f in glob.glob(os.path.join(OBJDIR, "*.o")):
             os.remove(f)

@@ -33,180 +33,11 @@
 //     the sums of the whole range stay in MFMA accumulators, then ONE fp32 atomic add per element.
 //   - both operands have the reduction index (pixel) as the slow LDS dimension: bf16 fragments are
 //     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
-#include <algorithm>
-#include <stdlib.h>
-#include <vector>
-
-#include "common.h"
+#define COLVO_ACC_CONSTRAINT "+v"     // built with -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py)
+#include "conv_common.h"
 
 namespace colvo {
 namespace {
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-
-struct bf16_t { uint16_t v; };
-
-template <typename T> struct TT;
-template <> struct TT<float> { static constexpr int G = 4; static constexpr int ES = 4; };
-template <> struct TT<bf16_t> { static constexpr int G = 8; static constexpr int ES = 2; };
-
-constexpr int NT = 256;
-constexpr int BM = 128;   // output pixels per workgroup (4 waves x 2 fragments x 16 rows)
-
-// LDS pitches.  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (not in
-// contiguous 16-lane groups): 8 lanes of one k-group plus 8 lanes of the next one (+16 B).  With a pitch of r
-// 16-byte slots per fragment row the group is conflict-free iff {r*l mod 16} are distinct EVEN slots for the 8 rows
-// of a half: r = 6 (96 B) for 64-byte payloads, r = 2 (32 B, no padding) for 32-byte payloads.
-// In general any pitch of r slots with r = 2 (mod 4) works: {r*l mod 16} are then 8 distinct even slots for the 8 rows
-// of a half group, and the other k-group sits on the odd slots.
-constexpr int pitch_slots(int n) { return n + ((2 - n % 4) + 4) % 4; }
-constexpr int pitch_bytes(int payload) { return pitch_slots(payload / 16) * 16; }
-constexpr int wrow_bytes(int granules) { return pitch_slots(granules) * 16; }
-
-enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
-
-struct Gather {               // how the (virtual) conv input is read from the stored sources
-    const char* src[2];
-    int C[2];
-    int Hs[2], Ws[2];
-    int mode[2];
-    int Hi, Wi;               // virtual input extent (zero outside)
-    int stride;
-};
-
-struct ConvK {
-    Gather g;
-    int Ho, Wo;               // conv output extent
-    const char* w;            // [N][9][Ctot]
-    int Ctot, N;
-    const float* bias;
-    int relu;
-    char* out;                // [B][Ho(/2)][Wo(/2)][N]
-    const char* mask;         // same shape as out or null
-    int accumulate, pool2;
-    int toh, tow, tiles_x, tiles_y;
-    uint32_t m_pw, m_tow;     // ceil(2^32 / patch width), ceil(2^32 / tow): index / d == umulhi(index, m) for index < 2^16
-#ifdef COLVO_ABLATE
-    int abl;                  // developer build only (tools/ablate_conv.sh): bit mask of kernel phases to skip
-    long long* trace;         // developer build only: [workgroup][8] wall-clock stamps (100 MHz) of the kernel phases
-#endif
-};
-
-#ifdef COLVO_ABLATE
-#define ABL(bit) ((a.abl & (bit)) != 0)
-#define TRACE(slot)                                                                                       \
-    do {                                                                                                  \
-        if (a.trace && threadIdx.x == 0)                                                                  \
-            a.trace[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = \
-                (long long)wall_clock64();                                                                \
-    } while (0)
-#else
-#define ABL(bit) false
-#define TRACE(slot) do {} while (0)
-#endif
-
-struct WgradK {
-    Gather g;
-    int Ho, Wo, B;
-    const char* dy;           // [B][Ho][Wo][Cout]
-    int Cout;
-    float* dw;                // [Cout][9][Ctot]
-    int Ctot;
-    float* db;
-    int toh, tow, tiles_x, tiles_y, ntiles, tiles_per_split;
-    uint32_t m_pw, m_tow;     // see ConvK
-};
-
-// i / d for 0 <= i < 2^16, 2 <= d < 2^16 with m = ceil(2^32 / d): one v_mul_hi_u32 instead of the ~35-instruction
-// runtime division (the address set-up of a workgroup was most of its VALU time)
-__device__ __forceinline__ int mdiv(int i, uint32_t m) { return (int)__umulhi((uint32_t)i, m); }
-inline uint32_t mdiv_magic(int d) { return (uint32_t)((0x100000000ULL + (uint32_t)d - 1) / (uint32_t)d); }
-
-// Accumulator hand-over from the MFMA chain to the epilogue.
-//
-// hipcc's register allocator sometimes ROTATES the accumulators of a chain, i.e. emits MFMAs whose vDst is not their SrcC
-// (`v_mfma a[4:7], .., .., a[8:11]`).  Measured on MI355X (tools/ubench/mfma_hazard.hip, profiles/r2_mfma_hazard.md):
-//   * in-place MFMAs (vDst == SrcC): v_mfma_f32_16x16x4_f32 results are hardware-interlocked against VALU reads (correct
-//     with ZERO wait states); v_mfma_f32_16x16x32_bf16 results need the 7 wait states of LLVM's table -- hipcc is right;
-//   * rotated MFMAs: NOT interlocked; the f32 form needs >= 10, the bf16 form >= 8 wait states in a 2-waves-per-SIMD
-//     micro-benchmark -- hipcc inserts 10 / 7, i.e. no margin / one too few -- and in the real f32 persistent kernel a
-//     read 13 states after a rotated MFMA still came back stale in a few lanes (the round-1 "stale accumulator" bug).
-// A wait-state pad cannot be sized for that, so the chain is closed with one IN-PLACE MFMA per accumulator
-// (acc = 0 * 0 + acc, vDst tied to SrcC by the asm constraint): the SrcC hand-over from a rotated producer is interlocked
-// (ubench ROT 2 / ROT 3), and the terminator's own result is of the safe in-place kind.  All terminators and the 7 + 4
-// wait states the bf16 form needs sit in ONE asm statement whose outputs are the accumulators, so no read can be
-// scheduled in between.  The library is built with -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py): accumulators live
-// in VGPRs, otherwise the "+v" operands would make hipcc copy AGPR -> VGPR (= read the results) in FRONT of this statement.
-// tools/isa_check_mfma.py (tests/test_isa_cpu.py) verifies on the emitted ISA that no rotated MFMA result is read early.
-#define MT_(i) MFMA_TERM_OP " %" #i ", %[z], %[z], %" #i "\n\t"
-#define MG_(i) "+v"(acc[i])
-template <typename T, int N>
-__device__ __forceinline__ void mfma_result_guard(f32x4 (&acc)[N]) {
-    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10 || N == 12 || N == 20,
-                  "mfma_result_guard: add a case for this accumulator count");
-    // "s_nop 1" in front: the zero operand may have been written by the VALU instruction just before (VALU write -> MFMA read)
-#define MFMA_GUARD_BODY()                                                                                                  \
-    if constexpr (N == 1) asm volatile("s_nop 1\n\t" MT_(0) MFMA_TERM_TAIL : MG_(0) : [z] "v"(z));                             \
-    else if constexpr (N == 2) asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MFMA_TERM_TAIL : MG_(0), MG_(1) : [z] "v"(z));             \
-    else if constexpr (N == 3) asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MFMA_TERM_TAIL : MG_(0), MG_(1), MG_(2) : [z] "v"(z)); \
-    else if constexpr (N == 4)                                                                                           \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MFMA_TERM_TAIL : MG_(0), MG_(1), MG_(2), MG_(3) : [z] "v"(z));      \
-    else if constexpr (N == 5)                                                                                           \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MFMA_TERM_TAIL                                            \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4) : [z] "v"(z));                                              \
-    else if constexpr (N == 6)                                                                                           \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MFMA_TERM_TAIL                                     \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5) : [z] "v"(z));                                      \
-    else if constexpr (N == 8)                                                                                           \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MFMA_TERM_TAIL                       \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7) : [z] "v"(z));                      \
-    else if constexpr (N == 10)                                                                                          \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MFMA_TERM_TAIL         \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9) : [z] "v"(z));      \
-    else if constexpr (N == 12)                                                                                          \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
-                     MFMA_TERM_TAIL                                                                                      \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11)   \
-                     : [z] "v"(z));                                                                                      \
-    else                                                                                                                 \
-        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
-                     MT_(12) MT_(13) MT_(14) MT_(15) MT_(16) MT_(17) MT_(18) MT_(19) MFMA_TERM_TAIL                      \
-                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11),  \
-                       MG_(12), MG_(13), MG_(14), MG_(15), MG_(16), MG_(17), MG_(18), MG_(19)                            \
-                     : [z] "v"(z))
-    if constexpr (TT<T>::ES == 4) {
-#define MFMA_TERM_OP "v_mfma_f32_16x16x4_f32"
-#define MFMA_TERM_TAIL "s_nop 3"       /* interlocked in hardware; a token pad for the (unmodelled) asm boundary */
-        const float z = 0.0f;
-        MFMA_GUARD_BODY();
-#undef MFMA_TERM_OP
-#undef MFMA_TERM_TAIL
-    } else {
-#define MFMA_TERM_OP "v_mfma_f32_16x16x32_bf16"
-#define MFMA_TERM_TAIL "s_nop 11"      /* in-place XDL 16x16x32 result -> VALU read: 7 wait states (+4 margin) */
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        MFMA_GUARD_BODY();
-#undef MFMA_TERM_OP
-#undef MFMA_TERM_TAIL
-    }
-#undef MFMA_GUARD_BODY
-}
-#undef MT_
-#undef MG_
-
-__device__ __forceinline__ u32x4 ld16(const char* p) { return *reinterpret_cast<const u32x4*>(p); }
-// 16-byte buffer load: 32-bit per-lane byte offset + scalar byte offset; an offset beyond the descriptor's size
-// returns zeros (hardware bounds check), so padding / out-of-image granules need no branch: they get OOB_OFF.
-__device__ __forceinline__ u32x4 bld16(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-}
-constexpr int OOB_OFF = 0x40000000;
-__device__ __forceinline__ void st16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
 // Stage the input patch of one tile / one channel chunk: sP[pix][CK] (pitch PIXP bytes).
 template <typename T, int NG>
@@ -451,9 +282,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     TRACE(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.y * BN;
-    const int ty = blockIdx.x / a.tiles_x, tx = blockIdx.x - ty * a.tiles_x;
+    // 1-D grid, XCD-contiguous: logical id = (image, pixel tile, output-channel tile), channel tile fastest
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int tlin = lid / a.ntn;
+    const int n0 = (lid - tlin * a.ntn) * BN;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int b = tlin / tpi, trem = tlin - b * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
     const int oy0 = ty * a.toh, ox0 = tx * a.tow;
     const int S = a.g.stride;
     const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
@@ -1175,306 +1010,8 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
 }
 
 // --------------------------------------------------------------------------------------------- //
-// weight-gradient kernel                                                                         //
-// --------------------------------------------------------------------------------------------- //
-// TAIL: see k_conv3x3 (the stride-2 patch tail; its dead loads made hipcc drain the prefetch in front of the MFMA phase)
-template <typename T, int MT, int NG, bool TAIL>
-__global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
-    constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G;
-    constexpr int NCOL = 9 * CK;                   // (tap, c) columns of this chunk
-    constexpr int NFR = (NCOL + 15) / 16;          // column fragments
-    constexpr int FPW = (NFR + 3) / 4;             // fragments per wave
-    constexpr int PIXP = pitch_bytes(NG * 16);
-    constexpr int DYP = 16 * MT * ES + 16;         // dY row pitch (bytes)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sDY = smem;                              // [BM][16*MT]
-    char* sX = smem + BM * DYP;                    // patch
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kg = lane >> 4;
-    const int co0 = blockIdx.y * 16 * MT;
-    // chunk -> (source, channel offset)
-    const int chunks0 = a.g.C[0] / CK;
-    const int s = ((int)blockIdx.z < chunks0) ? 0 : 1;
-    const int c0 = (s == 0 ? (int)blockIdx.z : (int)blockIdx.z - chunks0) * CK;
-    const int wc0 = (s == 0 ? 0 : a.g.C[0]) + c0;
-    const int S = a.g.stride;
-    const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
-    const int npix = a.toh * a.tow;
-
-    // per-lane column decode of the owned fragments
-    int boff[FPW];      // LDS byte offset of this lane's (tap, c) inside a patch pixel row-set
-    int ocol[FPW];      // element offset tap*Ctot + c of this lane's OUTPUT column (-1: padding)
-#pragma unroll
-    for (int fi = 0; fi < FPW; ++fi) {
-        const int f = wave + 4 * fi;
-        // address column (tr read: lane supplies the address of columns 4p..4p+3; plain: own column)
-        const int ncol_addr = 16 * f + ((ES == 2) ? 4 * (lane & 3) : l15);
-        int tap = min(ncol_addr / CK, 8);
-        const int c = ncol_addr - (ncol_addr / CK) * CK;
-        boff[fi] = ((tap / 3) * PW + (tap % 3)) * PIXP + c * ES;
-        const int ncol = 16 * f + l15;
-        ocol[fi] = (f < NFR && ncol < NCOL) ? ((ncol / CK) * a.Ctot + (ncol % CK)) : -1;
-    }
-
-    f32x4 acc[MT][FPW];
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int fi = 0; fi < FPW; ++fi) acc[mi][fi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float dbacc = 0.0f;
-
-    const int t_begin = blockIdx.x * a.tiles_per_split;
-    const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-
-    // software pipeline over pixel tiles: the dY tile and the input patch of tile t+1 are loaded into registers
-    // before the MFMAs of tile t and written to LDS after them
-    constexpr int DGR = 16 * MT / G;                       // dY granules per pixel row
-    constexpr int DIT = (BM * DGR + NT - 1) / NT;
-    constexpr int PPF = TAIL ? 9 : 3;              // stride-2 patches: everything in the prefetch
-    const int ptotal = PH * PW * NG;
-    u32x4 dyv[DIT], pv[PPF];
-
-    // Tile coordinates (image, tile row, tile column) are wave-uniform and advance incrementally; everything that
-    // depends on the thread only (its pixel / granule inside the tile or patch) is computed ONCE, with magic-number
-    // divisions.  Per tile a thread then needs a handful of adds and compares per staged granule -- this loop was
-    // VALU-bound on ~20 runtime integer divisions per tile.
-    struct TileC { int b, ty, tx; };
-    auto tile_next = [&](TileC& c) {
-        if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.b; } }
-    };
-    TileC cur;
-    {
-        const int t = __builtin_amdgcn_readfirstlane(t_begin);
-        cur.b = t / tiles_per_img;
-        const int tr_ = t - cur.b * tiles_per_img;
-        cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
-    }
-    // branch-free staging loads: buffer descriptors over the whole dY tensor / the whole source tensor, invalid
-    // granules get an out-of-range offset and come back as zeros (see k_conv3x3)
-    const long long dy_bytes = (long long)a.B * a.Ho * a.Wo * a.Cout * ES;
-    const long long x_bytes = (long long)a.B * a.g.Hs[s] * a.g.Ws[s] * a.g.C[s] * ES;
-    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(dy_bytes < 0x7fffffffLL ? dy_bytes : 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[s], 0, (int)(x_bytes < 0x7fffffffLL ? x_bytes : 0x7fffffffLL), 0x00020000);
-    const int Hs = a.g.Hs[s], Ws = a.g.Ws[s], Cs = a.g.C[s];
-    const int sh = (a.g.mode[s] != MODE_DIRECT) ? 1 : 0;   // up-sampled source: stored at half size
-
-    int dy_off[DIT], dy_yx[DIT], dy_lds[DIT];             // offset inside the tile's image region, (oy << 16 | ox), LDS
-#pragma unroll
-    for (int it = 0; it < DIT; ++it) {
-        const int i = it * NT + tid;
-        const int pp_ = i / DGR, gch = i - pp_ * DGR;
-        const int oy = mdiv(pp_, a.m_tow), ox = pp_ - oy * a.tow;
-        const bool ok = (BM * DGR % NT == 0 || i < BM * DGR) && (pp_ < npix) && (co0 + gch * G < a.Cout);
-        dy_off[it] = ok ? ((oy * a.Wo + ox) * a.Cout + co0 + gch * G) * ES : OOB_OFF;
-        dy_yx[it] = (oy << 16) | ox;
-        dy_lds[it] = pp_ * DYP + gch * 16;
-    }
-    int p_yx[PPF], p_cg[PPF];                              // (py << 16 | px) inside the patch (py = 0x7fff: none), granule
-#pragma unroll
-    for (int it = 0; it < PPF; ++it) {
-        const int i = it * NT + tid;
-        const int pix = i / NG;
-        p_cg[it] = i - pix * NG;
-        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-        p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
-    }
-    auto load_dy = [&](const TileC& c) {
-        const int oy0 = c.ty * a.toh, ox0 = c.tx * a.tow;
-        const int base = ((c.b * a.Ho + oy0) * a.Wo + ox0) * a.Cout * ES;      // wave-uniform: the scalar offset
-        const int remy = a.Ho - oy0, remx = a.Wo - ox0;
-        if (remy >= a.toh && remx >= a.tow) {              // interior tile: no per-granule test
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) dyv[it] = bld16(rdy, dy_off[it], base);
-        } else {
-#pragma unroll
-            for (int it = 0; it < DIT; ++it) {
-                const bool ok = ((dy_yx[it] >> 16) < remy) && ((dy_yx[it] & 0xffff) < remx);
-                dyv[it] = bld16(rdy, ok ? dy_off[it] : OOB_OFF, base);
-            }
-        }
-    };
-    auto store_dy = [&]() {
-#pragma unroll
-        for (int it = 0; it < DIT; ++it)
-            if (BM * DGR % NT == 0 || it * NT + tid < BM * DGR) st16(sDY + dy_lds[it], dyv[it]);
-    };
-    auto patch_voff = [&](const TileC& c, int yx, int cg) -> int {
-        const int vy = c.ty * a.toh * S - 1 + (yx >> 16), vx = c.tx * a.tow * S - 1 + (yx & 0xffff);
-        const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi);
-        return inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + c0 + cg * G) * ES : OOB_OFF;
-    };
-    auto load_p = [&](const TileC& c) {
-        const int base = c.b * Hs * Ws * Cs * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rx, patch_voff(c, p_yx[it], p_cg[it]), base);
-    };
-    auto store_p = [&](const TileC& c) {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
-        }
-        // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
-        const int base = c.b * Hs * Ws * Cs * ES;
-        if constexpr (TAIL)
-        for (int g0 = PPF * NT; g0 < ptotal; g0 += 3 * NT) {
-            u32x4 tt[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = g0 + u * NT + tid;
-                const int pix = i / NG, cg = i - pix * NG;
-                const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-                tt[u] = bld16(rx, (i < ptotal) ? patch_voff(c, (py << 16) | px, cg) : OOB_OFF, base);
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = g0 + u * NT + tid;
-                if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, tt[u]); }
-            }
-        }
-    };
-    // bias gradient: all 256 threads, thread = (channel, pixel phase); NPH partial sums per channel meet in the atomics
-    constexpr int NPH = NT / (16 * MT);
-    const int db_co = tid % (16 * MT), db_ph = tid / (16 * MT);
-
-    if (t_begin < t_end) { load_dy(cur); load_p(cur); }
-    for (int t = t_begin; t < t_end; ++t) {
-        __syncthreads();
-        store_dy();
-        store_p(cur);
-        __syncthreads();
-        tile_next(cur);
-        if (t + 1 < t_end) { load_dy(cur); load_p(cur); }          // in flight during the MFMAs below
-
-        if (blockIdx.z == 0 && a.db) {
-            float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll 4
-            for (int p = db_ph; p < BM; p += 2 * NPH) {   // rows beyond the tile hold zeros
-                if constexpr (ES == 2) {
-                    s0 += bf2f(*reinterpret_cast<const uint16_t*>(sDY + p * DYP + db_co * 2));
-                    s1 += bf2f(*reinterpret_cast<const uint16_t*>(sDY + (p + NPH) * DYP + db_co * 2));
-                } else {
-                    s0 += *reinterpret_cast<const float*>(sDY + p * DYP + db_co * 4);
-                    s1 += *reinterpret_cast<const float*>(sDY + (p + NPH) * DYP + db_co * 4);
-                }
-            }
-            dbacc += s0 + s1;
-        }
-
-        if constexpr (ES == 2) {
-            // K = 128 pixels in 4 steps of 32; fragments by hardware-transposed LDS reads
-            const int q = l15 >> 2, pp = lane & 3;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                int xo[2], yo[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    int p = 32 * ks + 8 * kg + q + 4 * h;
-                    yo[h] = p * DYP;
-                    if (p >= npix) p = 0;     // its dY row is zero
-                    const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-                    xo[h] = ((oy * S) * PW + ox * S) * PIXP;
-                }
-                s16x8 af[MT];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sDY + yo[0] + (16 * mi + 4 * pp) * 2));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sDY + yo[1] + (16 * mi + 4 * pp) * 2));
-                    af[mi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-#pragma unroll
-                for (int fi = 0; fi < FPW; ++fi) {
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sX + xo[0] + boff[fi]));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(sX + xo[1] + boff[fi]));
-                    const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-                        acc[mi][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf), acc[mi][fi], 0, 0, 0);
-                }
-            }
-        } else {
-            // K = 128 pixels in 32 steps of 4 (exact f32 MFMA 16x16x4); lane k-slot = kg
-            int p = kg;
-            int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-            for (int ks = 0; ks < BM / 4; ++ks) {
-                const bool live = p < npix;
-                const int xo = live ? ((oy * S) * PW + ox * S) * PIXP : 0;
-                float av[MT];
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-                    av[mi] = *reinterpret_cast<const float*>(sDY + p * DYP + (16 * mi + l15) * 4);
-#pragma unroll
-                for (int fi = 0; fi < FPW; ++fi) {
-                    const float bvv = *reinterpret_cast<const float*>(sX + xo + boff[fi]);
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
-                        acc[mi][fi] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bvv, acc[mi][fi], 0, 0, 0);
-                }
-                p += 4; ox += 4;
-                while (ox >= a.tow) { ox -= a.tow; ++oy; }
-            }
-        }
-    }
-
-    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
-    // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int fi = 0; fi < FPW; ++fi) {
-            if (ocol[fi] < 0) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + 16 * mi + 4 * kg + r;
-                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
-            }
-        }
-    if (blockIdx.z == 0 && a.db) {                       // fold the NPH pixel phases in LDS: one atomic per channel
-        __syncthreads();
-        float* sdb = reinterpret_cast<float*>(smem);
-        sdb[tid] = dbacc;
-        __syncthreads();
-        if (tid < 16 * MT && co0 + tid < a.Cout) {
-            float t = 0.0f;
-#pragma unroll
-            for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
-            atomicAdd(a.db + co0 + tid, t);
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------- //
 // host side                                                                                      //
 // --------------------------------------------------------------------------------------------- //
-struct Tile { int toh, tow; };
-
-// choose the tile region (<=128 pixels) that wastes the fewest fragment rows; ties: least staged patch
-Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128) {
-    Tile best{even ? 2 : 1, even ? 2 : 1};
-    double best_cost = 1e30;
-    const int step = even ? 2 : 1;
-    for (int tow = step; tow <= (Wo + step - 1) / step * step && tow <= BM; tow += step) {
-        int toh = BM / tow;
-        if (even) toh &= ~1;
-        const int hcap = (Ho + step - 1) / step * step;
-        if (toh > hcap) toh = hcap;
-        if (toh < step) continue;
-        const long tiles = (long)((Ho + toh - 1) / toh) * ((Wo + tow - 1) / tow);
-        const long patch = (long)((toh - 1) * stride + 3) * ((tow - 1) * stride + 3);
-        const double cost = (double)tiles * (BM + 0.25 * patch);
-        if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow}; }
-    }
-    return best;
-}
-
 template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0, int NTH = 256>
 int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
@@ -1492,9 +1029,15 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
         if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
     }
-    dim3 grid(k.tiles_x * k.tiles_y, (k.N + BN - 1) / BN, B);
+    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    ConvK kk = k;
+    kk.ntn = (k.N + BN - 1) / BN;
+    kk.xcd = xcd_on;
+    const long long nwg_ll = (long long)k.tiles_x * k.tiles_y * kk.ntn * B;
+    COLVO_CHECK_ARG(nwg_ll < (1ll << 30), "conv: too many workgroups");
+    dim3 grid((unsigned)nwg_ll, 1, 1);
 #ifdef COLVO_ABLATE
-    ConvK ka = k;
+    ConvK ka = kk;
     { const char* e = getenv("COLVO_ABL"); ka.abl = e ? atoi(e) : 0; }
     ka.trace = nullptr;
     static long long* tbuf = nullptr;
@@ -1530,7 +1073,7 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     }
     return 0;
 #endif
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, k);
+    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, kk);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
 }
@@ -1726,105 +1269,6 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
 
-template <typename T, int MT, int NG, bool TAIL>
-int launch_wgrad_tail(WgradK k, hipStream_t s) {
-    constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
-    const int S = k.g.stride;
-    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
-    const size_t lds = (size_t)BM * DYP + (size_t)PH * PW * PIXP + 64;
-    COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: tile needs %zu bytes of LDS", lds);
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<T, MT, NG, TAIL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-        configured = 160 * 1024;
-    }
-    const int chunks = (k.g.C[0] + k.g.C[1]) / CK;
-    const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
-    // Pixel-range splits: every split adds one fp32 atomic per weight (chip-wide ~1.3 TB/s of atomics), so cap
-    // the atomic traffic at ~3 MB per launch (re-tuned for the 32-wide co tile: 12 MB 592 us, 6 MB 575, 3 MB 566),
-    // but keep at least ~256 workgroups in flight and at most ~1024.
-    const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
-    const int per_split = chunks * cot;
-    static const double atomic_budget = [] { const char* e = getenv("COLVO_WGRAD_ATOMIC_MB"); return (e ? atof(e) : 3.0) * 1e6; }();
-    static const int wg_lo = [] { const char* e = getenv("COLVO_WGRAD_WG_LO"); return e ? atoi(e) : 256; }();
-    static const int wg_hi = [] { const char* e = getenv("COLVO_WGRAD_WG_HI"); return e ? atoi(e) : 1024; }();
-    int nsplit = (int)(atomic_budget / wbytes);
-    const int lo = (wg_lo + per_split - 1) / per_split, hi = (wg_hi + per_split - 1) / per_split;
-    if (nsplit > hi) nsplit = hi;
-    if (nsplit < lo) nsplit = lo;
-    if (nsplit > k.ntiles) nsplit = k.ntiles;
-    if (nsplit < 1) nsplit = 1;
-    k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
-    nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
-    dim3 grid(nsplit, cot, chunks);
-    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
-    COLVO_CHECK_LAUNCH("k_wgrad3x3");
-    return 0;
-}
-
-template <typename T, int MT, int NG>
-int launch_wgrad(const WgradK& k, hipStream_t s) {
-    const int S = k.g.stride;
-    const long ptotal = (long)((k.toh - 1) * S + 3) * ((k.tow - 1) * S + 3) * NG;
-    if (ptotal > 3 * NT) return launch_wgrad_tail<T, MT, NG, true>(k, s);
-    return launch_wgrad_tail<T, MT, NG, false>(k, s);
-}
-
-template <typename T, int MT>
-int launch_wgrad_ng(const WgradK& k, int ng, hipStream_t s) {
-    switch (ng) {
-        case 4: return launch_wgrad<T, MT, 4>(k, s);
-        case 2: return launch_wgrad<T, MT, 2>(k, s);
-        default: return launch_wgrad<T, MT, 1>(k, s);
-    }
-}
-
-template <typename T>
-int launch_wgrad_t(const WgradK& k, hipStream_t s) {
-    constexpr int G = TT<T>::G;
-    static const int ng_max = [] { const char* e = getenv("COLVO_WGRAD_NG_MAX"); return e ? atoi(e) : 4; }();   // tuning knob
-    int ng = ng_max;
-    for (int i = 0; i < 2; ++i)
-        if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
-    for (int i = 0; i < 2; ++i)
-        COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "wgrad: channel count %d is not a multiple of %d", k.g.C[i], G);
-    // co tile: 32 wide (MT = 2) measured better than 64 on every layer -- twice the (co, chunk) combinations, so half the
-    // pixel-range splits and half the fp32 atomic traffic for the same number of workgroups (wgrad 638 -> 589 us)
-    static const int mt_max = [] { const char* e = getenv("COLVO_WGRAD_MT_MAX"); return e ? atoi(e) : 2; }();   // tuning knob
-    if (k.Cout >= 64 && mt_max >= 4) return launch_wgrad_ng<T, 4>(k, ng, s);
-    if (k.Cout >= 32 && mt_max >= 2) return launch_wgrad_ng<T, 2>(k, ng, s);
-    return launch_wgrad_ng<T, 1>(k, ng, s);
-}
-
-int check_desc(const ColvoConvDesc* d, const char* who) {
-    COLVO_CHECK_ARG(d, "%s: null descriptor", who);
-    COLVO_CHECK_ARG(d->dtype == COLVO_F32 || d->dtype == COLVO_BF16, "%s: bad dtype %d", who, d->dtype);
-    COLVO_CHECK_ARG(d->ksize == 3, "%s: only 3x3 convolutions are on this path (got k=%d)", who, d->ksize);
-    COLVO_CHECK_ARG(d->stride == 1 || d->stride == 2, "%s: stride must be 1 or 2", who);
-    COLVO_CHECK_ARG(d->B >= 1 && d->B <= 65535 && d->Hi >= 1 && d->Wi >= 1, "%s: bad shape", who);
-    COLVO_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1,
-                    "%s: output %dx%d does not match input %dx%d / stride %d", who, d->Ho, d->Wo, d->Hi, d->Wi, d->stride);
-    COLVO_CHECK_ARG(d->C0 >= 8 && d->C0 % 8 == 0 && d->C1 >= 0 && d->C1 % 8 == 0 && d->Cout >= 8 && d->Cout % 8 == 0,
-                    "%s: channel counts must be multiples of 8 (C0=%d C1=%d Cout=%d)", who, d->C0, d->C1, d->Cout);
-    COLVO_CHECK_ARG(!(d->up0 && ((d->Hi | d->Wi) & 1)) && !(d->up1 && ((d->Hi | d->Wi) & 1)),
-                    "%s: up-sampled sources need an even input size", who);
-    COLVO_CHECK_ARG(!((d->up0 || d->up1) && d->stride != 1), "%s: up-sampled sources need stride 1", who);
-    return 0;
-}
-
-void fill_gather(const ColvoConvDesc* d, const void* x0, const void* x1, Gather& g) {
-    g.src[0] = (const char*)x0; g.src[1] = (const char*)x1;
-    g.C[0] = d->C0; g.C[1] = x1 ? d->C1 : 0;
-    g.mode[0] = d->up0 ? MODE_UP2 : MODE_DIRECT;
-    g.mode[1] = d->up1 ? MODE_UP2 : MODE_DIRECT;
-    g.Hs[0] = d->up0 ? d->Hi / 2 : d->Hi; g.Ws[0] = d->up0 ? d->Wi / 2 : d->Wi;
-    g.Hs[1] = d->up1 ? d->Hi / 2 : d->Hi; g.Ws[1] = d->up1 ? d->Wi / 2 : d->Wi;
-    g.Hi = d->Hi; g.Wi = d->Wi; g.stride = d->stride;
-}
-
 }  // namespace
 }  // namespace colvo
 
@@ -1867,43 +1311,4 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     k.accumulate = accumulate; k.pool2 = up;
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, up != 0, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, up != 0, (hipStream_t)stream);
-}
-
-extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
-                                float* db, colvo_stream_t stream) {
-    if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
-    COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
-    // The kernel addresses dY and the sources with 32-bit buffer offsets (< 1 GiB per tensor): larger batches are
-    // processed in image slices -- the gradient accumulates into dw / db anyway.
-    {
-        const long long es = d->dtype == COLVO_F32 ? 4 : 2;
-        const long long cmax = d->C0 > d->C1 ? d->C0 : d->C1;
-        const long long per_img = std::max((long long)d->Ho * d->Wo * d->Cout, (long long)d->Hi * d->Wi * cmax) * es;
-        COLVO_CHECK_ARG(per_img < 0x40000000LL, "colvo_conv_wgrad: a single image of %lld bytes is not supported", per_img);
-        const int bmax = (int)std::max(1LL, (0x40000000LL - 1) / per_img);
-        if (d->B > bmax) {
-            const long long e0 = (long long)(d->up0 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C0 * es;
-            const long long e1 = (long long)(d->up1 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C1 * es;
-            const long long ey = (long long)d->Ho * d->Wo * d->Cout * es;
-            for (int b0 = 0; b0 < d->B; b0 += bmax) {
-                ColvoConvDesc sub = *d;
-                sub.B = std::min(bmax, d->B - b0);
-                if (int e = colvo_conv_wgrad(&sub, (const char*)x0 + b0 * e0, x1 ? (const char*)x1 + b0 * e1 : nullptr,
-                                             (const char*)dy + b0 * ey, dw, db, stream))
-                    return e;
-            }
-            return 0;
-        }
-    }
-    WgradK k{};
-    fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
-    k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
-    k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
-    const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
-    k.toh = t.toh; k.tow = t.tow;
-    k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
-    k.ntiles = d->B * k.tiles_x * k.tiles_y;
-    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * d->stride + 3);
-    return d->dtype == COLVO_F32 ? launch_wgrad_t<float>(k, (hipStream_t)stream)
-                                 : launch_wgrad_t<bf16_t>(k, (hipStream_t)stream);
 }

@@ -5,9 +5,13 @@ the device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused l
 side stream (fork/join by events), optional RCCL buckets, fused Adam -- can be captured once into a hipGraph
 (torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch: no host cost at all.
 
-Measured on MI355X (ROCm 7.2) the replay runs the two-stream backward SERIALLY (2.12 ms per step = the no-overlap time),
-while the recorded command lists of coivo_amd/program.py keep the overlap at ~1 ms of host time per step (1.85 ms), so
-bench.py uses those by default and this class is the option for hosts that are otherwise busy.
+Measured on MI355X (ROCm 7.2, round 2, gpurun_out/r2_graph_env*.log): a capture that contains the weight-gradient side
+stream (fork / join by events) replays in 4.2-4.4 ms per step -- 2.4 x the eager step -- whatever
+DEBUG_CLR_GRAPH_PACKET_CAPTURE / DEBUG_HIP_FORCE_GRAPH_QUEUES say, while a single-stream capture replays in 1.97 ms =
+the eager single-stream time (the step is GPU-bound: the host enqueues it in 1.15 ms through the recorded command
+lists of coivo_amd/program.py).  The graphed step is therefore captured WITHOUT the side stream (`overlap_wgrad` is
+switched off on the two networks while this object owns them); eager launches with the two-stream overlap (1.77 ms)
+stay bench.py's default and this class is the option for hosts that are otherwise busy.
 
 Inputs live in static device buffers (`frames` = [2B,3,H,W]: target frames then reference frames, `K`); the caller
 writes the next batch into them (or passes tensors to __call__, which copies) and replays.
@@ -26,6 +30,9 @@ class GraphedTrainStep:
                  warmup: int = 2):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
+        for n in (depth_net, pose_net):          # single-stream capture (see the module docstring)
+            n.overlap_wgrad = False
+            n.clear_programs()
         self.B, self.ssim_weight = B, ssim_weight
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
