@@ -68,6 +68,10 @@ SIGNATURES = {
     "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
     "colvo_zero": (_i, [_vp, _sz, _vp]),
+    "colvo_frames_u8_to_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "colvo_backproject": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "colvo_stitch_workspace_ints": (_sz, [_i, _i, _i, _i]),
+    "colvo_stitch_point_cloud": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
 }
 

@@ -221,6 +221,32 @@ int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
+ * SURVEY.md §8f-3  inference: dense depth maps stitched along the integrated trajectory into a  *
+ *   world-frame point cloud (README.md:9, :29).  spec: backproject / stitch_point_cloud.        *
+ * ------------------------------------------------------------------------------------------- */
+/* depth [B,1,H,W], K [B,3,3], cam2world [B,4,4] (row-major; the trajectory integration itself is N tiny 4x4 products and
+ * stays on the host) -> points [B,H*W,3] in row-major pixel order. */
+int colvo_backproject(const float* depth, const float* K, const float* cam2world, int B, int H, int W,
+                      float* points, colvo_stream_t stream);
+/* Every `stride`-th pixel (rows and columns) of N frames whose depth is < max_depth, back-projected and compacted in
+ * frame-major, row-major order (deterministic: counts + scan, no atomics).  points must hold
+ * N*ceil(H/stride)*ceil(W/stride)*3 floats; n_points[0] receives the number of points written.
+ * workspace: colvo_stitch_workspace_ints(N,H,W,stride) int32. */
+size_t colvo_stitch_workspace_ints(int N, int H, int W, int stride);
+int colvo_stitch_point_cloud(const float* depths, const float* K, const float* cam2world, int N, int H, int W,
+                             int stride, float max_depth, int32_t* workspace, float* points, int32_t* n_points,
+                             colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * SURVEY.md §8f-4  frames as a decoder delivers them -> the path's input format.                *
+ *   (README.md:13 dataset; spec: resize_frames_u8)                                              *
+ * ------------------------------------------------------------------------------------------- */
+/* frames [B,h,w,3] uint8 interleaved RGB (device) -> out [B,3,H,W] fp32 in [0,1]: bilinear resize with half-pixel
+ * centres (source index = (h/H)*(y+0.5)-0.5 clamped at 0), channel de-interleave and /255 in one pass. */
+int colvo_frames_u8_to_f32(const uint8_t* frames, int B, int h, int w, int H, int W, float* out,
+                           colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
  * Command lists: ONE call enqueues a recorded sequence of the entry points above (a network's  *
  * forward or backward) on a main and a side stream -- the host's per-launch cost, not the GPU, *
  * bounded the batch-8 step when every layer was a separate host call.                          *

@@ -431,6 +431,80 @@ def train_step(depth_net, pose_net, optimizer, tgt, ref, K) -> torch.Tensor:
 ADAM_KW = dict(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
 
 
+# --------------------------------------------------------------------------- #
+# §8f-3: inference path (README.md:9 "complete 3D reconstruction of the        #
+#        intestine", :29 "stitching together the dense depth maps of each      #
+#        frame using the colonoscopic trajectory")                             #
+# --------------------------------------------------------------------------- #
+def resize_frames_u8(frames_u8: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """§8f-4 input format: [B,h,w,3] uint8 interleaved RGB -> [B,3,H,W] float32 in [0,1], bilinear, half-pixel centres."""
+    x = frames_u8.permute(0, 3, 1, 2).to(torch.float32)
+    if tuple(x.shape[-2:]) != (H, W):
+        x = F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False, antialias=False)
+    return x / 255.0
+
+
+def resize_intrinsics(K: torch.Tensor, hw_from, hw_to) -> torch.Tensor:
+    """Intrinsics of a frame resized by resize_frames_u8: pixel centres on integers (§1), so a point at source
+    coordinate x lands at (x + 0.5) * s - 0.5."""
+    (h, w), (H, W) = hw_from, hw_to
+    sy, sx = H / h, W / w
+    K2 = K.clone()
+    K2[..., 0, 0] = K[..., 0, 0] * sx
+    K2[..., 1, 1] = K[..., 1, 1] * sy
+    K2[..., 0, 2] = (K[..., 0, 2] + 0.5) * sx - 0.5
+    K2[..., 1, 2] = (K[..., 1, 2] + 0.5) * sy - 0.5
+    return K2
+
+
+def pose_to_matrix4(pose: torch.Tensor) -> torch.Tensor:
+    """[N,6] -> [N,4,4] homogeneous transform (P_ref = R P_tgt + t, pose_vec2mat)."""
+    T = pose_vec2mat(pose)
+    bottom = torch.zeros(T.shape[0], 1, 4, dtype=T.dtype, device=T.device)
+    bottom[:, 0, 3] = 1.0
+    return torch.cat([T, bottom], dim=1)
+
+
+def integrate_trajectory(rel_poses: torch.Tensor) -> torch.Tensor:
+    """Camera-to-world transforms of frames 0..N from the N relative poses of consecutive pairs.
+
+    rel_poses[k] is PoseNet's output for (target = frame k, reference = frame k+1), i.e. it maps frame-k points into
+    frame k+1.  World = camera 0, so  M_0 = I,  M_{k+1} = M_k @ inverse(T_k).  -> [N+1,4,4] (float64 recommended)."""
+    T = pose_to_matrix4(rel_poses)
+    M = [torch.eye(4, dtype=T.dtype, device=T.device)]
+    for k in range(T.shape[0]):
+        R, t = T[k, :3, :3], T[k, :3, 3]
+        Tinv = torch.eye(4, dtype=T.dtype, device=T.device)
+        Tinv[:3, :3] = R.t()
+        Tinv[:3, 3] = -(R.t() @ t)
+        M.append(M[-1] @ Tinv)
+    return torch.stack(M)
+
+
+def backproject(depth: torch.Tensor, K: torch.Tensor, cam2world: torch.Tensor) -> torch.Tensor:
+    """depth [B,1,H,W], K [B,3,3], cam2world [B,4,4] -> world points [B,H*W,3] (row-major pixel order)."""
+    B, _, H, W = depth.shape
+    dt, dev = depth.dtype, depth.device
+    fx, fy = K[:, 0, 0].view(B, 1, 1), K[:, 1, 1].view(B, 1, 1)
+    cx, cy = K[:, 0, 2].view(B, 1, 1), K[:, 1, 2].view(B, 1, 1)
+    u = torch.arange(W, dtype=dt, device=dev).view(1, 1, W)
+    v = torch.arange(H, dtype=dt, device=dev).view(1, H, 1)
+    d = depth[:, 0]
+    P = torch.stack([(u - cx) / fx * d, (v - cy) / fy * d, d], dim=-1).view(B, H * W, 3)
+    R, t = cam2world[:, :3, :3], cam2world[:, :3, 3]
+    return P @ R.transpose(1, 2) + t.unsqueeze(1)
+
+
+def stitch_point_cloud(depths: torch.Tensor, K: torch.Tensor, cam2world: torch.Tensor, *, stride: int = 1,
+                       max_depth: float = MAX_DEPTH) -> torch.Tensor:
+    """The reconstruction of README.md:29: every `stride`-th pixel of every frame, back-projected into the world frame of
+    camera 0; pixels at or beyond `max_depth` are dropped.  depths [N,1,H,W], K [N,3,3], cam2world [N,4,4] -> [M,3]."""
+    N, _, H, W = depths.shape
+    pts = backproject(depths, K, cam2world).view(N, H, W, 3)[:, ::stride, ::stride]
+    keep = depths[:, 0, ::stride, ::stride] < max_depth
+    return pts[keep]
+
+
 def make_models(seed: int = 0, dtype=torch.float32):
     dn, pn = DepthNet().to(dtype), PoseNet().to(dtype)
     init_weights(dn, seed)

@@ -165,6 +165,32 @@ def test_multiscale_and_full_loss():
     assert d_t.grad.abs().max() > 0 and d_r.grad.abs().max() > 0
 
 
+def test_trajectory_and_backprojection_known_answers():
+    """Pure translations add up; a rotation about y followed by its inverse returns to the start; back-projecting a
+    constant-depth plane with the identity pose gives depth * K^-1 [u, v, 1]; a pure camera shift moves the cloud."""
+    rel = torch.zeros(3, 6, dtype=torch.float64)
+    rel[:, 0] = -0.1                      # frame-k points move by -0.1 in x when expressed in frame k+1 = camera moved +0.1
+    M = S.integrate_trajectory(rel)
+    assert M.shape == (4, 4, 4) and torch.allclose(M[3, :3, 3], torch.tensor([0.3, 0.0, 0.0], dtype=torch.float64))
+    rel = torch.tensor([[0, 0, 0, 0, 0.3, 0], [0, 0, 0, 0, -0.3, 0]], dtype=torch.float64)
+    M = S.integrate_trajectory(rel)
+    assert torch.allclose(M[2], torch.eye(4, dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(M[1][:3, :3] @ M[1][:3, :3].T, torch.eye(3, dtype=torch.float64), atol=1e-12)
+    B, H, W = 2, 4, 6
+    K = synth.intrinsics(B, H, W, dtype=torch.float64)
+    depth = torch.full((B, 1, H, W), 2.0, dtype=torch.float64)
+    eye = torch.eye(4, dtype=torch.float64).expand(B, 4, 4).clone()
+    P = S.backproject(depth, K, eye)
+    assert P.shape == (B, H * W, 3) and torch.allclose(P[..., 2], torch.full((B, H * W), 2.0, dtype=torch.float64))
+    assert abs(P[0, 0, 0].item() - 2.0 * (0 - K[0, 0, 2].item()) / K[0, 0, 0].item()) < 1e-12
+    shift = eye.clone(); shift[:, 0, 3] = 0.5
+    assert torch.allclose(S.backproject(depth, K, shift), P + torch.tensor([0.5, 0, 0], dtype=torch.float64))
+    cloud = S.stitch_point_cloud(depth, K, eye, stride=2)
+    assert cloud.shape == (B * 2 * 3, 3)
+    far = depth.clone(); far[0, 0, 0, 0] = S.MAX_DEPTH
+    assert S.stitch_point_cloud(far, K, eye).shape[0] == B * H * W - 1
+
+
 def test_depthnet_posenet_shapes_and_ranges():
     dn, pn = S.make_models(0)
     b = synth.make_batch(2, 32, 64, seed=6)
