@@ -278,38 +278,54 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[t][c] = 0.0f;
     float sb = 0.0f;
-    for (int q = p0 + (int)threadIdx.x; q < p1; q += NT) {
+    // The loads of pixel q + 256 are issued before the 9*C multiply-adds of pixel q (two waves per SIMD at ~180 VGPRs:
+    // without it every iteration waited out a full memory round trip; 54 -> us, profiles/r2_bench_kernel_stats.csv).
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    constexpr int NV = C * ES / 16;              // the pixel's C channels as 16-byte vectors (C * ES is a multiple of 16)
+    struct Px { u4 raw[NV]; float d[9]; float dc; };
+    auto fetch = [&](int q, Px& o) {
         const int qy = q / W, qx = q - qy * W;
-        float xv[C];
-        {   // the pixel's C channels as 16-byte vectors (C * ES is a multiple of 16)
-            typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-            const u4* px = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(x) + ((size_t)b * HW + q) * C * ES);
+        const u4* px = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(x) + ((size_t)b * HW + q) * C * ES);
 #pragma unroll
-            for (int v = 0; v < C * ES / 16; ++v) {
-                const u4 t = px[v];
-                if constexpr (ES == 4) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xv[4 * v + k] = __uint_as_float(t[k]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        xv[8 * v + 2 * k] = __uint_as_float(t[k] << 16);
-                        xv[8 * v + 2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
-                    }
-                }
-            }
-        }
-        sb += dpre[(size_t)b * HW + q];
+        for (int v = 0; v < NV; ++v) o.raw[v] = px[v];
+        o.dc = dpre[(size_t)b * HW + q];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                // output pixel whose tap (ky,kx) lands on q
-                const int oy = qy - ky + 1, ox = qx - kx + 1;
-                const float d = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dpre[((size_t)b * H + oy) * W + ox] : 0.0f;
-#pragma unroll
-                for (int c = 0; c < C; ++c) acc[ky * 3 + kx][c] = fmaf(d, xv[c], acc[ky * 3 + kx][c]);
+                const int oy = qy - ky + 1, ox = qx - kx + 1;      // output pixel whose tap (ky,kx) lands on q
+                o.d[ky * 3 + kx] = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dpre[((size_t)b * H + oy) * W + ox] : 0.0f;
             }
+    };
+    int q = p0 + (int)threadIdx.x;
+    Px cur;
+    if (q < p1) fetch(q, cur);
+    while (q < p1) {
+        const int qn = q + NT;
+        Px nxt = cur;
+        if (qn < p1) fetch(qn, nxt);
+        float xv[C];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const u4 t = cur.raw[v];
+            if constexpr (ES == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[4 * v + k] = __uint_as_float(t[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xv[8 * v + 2 * k] = __uint_as_float(t[k] << 16);
+                    xv[8 * v + 2 * k + 1] = __uint_as_float(t[k] & 0xFFFF0000u);
+                }
+            }
+        }
+        sb += cur.dc;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[t][c] = fmaf(cur.d[t], xv[c], acc[t][c]);
+        cur = nxt;
+        q = qn;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -603,7 +619,9 @@ extern "C" int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpr
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
     if (C == 16) {
-        const int ppb = 2048;   // pixels per workgroup (8 per thread)
+        // pixels per workgroup: a multiple of 256, at least 8 per thread, and at most ~512 workgroups (two per CU resident)
+        int ppb = 2048;
+        while ((HW + ppb - 1) / ppb * B > 512 && ppb < 16384) ppb += 256;
         DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
                                               dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
     } else {

@@ -12,8 +12,14 @@ namespace {
 // weight-gradient kernel                                                                         //
 // --------------------------------------------------------------------------------------------- //
 // TAIL: see k_conv3x3 (the stride-2 patch tail; its dead loads made hipcc drain the prefetch in front of the MFMA phase)
-template <typename T, int MT, int NG, bool TAIL>
-__global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
+// KS: pixel-tile teams per workgroup.  The number of workgroups is capped by the fp32 atomics every one of them ends with
+// (one per weight element of its (co tile, channel chunk) slab), and at that cap most layers ran ONE 4-wave workgroup per
+// CU: one wave per SIMD, nothing to hide the staging latency or the LDS round trips behind (~1.4 us per 128-pixel tile,
+// MFMA pipe 7-14 % busy).  A workgroup of KS teams of 4 waves walks KS pixel tiles at a time -- each team its own staging
+// buffers, same barriers -- and the teams' accumulators meet in LDS (ds_add_f32) before ONE set of global atomics leaves
+// the workgroup, coalesced along the weight rows: KS times the waves per CU at the same atomic traffic.
+template <typename T, int MT, int NG, bool TAIL, int KS = 1>
+__global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G;
     constexpr int NCOL = 9 * CK;                   // (tap, c) columns of this chunk
@@ -22,10 +28,8 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int DYP = 16 * MT * ES + 16;         // dY row pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sDY = smem;                              // [BM][16*MT]
-    char* sX = smem + BM * DYP;                    // patch
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;       // inside the team
+    const int team = (KS > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x / NT) : 0;
     const int l15 = lane & 15, kg = lane >> 4;
     // 1-D grid, XCD-contiguous: logical id = (pixel-range split, channel chunk, co tile), co tile fastest -- the
     // workgroups of one pixel range (same dY tiles, same patches) sit on one L2
@@ -42,6 +46,9 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     const int S = a.g.stride;
     const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
     const int npix = a.toh * a.tow;
+    const int stage = (BM * DYP + PH * PW * PIXP + 15) & ~15;    // one team's staging buffers
+    char* sDY = smem + team * stage;               // [BM][16*MT]
+    char* sX = sDY + BM * DYP;                     // patch
 
     // per-lane column decode of the owned fragments
     int boff[FPW];      // LDS byte offset of this lane's (tap, c) inside a patch pixel row-set
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     };
     TileC cur;
     {
-        const int t = __builtin_amdgcn_readfirstlane(t_begin);
+        const int t = __builtin_amdgcn_readfirstlane(t_begin + team);
         cur.b = t / tiles_per_img;
         const int tr_ = t - cur.b * tiles_per_img;
         cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
@@ -121,10 +128,12 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
         p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
     }
-    auto load_dy = [&](const TileC& c) {
+    // `live`: false for a team whose tile index ran past the workgroup's range (it still takes part in the barriers; its
+    // loads are out of range and stage zeros)
+    auto load_dy = [&](const TileC& c, bool live) {
         const int oy0 = c.ty * a.toh, ox0 = c.tx * a.tow;
-        const int base = ((c.b * a.Ho + oy0) * a.Wo + ox0) * a.Cout * ES;      // wave-uniform: the scalar offset
-        const int remy = a.Ho - oy0, remx = a.Wo - ox0;
+        const int base = live ? ((c.b * a.Ho + oy0) * a.Wo + ox0) * a.Cout * ES : 0;      // wave-uniform: the scalar offset
+        const int remy = live ? a.Ho - oy0 : 0, remx = a.Wo - ox0;
         if (remy >= a.toh && remx >= a.tow) {              // interior tile: no per-granule test
 #pragma unroll
             for (int it = 0; it < DIT; ++it) dyv[it] = bld16(rdy, dy_off[it], base);
@@ -146,19 +155,21 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
         const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi);
         return inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + c0 + cg * G) * ES : OOB_OFF;
     };
-    auto load_p = [&](const TileC& c) {
-        const int base = c.b * Hs * Ws * Cs * ES;
+    auto load_p = [&](const TileC& c, bool live) {
+        const int base = live ? c.b * Hs * Ws * Cs * ES : 0;
+        const int dead = live ? 0 : OOB_OFF;          // offsets are < OOB_OFF: OR-ing it in puts them out of range
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rx, patch_voff(c, p_yx[it], p_cg[it]), base);
+        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rx, patch_voff(c, p_yx[it], p_cg[it]) | dead, base);
     };
-    auto store_p = [&](const TileC& c) {
+    auto store_p = [&](const TileC& c, bool live) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
             if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
-        const int base = c.b * Hs * Ws * Cs * ES;
+        const int base = live ? c.b * Hs * Ws * Cs * ES : 0;
+        const int dead = live ? 0 : OOB_OFF;
         if constexpr (TAIL)
         for (int g0 = PPF * NT; g0 < ptotal; g0 += 3 * NT) {
             u32x4 tt[3];
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
                 const int i = g0 + u * NT + tid;
                 const int pix = i / NG, cg = i - pix * NG;
                 const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-                tt[u] = bld16(rx, (i < ptotal) ? patch_voff(c, (py << 16) | px, cg) : OOB_OFF, base);
+                tt[u] = bld16(rx, ((i < ptotal) ? patch_voff(c, (py << 16) | px, cg) : OOB_OFF) | dead, base);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
@@ -180,14 +191,16 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     constexpr int NPH = NT / (16 * MT);
     const int db_co = tid % (16 * MT), db_ph = tid / (16 * MT);
 
-    if (t_begin < t_end) { load_dy(cur); load_p(cur); }
-    for (int t = t_begin; t < t_end; ++t) {
+    // team g walks the tiles t_begin + g, t_begin + g + KS, ...; every team runs the same number of iterations
+    if (t_begin < t_end) { const bool live = t_begin + team < t_end; load_dy(cur, live); load_p(cur, live); }
+    for (int t = t_begin; t < t_end; t += KS) {
         __syncthreads();
         store_dy();
-        store_p(cur);
+        store_p(cur, t + team < t_end);
         __syncthreads();
-        tile_next(cur);
-        if (t + 1 < t_end) { load_dy(cur); load_p(cur); }          // in flight during the MFMAs below
+#pragma unroll
+        for (int q = 0; q < KS; ++q) tile_next(cur);
+        if (t + KS < t_end) { const bool live = t + KS + team < t_end; load_dy(cur, live); load_p(cur, live); }   // in flight during the MFMAs below
 
         if (bchunk == 0 && a.db) {
             float s0 = 0.0f, s1 = 0.0f;
@@ -265,30 +278,88 @@ __global__ __launch_bounds__(NT) void k_wgrad3x3(const WgradK a) {
     }
 
     mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
-    // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
+    float* sdb = reinterpret_cast<float*>(smem);
+    if constexpr (KS > 1) {
+        // The teams' accumulators meet in team 0 through LDS, one team per round with plain 16-byte stores (ds_add_f32
+        // measured ~170 cycles per wave instruction: 46 us for this exchange).  Then ONE set of global atomics per workgroup.
+        f32x4* sRed = reinterpret_cast<f32x4*>(smem);
+        sdb = reinterpret_cast<float*>(smem + MT * FPW * NT * 16);
+        for (int g = 1; g < KS; ++g) {
+            __syncthreads();                               // staging buffers / the previous round's slab are free
+            if (team == g) {
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int fi = 0; fi < FPW; ++fi) {
-            if (ocol[fi] < 0) continue;
+                    for (int fi = 0; fi < FPW; ++fi) sRed[(mi * FPW + fi) * NT + tid] = acc[mi][fi];
+            }
+            __syncthreads();
+            if (team == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + 16 * mi + 4 * kg + r;
-                if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int fi = 0; fi < FPW; ++fi) acc[mi][fi] += sRed[(mi * FPW + fi) * NT + tid];
             }
         }
-    if (bchunk == 0 && a.db) {                           // fold the NPH pixel phases in LDS: one atomic per channel
+    }
+    if (team == 0) {
+        // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int fi = 0; fi < FPW; ++fi) {
+                if (ocol[fi] < 0) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + 16 * mi + 4 * kg + r;
+                    if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
+                }
+            }
+    }
+    if (bchunk == 0 && a.db) {                           // fold the NPH pixel phases (of every team) in LDS: one atomic per channel
         __syncthreads();
-        float* sdb = reinterpret_cast<float*>(smem);
-        sdb[tid] = dbacc;
+        sdb[threadIdx.x] = dbacc;
         __syncthreads();
-        if (tid < 16 * MT && co0 + tid < a.Cout) {
+        if (threadIdx.x < 16 * MT && co0 + tid < a.Cout) {
             float t = 0.0f;
 #pragma unroll
-            for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
+            for (int ph = 0; ph < NPH * KS; ++ph) t += sdb[ph * 16 * MT + tid];
             atomicAdd(a.db + co0 + tid, t);
         }
     }
+}
+
+template <typename T, int MT, int NG, bool TAIL, int KS>
+int launch_wgrad_teams(WgradK k, hipStream_t s) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
+    constexpr int NFR = (9 * CK + 15) / 16, FPW = (NFR + 3) / 4;
+    const int S = k.g.stride;
+    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    const size_t stage = ((size_t)BM * DYP + (size_t)PH * PW * PIXP + 15) & ~(size_t)15;
+    const size_t lds = std::max(stage * KS, (size_t)MT * FPW * NT * 16 + (size_t)NT * KS * 4) + 64;   // staging | exchange slab + db
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: %d teams need %zu bytes of LDS", KS, lds);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<T, MT, NG, TAIL, KS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = 160 * 1024;
+    }
+    const int chunks = (k.g.C[0] + k.g.C[1]) / CK;
+    const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
+    // one workgroup per CU (KS * 4 waves fill its SIMDs): as many pixel-range splits as keep the grid within 256
+    const int per_split = chunks * cot;
+    static const int wg_target = [] { const char* e = getenv("COLVO_WGRAD_TEAM_WGS"); return e ? atoi(e) : 256; }();   // tuning knob
+    int nsplit = std::max(1, wg_target / per_split);
+    if (nsplit > k.ntiles) nsplit = k.ntiles;
+    k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
+    nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
+    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
+    dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
+    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_wgrad3x3 (teams)");
+    return 0;
 }
 
 template <typename T, int MT, int NG, bool TAIL>
@@ -297,6 +368,19 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    {
+        // Teams pay only on the two full-resolution layers (16 output channels: a one-fragment co tile, so the exchange is
+        // 20 KB per team, and one or two slabs in the (co tile, channel chunk) grid, so 256 workgroups walk 40-80 tiles each).
+        // Measured at batch 16, us: up1 47.8 -> 37.5, iconv1 38.5 -> 28.9; with 32-wide co tiles it loses (enc1b 30.7 -> 40.2,
+        // up2 / iconv2 32.8 -> 37.5) and everywhere else the walk is short and the per-workgroup costs decide: -1...+8
+        // (gpurun_out/r2_bench_conv_slabs*.log).  4 teams = 1024 threads, 128 registers per lane.
+        static const int teams = [] { const char* e = getenv("COLVO_WGRAD_TEAMS"); return e ? atoi(e) : 4; }();          // tuning knob; 1 = off
+        static const int max_slabs = [] { const char* e = getenv("COLVO_WGRAD_TEAM_MAX_SLABS"); return e ? atoi(e) : 2; }();   // tuning knob
+        const int slabs = ((k.g.C[0] + k.g.C[1]) / CK) * ((k.Cout + 16 * MT - 1) / (16 * MT));
+        const size_t stage = ((size_t)BM * DYP + (size_t)PH * PW * PIXP + 15) & ~(size_t)15;
+        if constexpr (!TAIL && MT == 1)
+            if (teams >= 4 && slabs <= max_slabs && stage * 4 + 64 <= 160 * 1024) return launch_wgrad_teams<T, MT, NG, TAIL, 4>(k, s);
+    }
     const size_t lds = (size_t)BM * DYP + (size_t)PH * PW * PIXP + 64;
     COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;

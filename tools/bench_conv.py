@@ -46,6 +46,7 @@ def main():
     fwdonly = len(sys.argv) > 3 and sys.argv[3] == "fwdonly"
     dev = torch.device("cuda:0")
     tot = [0.0, 0.0, 0.0]
+    gsum = [0.0, 0.0, 0.0]
     print(f"{'layer':8s} {'shape':28s} {'GFLOP':>7s} | {'fwd us':>8s} {'GF/us':>6s} | {'dgrad us':>8s} {'GF/us':>6s} | {'wgrad us':>8s} {'GF/us':>6s}")
     for (name, b, hi, wi, c0, c1, up, cout, stride) in layers(B, 256, 320):
         d = ops.conv_desc(dt, b, hi, wi, c0, cout, stride=stride, C1=c1, up0=up)
@@ -67,13 +68,15 @@ def main():
         tw = 1.0 if fwdonly else timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db))
         gd = gf * c0 / cin
         tot[0] += tf; tot[1] += td; tot[2] += tw
+        gsum[0] += gf; gsum[1] += gd; gsum[2] += gf
         shape = "%d+%d->%d @%dx%d s%d%s" % (c0, c1, cout, d.Ho, d.Wo, stride, " up" if up else "")
         print(f"{name:8s} {shape:28s} {gf:7.2f} | {tf:8.1f} {gf / tf:6.1f} | {td:8.1f} {gd / td:6.1f} | {tw:8.1f} {gf / tw:6.1f}")
     print(f"totals: fwd {tot[0]:.0f} us  dgrad {tot[1]:.0f} us  wgrad {tot[2]:.0f} us")
-    gtot = 159.0    # GFLOP per pass of the DepthNet stack at B=16, 256x320 (sum of the GFLOP column; dgrad without enc1a's)
-    if B == 16 and not fwdonly:
-        print("MFMA rate per pass (of 2500 TFLOP/s dense bf16): fwd %.1f %%  dgrad %.1f %%  wgrad %.1f %%" %
-              tuple(100.0 * gtot / t / 1e3 / 2500.0 * 1e3 for t in tot))
+    if not fwdonly:
+        # 1 GFLOP/us = 1000 TFLOP/s; dgrad of the first layer (gradient w.r.t. the images) is not computed
+        peak = 2500.0 if dt == torch.bfloat16 else 2500.0 / 16      # dense bf16 16x16x32 / f32 16x16x4 MFMA, TFLOP/s
+        print("MFMA rate per pass (of %.0f TFLOP/s dense): fwd %.1f %%  dgrad %.1f %%  wgrad %.1f %%" %
+              ((peak,) + tuple(100.0 * g / t * 1e3 / peak for g, t in zip(gsum, tot))))
 
 
 if __name__ == "__main__":
