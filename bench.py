@@ -134,7 +134,7 @@ def conv_flops_per_step(B, H, W):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per fwd+bwd launch pair from the committed PMC summary (profiles/rN_traffic.json), or None."""
+    """HBM bytes of the fused loss (all its kernels, per step) from the committed PMC summary (profiles/rN_traffic.json), or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
@@ -142,7 +142,7 @@ def pmc_traffic(workload):
     try:
         ks = json.load(open(files[-1]))["kernels"]
         sel = [k for k in ks if k["workload"] == workload]
-        return sum(k["hbm_bytes"] for k in sel) if len(sel) == 2 else None
+        return sum(k["hbm_bytes"] for k in sel) if sel else None     # r1: fwd + bwd kernels; r2 on: the one-pass kernel
     except Exception:
         return None
 

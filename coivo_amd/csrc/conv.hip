@@ -295,22 +295,6 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const int npix = a.toh * a.tow;
 
-    // the two fragment columns (pixels) of this lane
-    int pbase[2];
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        int p = wave * 32 + mf * 16 + l15;
-        if (p >= npix) p = 0;
-        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
-    }
-
-    f32x4 acc[2][NF];
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     // ---- software-pipelined K loop over channel chunks ----
     // Staging goes global -> registers -> LDS.  The registers of chunk k+1 are loaded (all loads of a thread
     // issued back to back) BEFORE the MFMAs of chunk k and written to LDS after them, so global latency hides
@@ -337,18 +321,6 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
         const int tap = gi / NG, cg = gi - tap * NG;
         woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
         woffL = ((WIT - 1) * NTH + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NTH + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
-    if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
-        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NTH) {
-            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
-            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
-        }
     }
     // two named descriptors / offset sets (arrays of descriptors end up in scratch and turn every load into a
     // waterfall loop)
@@ -442,6 +414,44 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
             }
         }
     };
+    // the first DEPTH chunks are requested as soon as their offsets exist; everything the loads do not need (fragment
+    // columns, LDS offsets, the padding granules, the bias) is computed while they are in flight
+    if (!ABL(4)) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int dead = (d < nch) ? 0 : OOB_OFF;
+            load_w(d, dead, wv[d]);
+            load_p(d, dead, pv[d]);
+        }
+    }
+    // the two fragment columns (pixels) of this lane
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
+    }
+
+    f32x4 acc[2][NF];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NTH + tid;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
+        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NTH) {
+            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
+        }
+    }
     // bias of this lane's output channels, fetched now so that its latency is not paid in the epilogue
     u32x4 biasv[NF];
     {
@@ -452,14 +462,6 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     }
 
     TRACE(1);
-    if (!ABL(4)) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int dead = (d < nch) ? 0 : OOB_OFF;
-            load_w(d, dead, wv[d]);
-            load_p(d, dead, pv[d]);
-        }
-    }
 #pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll

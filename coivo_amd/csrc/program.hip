@@ -1,5 +1,5 @@
 // program.hip -- command-list executor: one C-ABI call enqueues a whole recorded sequence of library calls (a network's
-// forward or backward) on two streams.
+// forward or backward) on a main stream and the side stream(s).
 //
 // Why: at batch 8 the DCDP step is ~115 launches of 5-50 us.  Driven call by call from the Python host the enqueue path
 // (~18 us per launch: tensor allocation, ctypes marshalling, event objects for the weight-gradient side stream) was
@@ -30,15 +30,49 @@ hipEvent_t next_event() {
     });
     return g_ev[g_ev_next.fetch_add(1, std::memory_order_relaxed) % NEV];
 }
+
+// A second side stream, owned by the library.  A weight-gradient kernel at its atomics-bound grid size puts ONE 4-wave
+// workgroup on a CU; with a single side stream they run one after the other, and the backward pass ends ~90 us after the
+// input-gradient chain with only such kernels left (profiles/r2_bench_kernel_stats.csv, kernel trace).  Consecutive FORKs
+// alternate between the caller's side stream and this one, so two weight-gradient kernels overlap each other as well as
+// the main stream.  Every call ends with the caller's side stream waiting for this one: joining the caller's stream -- all
+// the host ever does -- covers both.  COLVO_SIDE_STREAMS=1 turns it off.
+hipStream_t g_aux = nullptr;
+std::once_flag g_aux_once;
+
+hipStream_t aux_stream() {
+    std::call_once(g_aux_once, [] {
+        const char* e = getenv("COLVO_SIDE_STREAMS");
+        if (e && atoi(e) < 2) return;
+        if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) g_aux = nullptr;
+    });
+    return g_aux;
+}
+
+int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
+    hipEvent_t e = next_event();
+    hipError_t he = hipEventRecord(e, earlier);
+    if (he == hipSuccess) he = hipStreamWaitEvent(later, e, 0);
+    if (he != hipSuccess) set_error("colvo_run_commands: %s failed: %s", what, hipGetErrorString(he));
+    return (int)he;
+}
 }  // namespace
 
 extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, colvo_stream_t side_stream) {
     COLVO_CHECK_ARG(cmds && n >= 0, "colvo_run_commands: bad arguments");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+    hipStream_t aux = nullptr;
+    if (ss) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) aux = aux_stream();
+    }
+    hipStream_t side_cur = ss;            // where stream-1 commands go until the next FORK
+    bool aux_dirty = false;               // aux holds work the caller's side stream has not been ordered after
     for (int k = 0; k < n; ++k) {
         const ColvoCmd& c = cmds[k];
         COLVO_CHECK_ARG(c.stream == 0 || (c.stream == 1 && ss), "colvo_run_commands: command %d needs a side stream", k);
-        colvo_stream_t s = c.stream ? side_stream : main_stream;
+        colvo_stream_t s = c.stream ? (colvo_stream_t)side_cur : main_stream;
+        if (c.stream && side_cur == aux) aux_dirty = true;
         int rc = 0;
         switch (c.op) {
             case COLVO_CMD_CONV_FWD:
@@ -89,20 +123,14 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 break;
             case COLVO_CMD_FORK: {       // the side stream continues after everything enqueued so far on the main stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");
-                hipEvent_t e = next_event();
-                hipError_t he = hipEventRecord(e, ms);
-                if (he == hipSuccess) he = hipStreamWaitEvent(ss, e, 0);
-                rc = (int)he;
-                if (he != hipSuccess) set_error("colvo_run_commands: fork failed: %s", hipGetErrorString(he));
+                if (aux) side_cur = (side_cur == ss) ? aux : ss;
+                rc = order_after(side_cur, ms, "fork");
                 break;
             }
             case COLVO_CMD_JOIN: {       // the main stream continues after everything enqueued so far on the side stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: JOIN without a side stream");
-                hipEvent_t e = next_event();
-                hipError_t he = hipEventRecord(e, ss);
-                if (he == hipSuccess) he = hipStreamWaitEvent(ms, e, 0);
-                rc = (int)he;
-                if (he != hipSuccess) set_error("colvo_run_commands: join failed: %s", hipGetErrorString(he));
+                rc = order_after(ms, ss, "join");
+                if (rc == 0 && aux_dirty) { rc = order_after(ms, aux, "join"); }
                 break;
             }
             default:
@@ -111,5 +139,6 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
         }
         if (rc != 0) return rc;   // the failing entry point has set the message
     }
+    if (aux_dirty) return order_after(ss, aux, "side-stream hand-back");
     return 0;
 }

@@ -66,7 +66,7 @@ for kern in sorted({n for (n, c, g) in fs if "k_warp_loss" in n and "finalize" n
         wv = ws.get((kern, "WRITE_SIZE", g), 0.0)
         # SURVEY.md §8d bytes: forward 28 B/px, backward (recompute) 32 B/px; the one-pass training kernel does both
         # jobs (60 B/px by that definition while really reading each input once); its scaling kernel has none
-        alg = (60 if "bwd_march<true>" in kern else 0 if "fused_bwd" in kern else 32 if "bwd" in kern else 28) * px
+        alg = (60 if "bwd_march<true>" in kern or "k_warp_loss_fused" == kern else 0 if "fused_bwd" in kern else 32 if "bwd" in kern else 28) * px
         out["kernels"].append({"kernel": kern, "workload": shape, "hbm_read_bytes": v * 1024 * cal_f,
                                "hbm_write_bytes": wv * 1024 * cal_w, "hbm_bytes": v * 1024 * cal_f + wv * 1024 * cal_w,
                                "algorithmic_bytes": alg,
