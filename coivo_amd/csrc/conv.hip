@@ -577,260 +577,6 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 }
 
 // --------------------------------------------------------------------------------------------- //
-// forward / input-gradient kernel, persistent multi-chunk form                                   //
-// --------------------------------------------------------------------------------------------- //
-// k_conv3x3 with a tile loop around the chunk loop.  A one-tile workgroup pays 0.5 us of set-up, 1-1.8 us for the first
-// (un-hidden) stage and ~1 us of epilogue around 2-8 chunks of ~1.4 us, and a grid of 1.25 x the resident slots costs
-// two rounds.  Here the grid is the number of resident slots (a multiple of the n-tile count, so a workgroup keeps ITS
-// output-channel tile: weight offsets and bias are set up once); a workgroup walks the pixel tiles t0, t0 + step, ...
-// and the register prefetch runs THROUGH the tile boundary: chunk 0 of the next tile is in flight during the last
-// chunk's MFMAs and the epilogue stores.  Same LDS layout, staging and MFMA phase as k_conv3x3<.., DEPTH 1>.
-template <typename T, int BN, int NG, bool TAIL>
-__global__ __launch_bounds__(NT, (BN <= 32 && !TAIL) ? 3 : 2) void k_conv3x3_p(const ConvK a, int ntiles, int ntn, uint32_t m_tpi,
-                                                                             uint32_t m_tx) {
-    constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G;
-    constexpr int NGR = 9 * NG;
-    constexpr int STEPS = (NGR + 3) / 4;
-    constexpr int WROW = wrow_bytes(STEPS * 4);
-    constexpr int PIXP = pitch_bytes(NG * 16);
-    constexpr int NF = BN / 16;
-    constexpr int OUTP = BN + 4;
-    constexpr int WTOT = BN * NGR;
-    constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = TAIL ? 9 : 3;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sW = smem;
-    char* sP = smem + BN * WROW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, kg = lane >> 4;
-    const int nt = blockIdx.x % ntn;                        // this workgroup's output-channel tile (fixed)
-    const int n0 = nt * BN;
-    const int tstep = gridDim.x / ntn;                      // the host makes gridDim.x a multiple of ntn
-    const int S = a.g.stride;
-    const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
-    const int npix = a.toh * a.tow;
-    const int ptotal = PH * PW * NG;
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
-
-    int pbase[2];
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-        int p = wave * 32 + mf * 16 + l15;
-        if (p >= npix) p = 0;
-        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
-    }
-
-    // ---- tile-invariant set-up: weight offsets / LDS slots, bias, the patch granules of this thread ----
-    const int tapB = a.Ctot * ES;
-    int woff0, woffL, wlds[WIT];
-    {
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
-    if constexpr (STEPS * 4 != NGR) {
-        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
-            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
-            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
-        }
-    }
-    // this thread's patch granules: granule it*256 + tid = pixel it*(256/NG) + tid/NG, channel granule tid % NG -- the LDS
-    // slot advances by a constant per `it` and the channel granule does not depend on it at all
-    int pyx[PPF];                                           // (py << 16 | px) inside the patch (py = 0x3fff: none)
-    const int pcg16 = (tid & (NG - 1)) * 16;
-    const int plds0 = (tid / NG) * PIXP + pcg16;
-    constexpr int PLDS_STEP = (NT / NG) * PIXP;
-#pragma unroll
-    for (int it = 0; it < PPF; ++it) {
-        const int i = it * NT + tid;
-        const int pix = i / NG;
-        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-        pyx[it] = (i < ptotal) ? ((py << 16) | px) : (0x3fff << 16);
-    }
-    // descriptors over the WHOLE tensors (host guarantees < 1 GiB each): image and channel chunk go into the scalar offset
-    const int nimg = ntiles / tiles_per_img;
-    const int img0 = a.g.Hs[0] * a.g.Ws[0] * a.g.C[0] * ES, img1 = a.g.Hs[1] * a.g.Ws[1] * a.g.C[1] * ES;
-    const int img_out = a.Ho * a.Wo * a.N * ES;
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rimg0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, nimg * img0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rimg1 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.g.src[1] ? a.g.src[1] : a.g.src[0]), 0, a.g.C[1] > 0 ? nimg * img1 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, nimg * img_out, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rmask =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask ? a.mask : a.out), 0, a.mask ? nimg * img_out : 0, 0x00020000);
-    u32x4 biasv[NF];
-    {
-        const __amdgpu_buffer_rsrc_t rbias =
-            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
-#pragma unroll
-        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);
-    }
-
-    struct TileO { int b, oy0, ox0; };
-    auto tile_origin = [&](int tile) -> TileO {             // wave-uniform; magic divisions (host checks the ranges)
-        const int t = __builtin_amdgcn_readfirstlane(tile);
-        const int b = mdiv(t, m_tpi), tr_ = t - b * tiles_per_img;
-        const int ty = mdiv(tr_, m_tx), tx = tr_ - ty * a.tiles_x;
-        return TileO{b, ty * a.toh, tx * a.tow};
-    };
-    // per-tile byte offsets of this thread's patch granules inside an image of source 0 / 1 (OOB_OFF: padding)
-    int poff0[PPF], poff1[PPF];
-    auto tile_offsets = [&](const TileO& o) {
-        const int iy0 = o.oy0 * S - 1, ix0 = o.ox0 * S - 1;
-#pragma unroll
-        for (int sidx = 0; sidx < 2; ++sidx) {
-            const int Ws = a.g.Ws[sidx], Cs = a.g.C[sidx], mode = a.g.mode[sidx];
-            const int sh = (mode != MODE_DIRECT) ? 1 : 0, par = (mode == MODE_DILATE) ? 1 : 0;
-#pragma unroll
-            for (int it = 0; it < PPF; ++it) {
-                const int vy = iy0 + (pyx[it] >> 16), vx = ix0 + (pyx[it] & 0xffff);
-                const bool inb = ((unsigned)vy < (unsigned)a.g.Hi) && ((unsigned)vx < (unsigned)a.g.Wi) && (((vy | vx) & par) == 0);
-                const int off = (inb && Cs > 0) ? (((vy >> sh) * Ws + (vx >> sh)) * Cs * ES + pcg16) : OOB_OFF;
-                if (sidx == 0) poff0[it] = off; else poff1[it] = off;
-            }
-        }
-    };
-    u32x4 wv[WIT], pv[PPF];
-    auto load_w = [&](int k, int dead) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            wv[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    };
-    auto load_p = [&](int k, int bimg, int dead) {          // chunk k of the tile whose offsets are in poff0 / poff1
-        const int sidx = (k < nch0) ? 0 : 1;
-        const int c0 = (k - (sidx ? nch0 : 0)) * CK;
-        if (sidx == 0) {
-            const int so = bimg * img0 + c0 * ES;
-#pragma unroll
-            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg0, poff0[it] | dead, so);
-        } else {
-            const int so = bimg * img1 + c0 * ES;
-#pragma unroll
-            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, poff1[it] | dead, so);
-        }
-    };
-    auto store_wp = [&]() {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
-#pragma unroll
-        for (int it = 0; it < PPF; ++it)
-            if ((pyx[it] >> 16) != 0x3fff) st16(sP + plds0 + it * PLDS_STEP, pv[it]);
-    };
-
-    int tile = blockIdx.x / ntn;
-    if (tile >= ntiles) return;                             // (the host never launches such a workgroup)
-    TileO cur = tile_origin(tile);
-    tile_offsets(cur);
-    load_w(0, 0);
-    load_p(0, cur.b, 0);
-    for (; tile < ntiles; tile += tstep) {
-        const int next = tile + tstep;
-        const bool has_next = next < ntiles;                // wave-uniform
-        const TileO nxt = tile_origin(has_next ? next : 0);
-        f32x4 acc[2][NF];
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        Epi<T, NF> ep;
-        for (int k = 0; k < nch; ++k) {
-            __syncthreads();                                // the previous MFMA phase / pool2 epilogue has finished with LDS
-            store_wp();
-            __syncthreads();
-            // next stage into registers: chunk k+1 of this tile, or chunk 0 of the next one (through the tile boundary)
-            const bool last = (k + 1 == nch);
-            if (last) {
-                if (!a.pool2) {                             // mask / accumulate operands of THIS tile: in flight during its last MFMAs
-                    ep.offsets(a, cur.oy0, cur.ox0, n0, wave, l15, kg);   // (issued BEFORE the next tile's loads: vmcnt retires in
-                    ep.prefetch(a, rout, rmask, cur.b * img_out);         //  order, the epilogue must not wait for those)
-                }
-                if (has_next) tile_offsets(nxt);
-                const int dead = has_next ? 0 : OOB_OFF;
-                load_w(0, dead);
-                load_p(0, nxt.b, dead);
-            } else {
-                load_w(k + 1, 0);
-                load_p(k + 1, cur.b, 0);
-            }
-            // MFMA phase (fragments of k-group m+1 are read before the MFMAs of k-group m are issued)
-            {
-                u32x4 av[2][2], bv[2][NF];
-                auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
-                    const int gi = 4 * m + kg;
-                    int tap = gi / NG;
-                    const int cg = gi - tap * NG;
-                    tap = min(tap, 8);
-                    const int ky = tap / 3, kx = tap - 3 * ky;
-                    const int aoff = (ky * PW + kx) * PIXP + cg * 16;
-#pragma unroll
-                    for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
-#pragma unroll
-                    for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + gi * 16);
-                };
-                read_frags(0, av[0], bv[0]);
-#pragma unroll
-                for (int m = 0; m < STEPS; ++m) {
-                    const int c = m & 1;
-                    if (m + 1 < STEPS) read_frags(m + 1, av[c ^ 1], bv[c ^ 1]);
-                    if constexpr (ES == 2) {
-#pragma unroll
-                        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                            for (int nf = 0; nf < NF; ++nf)
-                                acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, bv[c][nf]), __builtin_bit_cast(bf16x8, av[c][mf]), acc[mf][nf], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                                for (int nf = 0; nf < NF; ++nf)
-                                    acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                        __uint_as_float(bv[c][nf][j]), __uint_as_float(av[c][mf][j]), acc[mf][nf], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[2 * NF]>(acc));
-        if (!a.pool2) {
-            ep.finish(a, acc, biasv, rout, cur.b * img_out);
-        } else {
-            __syncthreads();                                // every wave is done reading LDS: it becomes the fp32 output tile
-            float* sOut = reinterpret_cast<float*>(smem);
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-                for (int nf = 0; nf < NF; ++nf)
-                    *reinterpret_cast<f32x4*>(&sOut[(wave * 32 + mf * 16 + l15) * OUTP + nf * 16 + 4 * kg]) = acc[mf][nf];
-            __syncthreads();
-            conv_epilogue<T, BN>(a, sOut, cur.b, cur.oy0, cur.ox0, n0, tid);
-            if constexpr (STEPS * 4 != NGR) {               // sOut overlays the weight slab: restore its zero padding granules
-                __syncthreads();
-                for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
-                    const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
-                    st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
-                }
-            }
-        }
-        cur = nxt;
-    }
-}
-
-// --------------------------------------------------------------------------------------------- //
 // forward / input-gradient kernel, weights-resident persistent form                              //
 // --------------------------------------------------------------------------------------------- //
 // For single-chunk layers (C <= 32 bf16 / 16 f32: the high-resolution ends of the networks) a workgroup's work is a
@@ -1080,28 +826,14 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     return 0;
 }
 
-template <typename T, int BN, int NG, bool TAIL> int launch_conv_p_tail(const ConvK& k, int B, hipStream_t s);
-inline bool persistent_ok(const ConvK& k, int B, int es);
-
 template <typename T, int BN, int NG, int DEPTH = 1>
 int launch_conv(const ConvK& k, int B, hipStream_t s) {
     const int S = k.g.stride;
     const long ptotal = (long)((k.toh - 1) * S + 3) * ((k.tow - 1) * S + 3) * NG;
-    if constexpr (DEPTH == 1) {
-        // persistent multi-chunk form whenever the walk is long enough to pay (>= COLVO_P_MIN_WALK tiles per workgroup)
-        // off by default: measured 5-25 % SLOWER than the one-tile form on the DepthNet layers at B = 16 (3 instead of 4 resident
-        // workgroups per CU at 162 VGPRs; gpurun_out/r2_bench_conv_p*.log) -- kept for larger batches / further tuning
-        static const int p_on = [] { const char* e = getenv("COLVO_PERSIST"); return e ? atoi(e) : 0; }();
-        static const double p_min_walk = [] { const char* e = getenv("COLVO_P_MIN_WALK"); return e ? atof(e) : 1.2; }();
-        if (p_on && persistent_ok(k, B, TT<T>::ES)) {
-            const bool tail = ptotal > 3 * NT;
-            const long ntiles = (long)k.tiles_x * k.tiles_y * B, ntn = (k.N + BN - 1) / BN;
-            const int by_regs = (BN <= 32 && !tail) ? 3 : 2;
-            const double walk = (double)ntiles * ntn / (256.0 * by_regs);
-            if (walk >= p_min_walk)
-                return tail ? launch_conv_p_tail<T, BN, NG, true>(k, B, s) : launch_conv_p_tail<T, BN, NG, false>(k, B, s);
-        }
-    }
+    // (A persistent multi-chunk form -- grid = resident slots, a workgroup walks several pixel tiles with the register prefetch
+    // running through the tile boundary -- was built and measured this round: 5-25 % SLOWER on every DepthNet layer at B = 16
+    // (up3 18.8 -> 22.7 us): it needs 162 VGPRs, i.e. 3 instead of 4 resident workgroups per CU, and an evened-out walk leaves
+    // 2.5 workgroups per CU.  Removed)
     if (ptotal > 3 * NT) return launch_conv_tail<T, BN, NG, (DEPTH > 2 ? 2 : DEPTH), true>(k, B, s);   // depth 3 would spill
     if constexpr (DEPTH >= 2) {
         const int nch = (k.g.C[0] + k.g.C[1]) / (NG * TT<T>::G);
@@ -1109,54 +841,6 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
         if (nch == 16) return launch_conv_tail<T, BN, NG, DEPTH, false, 16>(k, B, s);
     }
     return launch_conv_tail<T, BN, NG, DEPTH, false>(k, B, s);
-}
-
-// persistent multi-chunk kernel: grid = resident slots rounded to a multiple of the n-tile count
-template <typename T, int BN, int NG, bool TAIL>
-int launch_conv_p_tail(const ConvK& k, int B, hipStream_t s) {
-    constexpr int STEPS = (9 * NG + 3) / 4;
-    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
-    const int S = k.g.stride;
-    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
-    size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
-    const size_t eplds = (size_t)BM * (BN + 4) * 4;
-    if (eplds > lds) lds = eplds;
-    COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
-    static size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_p<T, BN, NG, TAIL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-        configured = 160 * 1024;
-    }
-    const int ntiles = k.tiles_x * k.tiles_y * B;
-    const int ntn = (k.N + BN - 1) / BN;
-    // resident workgroups per CU: registers (launch bounds: 3 for the narrow stride-1 form, else 2) and LDS
-    const int by_regs = (BN <= 32 && !TAIL) ? 3 : 2;
-    int per_cu = (int)std::min<size_t>((size_t)by_regs, (160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
-    static const int p_wg_per_cu = [] { const char* e = getenv("COLVO_P_WG_PER_CU"); return e ? atoi(e) : 0; }();   // tuning knob
-    if (p_wg_per_cu > 0) per_cu = p_wg_per_cu;
-    long slots = 256L * per_cu;
-    long tiles_par = std::max(1L, std::min((long)ntiles, slots / ntn));      // pixel tiles in flight
-    // even out the walk: every workgroup gets ceil(ntiles / tiles_par) or one fewer
-    const long walk = (ntiles + tiles_par - 1) / tiles_par;
-    tiles_par = (ntiles + walk - 1) / walk;
-    dim3 grid((unsigned)(tiles_par * ntn), 1, 1);
-    hipLaunchKernelGGL((k_conv3x3_p<T, BN, NG, TAIL>), grid, dim3(NT), lds, s, k, ntiles, ntn,
-                       mdiv_magic(k.tiles_x * k.tiles_y), mdiv_magic(k.tiles_x));
-    COLVO_CHECK_LAUNCH("k_conv3x3_p");
-    return 0;
-}
-
-// can the persistent kernels address this problem?  (32-bit buffer offsets over whole tensors, magic-division ranges)
-inline bool persistent_ok(const ConvK& k, int B, int es) {
-    const long long s0 = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * es;
-    const long long s1 = (long long)B * k.g.Hs[1] * k.g.Ws[1] * k.g.C[1] * es;
-    const long long so = (long long)B * k.Ho * k.Wo * k.N * es / (k.pool2 ? 4 : 1);
-    const long long tpi = (long long)k.tiles_x * k.tiles_y;
-    return s0 < 0x40000000LL && s1 < 0x40000000LL && so < 0x40000000LL && tpi >= 2 && k.tiles_x >= 2 &&
-           tpi * tpi * B < 0x100000000LL && tpi * B < 65536;
 }
 
 template <typename T, int BN, int NG>
