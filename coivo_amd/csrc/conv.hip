@@ -189,6 +189,27 @@ struct Epi {
             for (int mf = 0; mf < 2; ++mf) off[mf][nf] = obase[mf] + noff;     // out of range -> loads 0 / store dropped
         }
     }
+    // k_dgrad_s2: the lane's two pixels are positions (gy, gx) of the OUTPUT-gradient tile; parity class (py, px) of the input
+    // gradient lives at (2 gy + py, 2 gx + px) of an image twice that size
+    __device__ __forceinline__ void offsets_s2(const ConvK& a, int oy0, int ox0, int n0, int wave, int l15, int kg, int py, int px) {
+        const int npix = a.toh * a.tow;
+        int obase[2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf) {
+            const int p = wave * 32 + mf * 16 + l15;
+            const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+            const int gy = oy0 + oy, gx = ox0 + ox;
+            const bool ok = (p < npix) && (gy < a.Ho) && (gx < a.Wo);
+            obase[mf] = ok ? ((2 * gy + py) * (2 * a.Wo) + 2 * gx + px) * a.N * ES : OOB_OFF;
+        }
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const int n = n0 + nf * 16 + kg * 4;
+            const int noff = (n < a.N) ? n * ES : OOB_OFF;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) off[mf][nf] = obase[mf] + noff;
+        }
+    }
     __device__ __forceinline__ void prefetch(const ConvK& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rmask, int soff) {
         if (a.mask) {
 #pragma unroll
@@ -577,6 +598,195 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 }
 
 // --------------------------------------------------------------------------------------------- //
+// input gradient of a STRIDE-2 conv, parity-decomposed                                           //
+// --------------------------------------------------------------------------------------------- //
+// dx[iy][ix][ci] = sum_{ky,kx,co} w[co][ky][kx][ci] * dy[oy][ox][co] with 2 oy + ky - 1 = iy: an even input row sees only
+// ky = 1 (oy = iy/2), an odd one ky = 0 (oy = (iy+1)/2) and ky = 2 (oy = (iy-1)/2); likewise the columns.  So the four
+// parity classes (iy & 1, ix & 1) of dx are 1-, 2-, 2- and 4-tap convolutions over dy.  As a stride-1 conv over the
+// zero-dilated dy (the general kernel's MODE_DILATE) three quarters of the MFMAs multiply inserted zeros and the patch of a
+// 128-pixel tile is 10 x 18 dilated pixels of which 45 are real.  Here a workgroup takes a tile of 128 dy POSITIONS, stages
+// their (toh+1) x (tow+1) patch and the usual [BN][9][CK] weight slab per chunk, and runs the nine taps ONCE: with 32-channel
+// chunks a k-group IS a tap, so each k-group's MFMAs go to the accumulator set of the tap's parity class (4 sets), reading
+// the patch at the tap's (+1 row if ky == 0, +1 column if kx == 0) offset.  Same MFMA count as one ordinary 3x3 tile, but
+// 512 input-gradient pixels instead of 128: a quarter of the MFMAs, a quarter of the workgroups, no dead patch bytes.
+// The weight operand is the flipped layout w_bwd [Cin][8 - tap][Cout] the dilated form uses (slot m holds tap 8 - m).
+template <typename T, int BN, int DEPTH, int NCH = 0>
+__global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_dgrad_s2(const ConvK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int WROW = wrow_bytes(STEPS * 4);     // rows of 36 granules: nothing to zero-pad
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int NF = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int tlin = lid / a.ntn;
+    const int n0 = (lid - tlin * a.ntn) * BN;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int b = tlin / tpi, trem = tlin - b * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int oy0 = ty * a.toh, ox0 = tx * a.tow;       // tile origin in dy
+    const int PH = a.toh + 1, PW = a.tow + 1;
+    const int npix = a.toh * a.tow;
+
+    constexpr int WTOT = BN * NGR;
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = 3;                              // (toh+1)(tow+1) <= 9 x 17 pixels x 4 granules = 612 <= 768
+    const int ptotal = PH * PW * NG;
+    const int nch = NCH ? NCH : a.g.C[0] / CK;
+    u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
+
+    const int tapB = a.Ctot * ES;
+    int woff0, woffL;
+    {
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
+    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
+    int poff[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        const int vy = oy0 + py, vx = ox0 + px;           // the row / column past dy's edge reads zeros
+        const bool inb = (i < ptotal) && (vy < Hs) && (vx < Ws);
+        poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
+    }
+    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+    };
+    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg, poff[it] | dead, so);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const int dead = (d < nch) ? 0 : OOB_OFF;
+        load_w(d, dead, wv[d]);
+        load_p(d, dead, pv[d]);
+    }
+    int wlds[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NT + tid;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    auto store_w = [&](const u32x4 (&w)[WIT]) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
+    };
+    auto store_p = [&](const u32x4 (&pvv)[PPF]) {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
+        }
+    };
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        pbase[mf] = (oy * PW + ox) * PIXP;
+    }
+    f32x4 acc[4][2][NF];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+    for (int k0 = 0; k0 < nch; k0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 + d;
+        if (DEPTH > 1 && k >= nch) break;
+        __syncthreads();
+        store_w(wv[d]);
+        store_p(pv[d]);
+        __syncthreads();
+        {
+            const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
+            load_w(k + DEPTH, dead, wv[d]);
+            load_p(k + DEPTH, dead, pv[d]);
+        }
+        u32x4 av[2][2], bv[2][NF];
+        auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
+            const int t = 8 - m, ky = t / 3, kx = t - 3 * ky;       // slot m of the flipped slab holds tap 8 - m
+            const int aoff = ((ky == 0 ? PW : 0) + (kx == 0 ? 1 : 0)) * PIXP + kg * 16;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) br[nf] = ld16(sW + (nf * 16 + l15) * WROW + (4 * m + kg) * 16);
+        };
+        read_frags(0, av[0], bv[0]);
+#pragma unroll
+        for (int m = 0; m < STEPS; ++m) {
+            const int cur = m & 1;
+            if (m + 1 < STEPS) read_frags(m + 1, av[cur ^ 1], bv[cur ^ 1]);
+            const int t = 8 - m, ky = t / 3, kx = t - 3 * ky;
+            const int cls = (ky != 1 ? 2 : 0) | (kx != 1 ? 1 : 0);   // parity class (iy & 1, ix & 1) this tap feeds
+            if constexpr (ES == 2) {
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf)
+                        acc[cls][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, bv[cur][nf]), __builtin_bit_cast(bf16x8, av[cur][mf]),
+                            acc[cls][mf][nf], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[cls][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                __uint_as_float(bv[cur][nf][j]), __uint_as_float(av[cur][mf][j]), acc[cls][mf][nf], 0, 0, 0);
+            }
+        }
+      }
+    }
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[8 * NF]>(acc));
+
+    const int img_bytes = 4 * a.Ho * a.Wo * a.N * ES;          // the input gradient: (2 Ho) x (2 Wo) x N
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
+    u32x4 nobias[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) nobias[nf] = u32x4{0u, 0u, 0u, 0u};
+    Epi<T, NF> ep[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                                // all four classes' mask / accumulate loads first
+        ep[c].offsets_s2(a, oy0, ox0, n0, wave, l15, kg, c >> 1, c & 1);
+        ep[c].prefetch(a, rout, rmask, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ep[c].finish(a, acc[c], nobias, rout, 0);
+}
+
+// --------------------------------------------------------------------------------------------- //
 // forward / input-gradient kernel, weights-resident persistent form                              //
 // --------------------------------------------------------------------------------------------- //
 // For single-chunk layers (C <= 32 bf16 / 16 f32: the high-resolution ends of the networks) a workgroup's work is a
@@ -955,6 +1165,42 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
 
+// parity-decomposed stride-2 input gradient (k_dgrad_s2): tiles over dy, four output pixels per tile position
+template <typename T, int BN, int DEPTH, int NCH>
+int launch_dgrad_s2_inst(ConvK k, int B, hipStream_t s) {
+    constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
+    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 1) * (k.tow + 1) * PIXP;
+    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    k.ntn = (k.N + BN - 1) / BN;
+    k.xcd = xcd_on;
+    const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
+    COLVO_CHECK_ARG(nwg < (1ll << 30) && lds <= 48 * 1024, "dgrad (stride 2): bad launch geometry");
+    hipLaunchKernelGGL((k_dgrad_s2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_dgrad_s2");
+    return 0;
+}
+
+template <typename T, int BN>
+int launch_dgrad_s2_bn(const ConvK& k, int B, hipStream_t s) {
+    const int nch = k.g.C[0] / (4 * TT<T>::G);
+    const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
+    static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 512L; }();
+    if (wgs <= lone_max) {          // about one workgroup per CU: two chunks in flight, K loop unrolled (see launch_conv_ng)
+        if (nch == 8) return launch_dgrad_s2_inst<T, BN, 2, 8>(k, B, s);
+        if (nch == 16) return launch_dgrad_s2_inst<T, BN, 2, 16>(k, B, s);
+    }
+    return launch_dgrad_s2_inst<T, BN, 1, 0>(k, B, s);
+}
+
+template <typename T>
+int launch_dgrad_s2(ConvK k, int B, hipStream_t s) {
+    const Tile t = pick_tile(k.Ho, k.Wo, 1, false);
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (k.Wo + t.tow - 1) / t.tow; k.tiles_y = (k.Ho + t.toh - 1) / t.toh;
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 1);
+    return k.N > 16 ? launch_dgrad_s2_bn<T, 32>(k, B, s) : launch_dgrad_s2_bn<T, 16>(k, B, s);
+}
+
 }  // namespace
 }  // namespace colvo
 
@@ -983,6 +1229,26 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     const int coff = src == 0 ? 0 : d->C0;
     const int up = src == 0 ? d->up0 : d->up1;
     ConvK k{};
+    {
+        // stride 2, even input extent, 32-channel chunks of dy: the parity-decomposed kernel (a quarter of the MFMAs)
+        static const int s2_on = [] { const char* e = getenv("COLVO_NO_DGRAD_S2"); return e ? 0 : 1; }();
+        const int ck = d->dtype == COLVO_F32 ? 16 : 32;
+        const long long out_bytes = (long long)d->Hi * d->Wi * Csrc * es, in_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
+        if (s2_on && d->stride == 2 && !up && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && d->Cout % ck == 0 &&
+            out_bytes < 0x40000000LL && in_bytes < 0x40000000LL) {
+            k.g.src[0] = (const char*)dy; k.g.src[1] = nullptr;
+            k.g.C[0] = d->Cout; k.g.C[1] = 0;
+            k.g.Hs[0] = d->Ho; k.g.Ws[0] = d->Wo; k.g.Hs[1] = k.g.Ws[1] = 0;
+            k.g.mode[0] = k.g.mode[1] = MODE_DIRECT;
+            k.g.Hi = d->Ho; k.g.Wi = d->Wo; k.g.stride = 1;
+            k.Ho = d->Ho; k.Wo = d->Wo;                // tiles run over dy; the kernel writes a (2 Ho) x (2 Wo) image
+            k.w = (const char*)w_bwd + (size_t)coff * 9 * d->Cout * es; k.Ctot = d->Cout; k.N = Csrc;
+            k.bias = nullptr; k.relu = 0; k.out = (char*)dx; k.mask = (const char*)relu_mask;
+            k.accumulate = accumulate; k.pool2 = 0;
+            return d->dtype == COLVO_F32 ? launch_dgrad_s2<float>(k, d->B, (hipStream_t)stream)
+                                         : launch_dgrad_s2<bf16_t>(k, d->B, (hipStream_t)stream);
+        }
+    }
     // the conv input is dy (Cout channels), dilated by zero insertion when the forward stride was 2
     k.g.src[0] = (const char*)dy; k.g.src[1] = nullptr;
     k.g.C[0] = d->Cout; k.g.C[1] = 0;

@@ -130,7 +130,7 @@ inline uint32_t mdiv_magic(int d) { return (uint32_t)((0x100000000ULL + (uint32_
 #define MG_(i) COLVO_ACC_CONSTRAINT(acc[i])
 template <typename T, int N>
 __device__ __forceinline__ void mfma_result_guard(f32x4 (&acc)[N]) {
-    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10 || N == 12 || N == 20,
+    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 5 || N == 6 || N == 8 || N == 10 || N == 12 || N == 16 || N == 20,
                   "mfma_result_guard: add a case for this accumulator count");
     // "s_nop 1" in front: the zero operand may have been written by the VALU instruction just before (VALU write -> MFMA read)
 #define MFMA_GUARD_BODY()                                                                                                  \
@@ -155,6 +155,12 @@ __device__ __forceinline__ void mfma_result_guard(f32x4 (&acc)[N]) {
         asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
                      MFMA_TERM_TAIL                                                                                      \
                      : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11)   \
+                     : [z] "v"(z));                                                                                      \
+    else if constexpr (N == 16)                                                                                          \
+        asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \
+                     MT_(12) MT_(13) MT_(14) MT_(15) MFMA_TERM_TAIL                                                      \
+                     : MG_(0), MG_(1), MG_(2), MG_(3), MG_(4), MG_(5), MG_(6), MG_(7), MG_(8), MG_(9), MG_(10), MG_(11),  \
+                       MG_(12), MG_(13), MG_(14), MG_(15)                                                                \
                      : [z] "v"(z));                                                                                      \
     else                                                                                                                 \
         asm volatile("s_nop 1\n\t" MT_(0) MT_(1) MT_(2) MT_(3) MT_(4) MT_(5) MT_(6) MT_(7) MT_(8) MT_(9) MT_(10) MT_(11)        \

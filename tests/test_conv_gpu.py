@@ -51,6 +51,13 @@ CASES = [
     (4, 256, 320, 16, 0, False, False, 16, 1),    # >= 2048 tiles, single chunk: weights-resident persistent kernel
     (4, 256, 320, 32, 0, True, False, 16, 1),     # ... its dgrad with the 2x2 sum-pool of an up-sampled source
     (8, 128, 160, 32, 0, False, False, 32, 1),    # ... 32-wide
+    # stride 2 with an even input: the parity-decomposed input gradient (k_dgrad_s2)
+    (2, 32, 40, 64, 0, False, False, 128, 2),     # 4 chunks (bf16), two N tiles, ragged tiles (16 x 20 positions)
+    (2, 16, 20, 128, 0, False, False, 256, 2),    # 8 chunks, few workgroups: unrolled two-chunk ring
+    (1, 16, 20, 256, 0, False, False, 512, 2),    # 16 chunks
+    (2, 64, 80, 8, 0, False, False, 32, 2),       # 8 input channels: narrower than the 16-wide channel tile
+    (3, 12, 18, 40, 0, False, False, 64, 2),      # channel count that is only a multiple of 8; 6 x 9 positions
+    (2, 2, 2, 32, 0, False, False, 32, 2),        # one position per image
 ]
 
 
