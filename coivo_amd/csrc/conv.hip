@@ -787,6 +787,206 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
 }
 
 // --------------------------------------------------------------------------------------------- //
+// forward conv over a nearest-2x UP-SAMPLED source, four output pixels per source position       //
+// --------------------------------------------------------------------------------------------- //
+// y[2a+py][2b+px] = sum_taps w[ky][kx] * x[a + r(py,ky)][b + r(px,kx)],  r(0,.) = (-1, 0, 0),  r(1,.) = (0, 0, +1): the 2x2
+// outputs above one source position read the same 3x3 source neighbourhood.  The general kernel treats them as four
+// unrelated pixels of the up-sampled image: a 128-pixel tile stages a 10x18-pixel patch and the [BN][9][CK] weight slab for
+// 144 MFMAs.  Here a workgroup takes a tile of 128 SOURCE positions, stages their (toh+2) x (tow+2) patch and the slab once
+// per chunk and runs 4 x 144 MFMAs on them (four accumulator sets, one per output parity class): per MFMA a quarter of the
+// staging, and 0.47 instead of 1.0 LDS fragment reads (the weight fragments of a tap serve all four classes, and a centre
+// row / column tap reads ONE patch fragment for both parities).  The chunk loop is then bound by the MFMA pipe, not by
+// its staging latency chain.
+template <typename T, int BN, int DEPTH, int NCH = 0>
+__global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int WROW = wrow_bytes(STEPS * 4);
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int NF = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int tlin = lid / a.ntn;
+    const int n0 = (lid - tlin * a.ntn) * BN;
+    const int tpi = a.tiles_x * a.tiles_y;
+    const int b = tlin / tpi, trem = tlin - b * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int oy0 = ty * a.toh, ox0 = tx * a.tow;       // tile origin in the stored (half-size) source
+    const int PH = a.toh + 2, PW = a.tow + 2;
+    const int npix = a.toh * a.tow;
+
+    constexpr int WTOT = BN * NGR;
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = 3;                              // host: (toh+2)(tow+2) x 4 granules <= 768
+    const int ptotal = PH * PW * NG;
+    const int nch = NCH ? NCH : a.g.C[0] / CK;
+    u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
+
+    const int tapB = a.Ctot * ES;
+    int woff0, woffL;
+    {
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
+    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
+    int poff[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        const int vy = oy0 - 1 + py, vx = ox0 - 1 + px;
+        const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
+        poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
+    }
+    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+    };
+    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg, poff[it] | dead, so);
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        const int dead = (d < nch) ? 0 : OOB_OFF;
+        load_w(d, dead, wv[d]);
+        load_p(d, dead, pv[d]);
+    }
+    int wlds[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NT + tid;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    auto store_w = [&](const u32x4 (&w)[WIT]) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
+    };
+    auto store_p = [&](const u32x4 (&pvv)[PPF]) {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
+        }
+    };
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        pbase[mf] = (oy * PW + ox) * PIXP;                  // patch pixel (oy, ox) = source position (a - 1, b - 1)
+    }
+    u32x4 biasv[NF];
+    {
+        const __amdgpu_buffer_rsrc_t rbias =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);
+    }
+    f32x4 acc[4][2][NF];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+    for (int k0 = 0; k0 < nch; k0 += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int k = k0 + d;
+        if (DEPTH > 1 && k >= nch) break;
+        __syncthreads();
+        store_w(wv[d]);
+        store_p(pv[d]);
+        __syncthreads();
+        {
+            const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
+            load_w(k + DEPTH, dead, wv[d]);
+            load_p(k + DEPTH, dead, pv[d]);
+        }
+#pragma unroll
+        for (int m = 0; m < STEPS; ++m) {
+            const int ky = m / 3, kx = m - 3 * ky;
+            u32x4 bv[NF];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + (4 * m + kg) * 16);
+            // patch row of parity py for tap row ky: (0,1,1) for py = 0, (1,1,2) for py = 1 -- the centre tap serves both
+            const int nrv = (ky == 1) ? 1 : 2, ncv = (kx == 1) ? 1 : 2;
+            u32x4 av[2][2][2];
+#pragma unroll
+            for (int rv = 0; rv < 2; ++rv)
+#pragma unroll
+                for (int cv = 0; cv < 2; ++cv) {
+                    if (rv >= nrv || cv >= ncv) continue;
+                    const int ro = (ky == 0) ? rv : (ky == 1) ? 1 : 1 + rv;
+                    const int co = (kx == 0) ? cv : (kx == 1) ? 1 : 1 + cv;
+                    const int aoff = (ro * PW + co) * PIXP + kg * 16;
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) av[rv][cv][mf] = ld16(sP + pbase[mf] + aoff);
+                }
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int rv = (ky == 1) ? 0 : py, cv = (kx == 1) ? 0 : px;
+                    const int cls = 2 * py + px;
+                    if constexpr (ES == 2) {
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf)
+                                acc[cls][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, bv[nf]), __builtin_bit_cast(bf16x8, av[rv][cv][mf]),
+                                    acc[cls][mf][nf], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                                for (int nf = 0; nf < NF; ++nf)
+                                    acc[cls][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        __uint_as_float(bv[nf][j]), __uint_as_float(av[rv][cv][mf][j]), acc[cls][mf][nf], 0, 0, 0);
+                    }
+                }
+        }
+      }
+    }
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[8 * NF]>(acc));
+
+    const int img_bytes = 4 * a.Ho * a.Wo * a.N * ES;          // the output: (2 Ho) x (2 Wo) x N
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        Epi<T, NF> ep;
+        ep.offsets_s2(a, oy0, ox0, n0, wave, l15, kg, c >> 1, c & 1);
+        ep.prefetch(a, rout, rmask, 0);                          // (forward: no mask, no accumulate -- nothing is loaded)
+        ep.finish(a, acc[c], biasv, rout, 0);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
 // forward / input-gradient kernel, weights-resident persistent form                              //
 // --------------------------------------------------------------------------------------------- //
 // For single-chunk layers (C <= 32 bf16 / 16 f32: the high-resolution ends of the networks) a workgroup's work is a
@@ -1165,6 +1365,29 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
 
+// forward over an up-sampled source (k_conv_up2): tiles over the stored half-size source
+template <typename T, int BN, int DEPTH, int NCH>
+int launch_conv_up2_inst(ConvK k, int B, hipStream_t s) {
+    constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
+    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 2) * (k.tow + 2) * PIXP;
+    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    k.ntn = (k.N + BN - 1) / BN;
+    k.xcd = xcd_on;
+    const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
+    COLVO_CHECK_ARG(nwg < (1ll << 30) && lds <= 48 * 1024, "conv (up-sampled source): bad launch geometry");
+    hipLaunchKernelGGL((k_conv_up2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_conv_up2");
+    return 0;
+}
+
+template <typename T, int BN>
+int launch_conv_up2_bn(const ConvK& k, int B, hipStream_t s) {
+    const int nch = k.g.C[0] / (4 * TT<T>::G);
+    if (nch == 8) return launch_conv_up2_inst<T, BN, 2, 8>(k, B, s);
+    if (nch == 16) return launch_conv_up2_inst<T, BN, 2, 16>(k, B, s);
+    return launch_conv_up2_inst<T, BN, 1, 0>(k, B, s);
+}
+
 // parity-decomposed stride-2 input gradient (k_dgrad_s2): tiles over dy, four output pixels per tile position
 template <typename T, int BN, int DEPTH, int NCH>
 int launch_dgrad_s2_inst(ConvK k, int B, hipStream_t s) {
@@ -1215,6 +1438,33 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
     k.Ho = d->Ho; k.Wo = d->Wo;
     k.w = (const char*)w_fwd; k.Ctot = d->C0 + d->C1; k.N = d->Cout;
     k.bias = bias; k.relu = d->relu; k.out = (char*)y; k.mask = nullptr; k.accumulate = 0; k.pool2 = 0;
+    {
+        // single up-sampled source with at least two 32-channel chunks: four output pixels per source position (k_conv_up2)
+        static const int up2_on = [] { const char* e = getenv("COLVO_NO_CONV_UP2"); return e ? 0 : 1; }();
+        const int es = d->dtype == COLVO_F32 ? 4 : 2, ck = d->dtype == COLVO_F32 ? 16 : 32;
+        const long long in_bytes = (long long)(d->Hi / 2) * (d->Wi / 2) * d->C0 * es, out_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
+        if (up2_on && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->C0 / ck >= 2 &&
+            in_bytes < 0x40000000LL && out_bytes < 0x40000000LL) {
+            ConvK u = k;
+            u.g.mode[0] = MODE_DIRECT;                    // read the stored half-size source as it is
+            u.g.Hi = d->Hi / 2; u.g.Wi = d->Wi / 2;
+            u.Ho = d->Hi / 2; u.Wo = d->Wi / 2;           // tiles run over source positions; the kernel writes (2 Ho) x (2 Wo)
+            const Tile t = pick_tile(u.Ho, u.Wo, 1, false);
+            if ((t.toh + 2) * (t.tow + 2) * 4 <= 3 * NT) {
+                u.toh = t.toh; u.tow = t.tow;
+                u.tiles_x = (u.Wo + t.tow - 1) / t.tow; u.tiles_y = (u.Ho + t.toh - 1) / t.toh;
+                u.m_tow = mdiv_magic(t.tow); u.m_pw = mdiv_magic(t.tow + 2);
+                hipStream_t s = (hipStream_t)stream;
+                // 16-wide channel tiles while 32-wide ones would leave CUs without a workgroup
+                static const long bn16_max = [] { const char* e = getenv("COLVO_UP2_BN16_MAX_WGS"); return e ? atol(e) : 640L; }();   // tuning knob
+                const long wgs32 = (long)u.tiles_x * u.tiles_y * d->B * ((u.N + 31) / 32);
+                const bool wide = u.N > 16 && wgs32 > bn16_max;
+                if (d->dtype == COLVO_F32)
+                    return wide ? launch_conv_up2_bn<float, 32>(u, d->B, s) : launch_conv_up2_bn<float, 16>(u, d->B, s);
+                return wide ? launch_conv_up2_bn<bf16_t, 32>(u, d->B, s) : launch_conv_up2_bn<bf16_t, 16>(u, d->B, s);
+            }
+        }
+    }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, false, (hipStream_t)stream);
 }

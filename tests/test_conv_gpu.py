@@ -58,6 +58,12 @@ CASES = [
     (2, 64, 80, 8, 0, False, False, 32, 2),       # 8 input channels: narrower than the 16-wide channel tile
     (3, 12, 18, 40, 0, False, False, 64, 2),      # channel count that is only a multiple of 8; 6 x 9 positions
     (2, 2, 2, 32, 0, False, False, 32, 2),        # one position per image
+    # single up-sampled source, >= 2 chunks: four output pixels per source position (k_conv_up2)
+    (2, 64, 80, 128, 0, True, False, 64, 1),      # 4 chunks, several tiles, two N tiles
+    (2, 16, 20, 256, 0, True, False, 128, 1),     # 8 chunks: unrolled two-chunk ring
+    (1, 16, 20, 512, 0, True, False, 256, 1),     # 16 chunks
+    (3, 10, 14, 64, 0, True, False, 24, 1),       # 5 x 7 source positions, ragged N
+    (2, 2, 2, 64, 0, True, False, 16, 1),         # a single source pixel per image
 ]
 
 
