@@ -364,11 +364,14 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
                          (((vy | vx) & par) == 0);
         return inb ? (((vy >> sh) * Ws + (vx >> sh)) * Cs + cg * G) * ES : OOB_OFF;
     };
-    int poff0[PPF], poff1[PPF];
+    int poff0[PPF], poff1[PPF], plds[PPF];          // global offsets per source, LDS offset (rows at the padded pitch a.pwp)
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         poff0[it] = patch_off(0, it * NTH + tid);
         poff1[it] = OOB_OFF;
+        const int i = it * NTH + tid, pix = i / NG, cg = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
     }
     if (a.g.C[1] > 0) {
 #pragma unroll
@@ -417,9 +420,10 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NTH + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
+            if (i < ptotal) st16(sP + plds[it], pvv[it]);
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
+        // (the host keeps a.pwp == PW for these: linear pixel index = LDS pixel index)
         if constexpr (TAIL) {
             int sidx, c0;
             chunk_src(k, sidx, c0);
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
         const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = ((oy * S) * PW + ox * S) * PIXP;
+        pbase[mf] = ((oy * S) * a.pwp + ox * S) * PIXP;
     }
 
     f32x4 acc[2][NF];
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
                 const int cg = gi - tap * NG;
                 tap = min(tap, 8);                      // padded k-groups multiply real pixels by zero weights
                 const int ky = tap / 3, kx = tap - 3 * ky;
-                const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+                const int aoff = (ky * a.pwp + kx) * PIXP + cg * 16;
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
 #pragma unroll
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
     const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
-    int poff[PPF];
+    int poff[PPF], plds[PPF];
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         const int i = it * NT + tid;
@@ -661,6 +665,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
         const int vy = oy0 + py, vx = ox0 + px;           // the row / column past dy's edge reads zeros
         const bool inb = (i < ptotal) && (vy < Hs) && (vx < Ws);
         poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
+        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
     }
     auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
         const int so = dead ? 0 : k * CK * ES;
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
+            if (i < ptotal) st16(sP + plds[it], pvv[it]);
         }
     };
     int pbase[2];
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
         const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = (oy * PW + ox) * PIXP;
+        pbase[mf] = (oy * a.pwp + ox) * PIXP;
     }
     f32x4 acc[4][2][NF];
 #pragma unroll
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
         u32x4 av[2][2], bv[2][NF];
         auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
             const int t = 8 - m, ky = t / 3, kx = t - 3 * ky;       // slot m of the flipped slab holds tap 8 - m
-            const int aoff = ((ky == 0 ? PW : 0) + (kx == 0 ? 1 : 0)) * PIXP + kg * 16;
+            const int aoff = ((ky == 0 ? a.pwp : 0) + (kx == 0 ? 1 : 0)) * PIXP + kg * 16;
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) ar[mf] = ld16(sP + pbase[mf] + aoff);
 #pragma unroll
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
     const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
-    int poff[PPF];
+    int poff[PPF], plds[PPF];
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         const int i = it * NT + tid;
@@ -848,6 +853,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
         const int vy = oy0 - 1 + py, vx = ox0 - 1 + px;
         const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
         poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
+        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
     }
     auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
         const int so = dead ? 0 : k * CK * ES;
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sP + pix * PIXP + cg * 16, pvv[it]); }
+            if (i < ptotal) st16(sP + plds[it], pvv[it]);
         }
     };
     int pbase[2];
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
         const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = (oy * PW + ox) * PIXP;                  // patch pixel (oy, ox) = source position (a - 1, b - 1)
+        pbase[mf] = (oy * a.pwp + ox) * PIXP;                  // patch pixel (oy, ox) = source position (a - 1, b - 1)
     }
     u32x4 biasv[NF];
     {
@@ -939,7 +945,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
                     if (rv >= nrv || cv >= ncv) continue;
                     const int ro = (ky == 0) ? rv : (ky == 1) ? 1 : 1 + rv;
                     const int co = (kx == 0) ? cv : (kx == 1) ? 1 : 1 + cv;
-                    const int aoff = (ro * PW + co) * PIXP + kg * 16;
+                    const int aoff = (ro * a.pwp + co) * PIXP + kg * 16;
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) av[rv][cv][mf] = ld16(sP + pbase[mf] + aoff);
                 }
@@ -1046,7 +1052,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
         const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = (oy * PW + ox) * PIXP;
+        pbase[mf] = (oy * a.pwp + ox) * PIXP;
     }
     // patch granules of this thread: (pixel, granule) inside the patch are tile-invariant
     int ppy[PPF], ppx[PPF], pcg[PPF];
@@ -1101,7 +1107,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
-            if (i < ptotal) st16(sP + (ppy[it] * PW + ppx[it]) * PIXP + pcg[it] * 16, pv[it]);
+            if (i < ptotal) st16(sP + (ppy[it] * a.pwp + ppx[it]) * PIXP + pcg[it] * 16, pv[it]);
         }
         __syncthreads();
         const int next = tile + gridDim.x;
@@ -1125,7 +1131,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
             const int cg = gi - tap * NG;
             tap = min(tap, 8);
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int aoff = (ky * PW + kx) * PIXP + cg * 16;
+            const int aoff = (ky * a.pwp + kx) * PIXP + cg * 16;
             u32x4 av[2], bv[NF];
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
@@ -1175,8 +1181,8 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
     const int S = k.g.stride;
-    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
-    size_t lds = (size_t)BN * WROW + (size_t)PH * PW * PIXP;
+    const int PH = (k.toh - 1) * S + 3;
+    size_t lds = (size_t)BN * WROW + (size_t)PH * k.pwp * PIXP;
     const size_t eplds = (size_t)(NTH / 2) * (BN + 4) * 4;
     if (eplds > lds) lds = eplds;
     COLVO_CHECK_ARG(lds <= 160 * 1024, "conv: tile needs %zu bytes of LDS", lds);
@@ -1257,8 +1263,8 @@ template <typename T, int BN, int NG>
 int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
-    const int PH = k.toh + 2, PW = k.tow + 2;
-    const size_t p_or_out = std::max((size_t)PH * PW * PIXP, (size_t)BM * (BN + 4) * 4);
+    const int PH = k.toh + 2;
+    const size_t p_or_out = std::max((size_t)PH * k.pwp * PIXP, (size_t)BM * (BN + 4) * 4);
     const size_t lds = (size_t)BN * WROW + p_or_out;
     const int ntiles = k.tiles_x * k.tiles_y * B;
     static const int res_wg_per_cu = [] { const char* e = getenv("COLVO_RES_WG_PER_CU"); return e ? atoi(e) : 4; }();   // tuning knob
@@ -1313,6 +1319,10 @@ inline void set_tile(ConvK& k, const Tile& t) {
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (k.Wo + t.tow - 1) / t.tow; k.tiles_y = (k.Ho + t.toh - 1) / t.toh;
     k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * k.g.stride + 3);
+    const int pw = (t.tow - 1) * k.g.stride + 3;
+    k.pwp = t.pwp > pw ? t.pwp : pw;
+    // patches beyond 3 x 256 granules are staged partly by the linear tail loop: no row padding there
+    if ((long)((t.toh - 1) * k.g.stride + 3) * pw * 4 > 3 * NT) k.pwp = pw;
 }
 
 template <typename T, int BN>
@@ -1354,7 +1364,7 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
             }
         }
     }
-    set_tile(k, pick_tile(k.Ho, k.Wo, k.g.stride, even));
+    set_tile(k, pick_tile(k.Ho, k.Wo, k.g.stride, even, 128, true));
     // Output-channel tile: 64 wide by default; when that grid would leave CUs idle (deep, low-resolution layers at small
     // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
     const long tiles = (long)k.tiles_x * k.tiles_y * B;
@@ -1369,7 +1379,7 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
 template <typename T, int BN, int DEPTH, int NCH>
 int launch_conv_up2_inst(ConvK k, int B, hipStream_t s) {
     constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
-    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 2) * (k.tow + 2) * PIXP;
+    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 2) * k.pwp * PIXP;
     static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
     k.ntn = (k.N + BN - 1) / BN;
     k.xcd = xcd_on;
@@ -1392,7 +1402,7 @@ int launch_conv_up2_bn(const ConvK& k, int B, hipStream_t s) {
 template <typename T, int BN, int DEPTH, int NCH>
 int launch_dgrad_s2_inst(ConvK k, int B, hipStream_t s) {
     constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
-    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 1) * (k.tow + 1) * PIXP;
+    const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 1) * k.pwp * PIXP;
     static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
     k.ntn = (k.N + BN - 1) / BN;
     k.xcd = xcd_on;
@@ -1417,8 +1427,8 @@ int launch_dgrad_s2_bn(const ConvK& k, int B, hipStream_t s) {
 
 template <typename T>
 int launch_dgrad_s2(ConvK k, int B, hipStream_t s) {
-    const Tile t = pick_tile(k.Ho, k.Wo, 1, false);
-    k.toh = t.toh; k.tow = t.tow;
+    const Tile t = pick_tile(k.Ho, k.Wo, 1, false, 128, true, 2);
+    k.toh = t.toh; k.tow = t.tow; k.pwp = std::max(t.pwp, t.tow + 1);
     k.tiles_x = (k.Wo + t.tow - 1) / t.tow; k.tiles_y = (k.Ho + t.toh - 1) / t.toh;
     k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 1);
     return k.N > 16 ? launch_dgrad_s2_bn<T, 32>(k, B, s) : launch_dgrad_s2_bn<T, 16>(k, B, s);
@@ -1449,9 +1459,9 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
             u.g.mode[0] = MODE_DIRECT;                    // read the stored half-size source as it is
             u.g.Hi = d->Hi / 2; u.g.Wi = d->Wi / 2;
             u.Ho = d->Hi / 2; u.Wo = d->Wi / 2;           // tiles run over source positions; the kernel writes (2 Ho) x (2 Wo)
-            const Tile t = pick_tile(u.Ho, u.Wo, 1, false);
+            const Tile t = pick_tile(u.Ho, u.Wo, 1, false, 128, true, 3);
             if ((t.toh + 2) * (t.tow + 2) * 4 <= 3 * NT) {
-                u.toh = t.toh; u.tow = t.tow;
+                u.toh = t.toh; u.tow = t.tow; u.pwp = std::max(t.pwp, t.tow + 2);
                 u.tiles_x = (u.Wo + t.tow - 1) / t.tow; u.tiles_y = (u.Ho + t.toh - 1) / t.toh;
                 u.m_tow = mdiv_magic(t.tow); u.m_pw = mdiv_magic(t.tow + 2);
                 hipStream_t s = (hipStream_t)stream;

@@ -5,7 +5,9 @@
 // them in AGPRs -- either way the guard's asm statement must not make hipcc copy (= read) the results in front of it.
 #pragma once
 #include <algorithm>
+#include <mutex>
 #include <stdlib.h>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -61,6 +63,7 @@ struct ConvK {
     const char* mask;         // same shape as out or null
     int accumulate, pool2;
     int toh, tow, tiles_x, tiles_y;
+    int pwp;                  // LDS pitch of a patch row, in pixels (>= patch width: padded against bank conflicts, pick_tile)
     uint32_t m_pw, m_tow;     // ceil(2^32 / patch width), ceil(2^32 / tow): index / d == umulhi(index, m) for index < 2^16
     int ntn, xcd;             // one-tile kernel: output-channel tiles per pixel tile (1-D grid, n-tile fastest), XCD remap on/off
 #ifdef COLVO_ABLATE
@@ -197,11 +200,65 @@ __device__ __forceinline__ u32x4 bld16(__amdgpu_buffer_rsrc_t r, int voff, int s
 constexpr int OOB_OFF = 0x40000000;
 __device__ __forceinline__ void st16(char* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 
-struct Tile { int toh, tow; };
+struct Tile { int toh, tow, pwp; };   // pwp: LDS pitch of a patch row in pixels (>= patch width; 0: not chosen, use the width)
 
-// choose the tile region (<=128 pixels) that wastes the fewest fragment rows; ties: least staged patch
-Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128) {
-    Tile best{even ? 2 : 1, even ? 2 : 1};
+// LDS cycles of the patch-fragment ds_read_b128 of the conv kernels, relative to conflict-free (1.0 ... 4.0): lane (l15, kg)
+// of wave w, fragment mf reads 16 bytes at ((oy*S)*pwp + ox*S)*96 + kg*16 with (oy, ox) = divmod(w*32 + mf*16 + l15, tow).
+// The instruction is serviced in the four 16-lane groups below, 64 banks of 4 bytes (MI355X_MICROARCH.md, LDS).
+inline double patch_read_conflicts(int toh, int tow, int pwp, int S) {
+    static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                   {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                   {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    const int npix = toh * tow;
+    long total = 0;
+    for (int w = 0; w < 4; ++w)
+        for (int mf = 0; mf < 2; ++mf)
+            for (int g = 0; g < 4; ++g) {
+                int slot_of[16];                            // 16-byte slots: a lane covers 4 consecutive banks = one slot of 16
+                for (int j = 0; j < 16; ++j) {
+                    const int lane = grp[g][j], l15 = lane & 15, kg = lane >> 4;
+                    int p = w * 32 + mf * 16 + l15;
+                    if (p >= npix) p = 0;
+                    const int oy = p / tow, ox = p - oy * tow;
+                    slot_of[j] = ((oy * S) * pwp + ox * S) * 6 + kg;
+                }
+                int worst = 1;                              // distinct addresses on one bank set serialise; equal ones broadcast
+                for (int r = 0; r < 16; ++r) {
+                    int distinct[16], n = 0;
+                    for (int j = 0; j < 16; ++j) {
+                        if ((slot_of[j] & 15) != r) continue;
+                        bool seen = false;
+                        for (int q = 0; q < n; ++q) if (distinct[q] == slot_of[j]) { seen = true; break; }
+                        if (!seen) distinct[n++] = slot_of[j];
+                    }
+                    if (n > worst) worst = n;
+                }
+                total += worst;
+            }
+    return (double)total / 32.0;
+}
+
+// Choose the tile region (<= BM pixels) that wastes the fewest fragment rows; ties: least staged patch.  With `lds_aware`
+// (the forward / input-gradient kernels) the cost also carries the bank conflicts of the patch-fragment reads -- half of a
+// 128 x 32 tile's LDS reads -- and the patch rows may be padded by up to 8 pixels in LDS: a 16 x 8 tile costs every such
+// read two passes, 8 x 16 none, and where 8-wide tiles are the better fit a row pitch of 16 pixels makes them conflict-free
+// (profiles/r2_conv_pmc.json: 26-48 % of the LDS-active cycles were conflicts).  ext = patch width - tile width at stride 1.
+// Results are cached: the search runs once per shape.
+inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool lds_aware = false, int ext = 3) {
+    static const bool aware_off = getenv("COLVO_NO_LDS_AWARE_TILES") != nullptr;      // A/B switch
+    if (aware_off) lds_aware = false;
+    struct Key { int Ho, Wo, stride, even, BM, aware, ext; };
+    static std::vector<std::pair<Key, Tile>> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& e : cache) {
+        const Key& q = e.first;
+        if (q.Ho == Ho && q.Wo == Wo && q.stride == stride && q.even == (int)even && q.BM == BM && q.aware == (int)lds_aware &&
+            q.ext == ext)
+            return e.second;
+    }
+    Tile best{even ? 2 : 1, even ? 2 : 1, 0};
     double best_cost = 1e30;
     const int step = even ? 2 : 1;
     for (int tow = step; tow <= (Wo + step - 1) / step * step && tow <= BM; tow += step) {
@@ -211,10 +268,19 @@ Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128) {
         if (toh > hcap) toh = hcap;
         if (toh < step) continue;
         const long tiles = (long)((Ho + toh - 1) / toh) * ((Wo + tow - 1) / tow);
-        const long patch = (long)((toh - 1) * stride + 3) * ((tow - 1) * stride + 3);
-        const double cost = (double)tiles * (BM + 0.25 * patch);
-        if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow}; }
+        const int ph = (toh - 1) * stride + ext, pw = (tow - 1) * stride + ext;
+        const double base = (double)tiles * (BM + 0.25 * ph * pw);
+        if (!lds_aware || BM != 128) {
+            if (base < best_cost) { best_cost = base; best = Tile{toh, tow, pw}; }
+            continue;
+        }
+        for (int pad = 0; pad <= 8; ++pad) {
+            const double cf = patch_read_conflicts(toh, tow, pw + pad, stride);
+            const double cost = base * (1.0 + 0.2 * (cf - 1.0)) * (1.0 + 0.002 * pad);
+            if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow, pw + pad}; }
+        }
     }
+    cache.push_back({Key{Ho, Wo, stride, (int)even, BM, (int)lds_aware, ext}, best});
     return best;
 }
 

@@ -1,10 +1,9 @@
 mkdir -p gpurun_out
-for n in 1 0 1 0; do
-  if [ $n = 1 ]; then export COLVO_NO_CONV_UP2=1; else unset COLVO_NO_CONV_UP2; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/r2_bench_up2_$n.log 2>&1 || exit 1
-  python - <<PY
+timeout -k 10 900 python -m pytest tests/test_nets_gpu.py tests/test_config1_gpu.py tests/test_large_gpu.py tests/test_program_gpu.py -x -q > gpurun_out/r2_tests_21.log 2>&1 || { tail -30 gpurun_out/r2_tests_21.log; exit 1; }
+tail -2 gpurun_out/r2_tests_21.log
+timeout -k 10 300 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/r2_bench_lds.log 2>&1 || exit 1
+python - <<PY
 import json
-d=json.loads(open("gpurun_out/r2_bench_up2_$n.log").read().strip().split("\n")[-1])
-print("no_up2=$n:", d["ms_per_step"], d["ms_per_step_hipevent_median"])
+d=json.loads(open("gpurun_out/r2_bench_lds.log").read().strip().split("\n")[-1])
+print(d["ms_per_step"], d["ms_per_step_hipevent_median"], d["value"])
 PY
-done
