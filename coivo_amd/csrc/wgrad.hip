@@ -11,6 +11,22 @@ namespace {
 // --------------------------------------------------------------------------------------------- //
 // weight-gradient kernel                                                                         //
 // --------------------------------------------------------------------------------------------- //
+// LDS pitch of a dY row.  bf16: the transposed reads (ds_read_b64_tr_b16: two 32-lane groups, 8 bytes per lane, 64 banks) of
+// one instruction touch 8 pixels x 32 bytes; they are conflict-free iff the 8 pixel rows start on 8 different 32-byte bank
+// octets, i.e. the pitch is an ODD multiple of 32 bytes AND the 8 pixels are consecutive (see the pixel order in the kernel).
+// With the former pitch of 80 bytes and pixel order every such read took two passes (profiles/r2_conv_pmc.json: 43-48 % of the
+// weight-gradient kernels' LDS cycles were bank conflicts); removing them was worth 2 % of the kernels' time.
+// (Also measured this round and dropped: a two-tile register ring for the staging loads -- 12 % SLOWER, 208 registers.)
+template <typename T, int MT>
+constexpr int dy_pitch() {
+#ifdef COLVO_WGRAD_OLD_LAYOUT                     // developer A/B build only
+    return 16 * MT * TT<T>::ES + 16;
+#else
+    if (TT<T>::ES == 4) return 16 * MT * 4 + 16;
+    return MT == 1 ? 32 : MT == 2 ? 96 : 160;
+#endif
+}
+
 // TAIL: see k_conv3x3 (the stride-2 patch tail; its dead loads made hipcc drain the prefetch in front of the MFMA phase)
 // KS: pixel-tile teams per workgroup.  The number of workgroups is capped by the fp32 atomics every one of them ends with
 // (one per weight element of its (co tile, channel chunk) slab), and at that cap most layers ran ONE 4-wave workgroup per
@@ -26,7 +42,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     constexpr int NFR = (NCOL + 15) / 16;          // column fragments
     constexpr int FPW = (NFR + 3) / 4;             // fragments per wave
     constexpr int PIXP = pitch_bytes(NG * 16);
-    constexpr int DYP = 16 * MT * ES + 16;         // dY row pitch (bytes)
+    constexpr int DYP = dy_pitch<T, MT>();         // dY row pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;       // inside the team
     const int team = (KS > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x / NT) : 0;
@@ -225,7 +241,13 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
                 int xo[2], yo[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+                    // K position (ks, kg, h, q) -> pixel: any bijection works as long as dY and X use the same one; this one
+                    // gives the 32 lanes of a read group 8 CONSECUTIVE pixels (kg & 1, q), see dy_pitch()
+#ifdef COLVO_WGRAD_OLD_LAYOUT
                     int p = 32 * ks + 8 * kg + q + 4 * h;
+#else
+                    int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
+#endif
                     yo[h] = p * DYP;
                     if (p >= npix) p = 0;     // its dY row is zero
                     const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 template <typename T, int MT, int NG, bool TAIL, int KS>
 int launch_wgrad_teams(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
+    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     constexpr int NFR = (9 * CK + 15) / 16, FPW = (NFR + 3) / 4;
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
@@ -365,7 +387,7 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
 template <typename T, int MT, int NG, bool TAIL>
 int launch_wgrad_tail(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = 16 * MT * ES + 16;
+    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
     {
