@@ -48,7 +48,8 @@ def main():
     tot = [0.0, 0.0, 0.0]
     gsum = [0.0, 0.0, 0.0]
     print(f"{'layer':8s} {'shape':28s} {'GFLOP':>7s} | {'fwd us':>8s} {'GF/us':>6s} | {'dgrad us':>8s} {'GF/us':>6s} | {'wgrad us':>8s} {'GF/us':>6s}")
-    for (name, b, hi, wi, c0, c1, up, cout, stride) in layers(B, 256, 320):
+    HH, WW = (int(v) for v in os.environ.get("CONV_BENCH_HW", "256x320").split("x"))      # e.g. 512x640 = BASELINE configs[2]
+    for (name, b, hi, wi, c0, c1, up, cout, stride) in layers(B, HH, WW):
         d = ops.conv_desc(dt, b, hi, wi, c0, cout, stride=stride, C1=c1, up0=up)
         hs, ws = (hi // 2, wi // 2) if up else (hi, wi)
         x0 = torch.randn(b, hs, ws, c0, device=dev).relu().to(dt)
