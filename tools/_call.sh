@@ -1,14 +1,3 @@
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_conv_gpu.py -x -q > gpurun_out/r2_tests_27.log 2>&1 || { tail -30 gpurun_out/r2_tests_27.log; exit 1; }
-tail -2 gpurun_out/r2_tests_27.log
-timeout -k 10 900 python -m pytest tests/test_nets_gpu.py tests/test_config1_gpu.py tests/test_large_gpu.py -x -q > gpurun_out/r2_tests_28.log 2>&1 || { tail -30 gpurun_out/r2_tests_28.log; exit 1; }
-tail -2 gpurun_out/r2_tests_28.log
-for n in 1 0 1 0; do
-  if [ $n = 1 ]; then export COLVO_NO_DGRAD_UP2=1; else unset COLVO_NO_DGRAD_UP2; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/r2_bench_du_$n.log 2>&1 || exit 1
-  python - <<PY
-import json
-d=json.loads(open("gpurun_out/r2_bench_du_$n.log").read().strip().split("\n")[-1])
-print("no_dgrad_up2=$n:", d["ms_per_step"], d["ms_per_step_hipevent_median"])
-PY
-done
+bash tools/collect_profiles.sh r2 && bash tools/pmc_conv.sh r2 && CONV_BENCH_ITERS=30 timeout -k 10 200 python tools/bench_conv.py 16 bf16 > gpurun_out/r2_bench_conv_final.log 2>&1 && timeout -k 10 400 python bench.py > gpurun_out/r2_bench_final.log 2>&1
+tail -3 gpurun_out/r2_bench_conv_final.log; tail -1 gpurun_out/r2_bench_final.log | cut -c1-300
