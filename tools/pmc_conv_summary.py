@@ -36,6 +36,8 @@ for (name, grid, lds), c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("d
     if not (name.startswith("k_conv3x3") or name.startswith("k_wgrad3x3")):
         continue
     m = {k: sum(v) / len(v) for k, v in c.items()}
+    if not m.get("duration_ns"):
+        continue          # seen in a counter pass only (dispatch shapes of the sq1 pass define the table)
     d = {"kernel": name, "grid_threads": grid, "lds_bytes": lds, "launches": len(c.get("duration_ns", [])),
          "duration_us": m.get("duration_ns", 0) / 1e3}
     wc = m.get("SQ_WAVE_CYCLES")
