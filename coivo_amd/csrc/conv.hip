@@ -327,6 +327,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     constexpr int PPF = TAIL ? 9 : 3;
     const int ptotal = PH * PW * NG;
     const int nch0 = a.g.C[0] / CK, nch = NCH ? NCH : nch0 + a.g.C[1] / CK;
+    constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];                  // DEPTH chunks in flight (register ring)
 
     // All address arithmetic is chunk-invariant except for the channel offset, so it is done ONCE per thread, and
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     }
 
     TRACE(1);
-#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+#pragma unroll KUNROLL
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
     constexpr int PPF = 3;                              // (toh+1)(tow+1) <= 9 x 17 pixels x 4 granules = 612 <= 768
     const int ptotal = PH * PW * NG;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
+    constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
 
     const int tapB = a.Ctot * ES;
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+#pragma unroll KUNROLL
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
@@ -830,6 +832,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
     constexpr int PPF = 3;                              // host: (toh+2)(tow+2) x 4 granules <= 768
     const int ptotal = PH * PW * NG;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
+    constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
 
     const int tapB = a.Ctot * ES;
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+#pragma unroll KUNROLL
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
@@ -1028,6 +1031,7 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
     constexpr int PPF = 10;                             // host: (2 toh + 2)(2 tow + 2) x 4 granules <= 2560
     const int ptotal = PH * PW * NG;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
+    constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
 
     const int tapB = a.Ctot * ES;
@@ -1103,7 +1107,7 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll(NCH > 0 ? NCH / DEPTH : 1)
+#pragma unroll KUNROLL
     for (int k0 = 0; k0 < nch; k0 += DEPTH) {
 #pragma unroll
       for (int d = 0; d < DEPTH; ++d) {
