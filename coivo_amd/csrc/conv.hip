@@ -1174,6 +1174,189 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
 }
 
 // --------------------------------------------------------------------------------------------- //
+// stride-1 conv, QUAD tile: four 128-pixel sub-tiles (2 x 2) per workgroup share one weight slab //
+// --------------------------------------------------------------------------------------------- //
+// The one-tile kernel stages a [BN][9][CK] weight slab and a (toh+2) x (tow+2) patch for 144 MFMAs per chunk and is bound by
+// that staging chain, not by the MFMA pipe; k_conv_up2, which runs 4 x 144 MFMAs on one staging, reaches
+// 52-56 % of the MFMA peak on large grids.  This is the same form for ordinary stride-1 layers (forward of the enc*b / iconv*
+// layers and their input gradients): a (2 toh) x (2 tow) output tile, ONE patch of (2 toh + 2) x (2 tow + 2) pixels (15 % fewer
+// halo pixels than four separate ones), one slab, four accumulator sets.  One or two direct sources (skip concat), bias / ReLU /
+// mask / accumulate epilogue as in the one-tile kernel.  ~210 VGPRs: one chunk of prefetch, two workgroups per CU.
+template <typename T, int BN>
+__global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int WROW = wrow_bytes(STEPS * 4);
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int NF = BN / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sW = smem;
+    char* sP = smem + BN * WROW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int tlin = lid / a.ntn;
+    const int n0 = (lid - tlin * a.ntn) * BN;
+    const int tpi = a.tiles_x * a.tiles_y;              // quad tiles per image
+    const int b = tlin / tpi, trem = tlin - b * tpi;
+    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const int oy0 = ty * 2 * a.toh, ox0 = tx * 2 * a.tow;
+    const int PH = 2 * a.toh + 2, PW = 2 * a.tow + 2;
+    const int npix = a.toh * a.tow;
+
+    constexpr int WTOT = BN * NGR;
+    constexpr int WIT = (WTOT + NT - 1) / NT;
+    constexpr int PPF = 10;                             // host: (2 toh + 2)(2 tow + 2) x 4 granules <= 2560
+    const int ptotal = PH * PW * NG;
+    const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
+    u32x4 wv[WIT], pv[PPF];
+
+    const int tapB = a.Ctot * ES;
+    int woff0, woffL;
+    {
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+    }
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    // both sources have the conv input's extent (direct mode): one pixel index per staged granule serves both
+    const int Hs = a.g.Hi, Ws = a.g.Wi;
+    const int C0 = a.g.C[0], C1 = a.g.C[1];
+    const __amdgpu_buffer_rsrc_t rimg0 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * C0 * ES), 0, Hs * Ws * C0 * ES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rimg1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(C1 > 0 ? a.g.src[1] + (size_t)b * Hs * Ws * C1 * ES : a.g.src[0]), 0, C1 > 0 ? Hs * Ws * C1 * ES : 0, 0x00020000);
+    int pidx[PPF], plds[PPF];                           // pixel index in the image (-1: outside), LDS offset
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG, cg = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        const int vy = oy0 - 1 + py, vx = ox0 - 1 + px;
+        const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
+        pidx[it] = inb ? vy * Ws + vx : -1;
+        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
+    }
+    const int cgoff = (tid & (NG - 1)) * 16;            // NT is a multiple of NG: a thread's granules all have cg = tid % NG
+    auto load_w = [&](int k, int dead) {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+    };
+    auto load_p = [&](int k, int dead) {
+        const bool second = !dead && k >= nch0;
+        const int Cs = second ? C1 : C0;
+        const int so = dead ? 0 : (second ? k - nch0 : k) * CK * ES;
+        const int pixB = Cs * ES;
+        if (!second) {
+#pragma unroll
+            for (int it = 0; it < PPF; ++it)
+                pv[it] = bld16(rimg0, ((pidx[it] >= 0) ? pidx[it] * pixB + cgoff : OOB_OFF) | dead, so);
+        } else {
+#pragma unroll
+            for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, (pidx[it] >= 0) ? pidx[it] * pixB + cgoff : OOB_OFF, so);
+        }
+    };
+    load_w(0, 0);
+    load_p(0, 0);
+    int wlds[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int i = it * NT + tid;
+        const int n = i / NGR;
+        wlds[it] = i * 16 + n * (WROW - NGR * 16);
+    }
+    int pbase[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+        int p = wave * 32 + mf * 16 + l15;
+        if (p >= npix) p = 0;
+        const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+        pbase[mf] = (oy * a.pwp + ox) * PIXP;               // inside sub-tile (0, 0); patch pixel (0, 0) = input (oy0 - 1, ox0 - 1)
+    }
+    u32x4 biasv[NF];
+    {
+        const __amdgpu_buffer_rsrc_t rbias =
+            __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) biasv[nf] = bld16(rbias, (n0 + nf * 16 + kg * 4) * 4, 0);
+    }
+    f32x4 acc[4][2][NF];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[c][mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int sub_row = a.toh * a.pwp * PIXP, sub_col = a.tow * PIXP;       // LDS offsets of sub-tiles (1, 0) and (0, 1)
+
+    for (int k = 0; k < nch; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
+#pragma unroll
+        for (int it = 0; it < PPF; ++it)
+            if (it * NT + tid < ptotal) st16(sP + plds[it], pv[it]);
+        __syncthreads();
+        {
+            const int dead = (k + 1 < nch) ? 0 : OOB_OFF;
+            load_w(k + 1, dead);
+            load_p(k + 1, dead);
+        }
+#pragma unroll
+        for (int m = 0; m < STEPS; ++m) {
+            const int ky = m / 3, kx = m - 3 * ky;
+            u32x4 bv[NF];
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + (4 * m + kg) * 16);
+            const int toff = (ky * a.pwp + kx) * PIXP + kg * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int soff = toff + (c >> 1) * sub_row + (c & 1) * sub_col;
+                u32x4 av[2];
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + soff);
+                if constexpr (ES == 2) {
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                        for (int nf = 0; nf < NF; ++nf)
+                            acc[c][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, bv[nf]), __builtin_bit_cast(bf16x8, av[mf]), acc[c][mf][nf], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+                            for (int nf = 0; nf < NF; ++nf)
+                                acc[c][mf][nf] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                    __uint_as_float(bv[nf][j]), __uint_as_float(av[mf][j]), acc[c][mf][nf], 0, 0, 0);
+                }
+            }
+        }
+    }
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[8 * NF]>(acc));
+
+    const int img_bytes = a.Ho * a.Wo * a.N * ES;
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        Epi<T, NF> ep;
+        ep.offsets(a, oy0 + (c >> 1) * a.toh, ox0 + (c & 1) * a.tow, n0, wave, l15, kg);
+        ep.prefetch(a, rout, rmask, 0);
+        ep.finish(a, acc[c], biasv, rout, 0);
+    }
+}
+
+// --------------------------------------------------------------------------------------------- //
 // forward / input-gradient kernel, weights-resident persistent form                              //
 // --------------------------------------------------------------------------------------------- //
 // For single-chunk layers (C <= 32 bf16 / 16 f32: the high-resolution ends of the networks) a workgroup's work is a
@@ -1556,6 +1739,58 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
 
+// quad-tile stride-1 kernel (k_conv_q): returns -1 when the layer does not qualify (the caller then takes the one-tile path)
+template <typename T>
+int try_launch_conv_q(const ConvK& k0, int B, hipStream_t s) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES, CK = 4 * G;
+    static const int q_on = [] { const char* e = getenv("COLVO_NO_CONV_QUAD"); return e ? 0 : 1; }();
+    // Measured (bf16; us, one-tile -> quad).  16 frames of 256x320: slower everywhere (enc2b 14.8 -> 23.5, iconv3 19.0 -> 34.2,
+    // iconv2 22.0 -> 24.2, enc5b 17.1 -> 42.1).  64 frames of 512x640: the 2-4-chunk layers at 1/2-1/4 resolution win (enc2b 199 ->
+    // 153, iconv3 265 -> 217, iconv2 370 -> 275), the 8-16-chunk layers lose to the one-tile kernel's two-chunk ring (enc4b 122 ->
+    // 164, iconv5 215 -> 297).  Hence: at least 2048 quad-tile workgroups and at most 4 chunks.
+    const char* mw = getenv("COLVO_QUAD_MIN_WGS");          // tuning knobs, read per call (the tests lower / raise them)
+    const long min_wgs = mw ? atol(mw) : 2048L;
+    const char* mc = getenv("COLVO_QUAD_MAX_CHUNKS");
+    const int max_chunks = mc ? atoi(mc) : 4;
+    const Gather& g = k0.g;
+    if (!q_on || g.stride != 1 || k0.pool2 || g.mode[0] != MODE_DIRECT || (g.C[1] > 0 && g.mode[1] != MODE_DIRECT)) return -1;
+    if (g.C[0] % CK || g.C[1] % CK || (g.C[0] + g.C[1]) / CK < 2 || (g.C[0] + g.C[1]) / CK > max_chunks) return -1;
+    if ((long long)g.Hi * g.Wi * std::max(g.C[0], g.C[1]) * ES >= 0x40000000LL || (long long)k0.Ho * k0.Wo * k0.N * ES >= 0x40000000LL)
+        return -1;
+    ConvK k = k0;
+    const Tile t = pick_tile((k.Ho + 1) / 2, (k.Wo + 1) / 2, 1, false, 128, true, 3);   // the sub-tile: at most half the image each way
+    const int PH = 2 * t.toh + 2, PW = 2 * t.tow + 2;
+    if (PH * PW * 4 > 10 * NT) return -1;
+    k.toh = t.toh; k.tow = t.tow;
+    k.tiles_x = (k.Wo + 2 * t.tow - 1) / (2 * t.tow); k.tiles_y = (k.Ho + 2 * t.toh - 1) / (2 * t.toh);
+    k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(PW);
+    k.pwp = PW;
+    // sub-tile reads are conflict-free when the sub-tile's own rows are (pick_tile) AND the patch pitch keeps the row phase:
+    // keep the padding pick_tile chose relative to ITS patch width (tow + 2)
+    if (t.pwp > t.tow + 2) k.pwp = PW + (t.pwp - (t.tow + 2));
+    const long tiles = (long)k.tiles_x * k.tiles_y * B;
+    const int bn = (k.N > 16 && tiles * ((k.N + 31) / 32) >= min_wgs) ? 32 : 16;
+    k.ntn = (k.N + bn - 1) / bn;
+    if (tiles * k.ntn < min_wgs) return -1;
+    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    k.xcd = xcd_on;
+    constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
+    const size_t lds = (size_t)bn * WROW + (size_t)PH * k.pwp * PIXP;
+    if (lds > 160 * 1024) return -1;
+    static bool configured[2] = {false, false};
+    if (lds > 48 * 1024 && !configured[bn == 32]) {
+        const void* f = bn == 32 ? reinterpret_cast<const void*>(&k_conv_q<T, 32>) : reinterpret_cast<const void*>(&k_conv_q<T, 16>);
+        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured[bn == 32] = true;
+    }
+    const dim3 grid((unsigned)(tiles * k.ntn));
+    if (bn == 32) hipLaunchKernelGGL((k_conv_q<T, 32>), grid, dim3(NT), lds, s, k);
+    else hipLaunchKernelGGL((k_conv_q<T, 16>), grid, dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_conv_q");
+    return 0;
+}
+
 // forward over an up-sampled source (k_conv_up2): tiles over the stored half-size source
 template <typename T, int BN, int DEPTH, int NCH>
 int launch_conv_up2_inst(ConvK k, int B, hipStream_t s) {
@@ -1687,6 +1922,11 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
             }
         }
     }
+    {
+        const int r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
+                                            : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
+        if (r >= 0) return r;
+    }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, false, (hipStream_t)stream);
 }
@@ -1769,6 +2009,11 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     k.w = (const char*)w_bwd + (size_t)coff * 9 * d->Cout * es; k.Ctot = d->Cout; k.N = Csrc;
     k.bias = nullptr; k.relu = 0; k.out = (char*)dx; k.mask = (const char*)relu_mask;
     k.accumulate = accumulate; k.pool2 = up;
+    if (d->stride == 1 && !up) {
+        const int r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
+                                            : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
+        if (r >= 0) return r;
+    }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, up != 0, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, up != 0, (hipStream_t)stream);
 }

@@ -66,6 +66,10 @@ CASES = [
     (2, 2, 2, 64, 0, True, False, 16, 1),         # a single source pixel per image
     (1, 8, 10, 32, 0, True, False, 512, 1),       # k_dgrad_up2 with 16 chunks of dy
     (2, 24, 40, 32, 0, True, False, 64, 1),       # ... 12 x 20 source positions: ragged tiles
+    # stride 1, direct sources, >= 2 chunks: the quad-tile kernel (k_conv_q) in the form1 runs
+    (2, 32, 64, 64, 64, False, False, 64, 1),     # concat of two sources, exact 16 x 32 quad tiles, two N tiles
+    (1, 40, 72, 128, 0, False, False, 48, 1),     # ragged quad tiles and ragged N
+    (2, 20, 12, 64, 32, False, False, 32, 1),     # sources of different width, narrow image (8-wide sub-tiles, padded rows)
 ]
 
 
@@ -82,20 +86,21 @@ def _close(got, ref, rtol, atol_scale, what):
 
 
 @pytest.fixture(autouse=True)
-def _both_up_dgrad_forms(request, monkeypatch):
-    """The sum-pool-in-the-K-loop input gradient of up-sampled layers (k_dgrad_up2) is selected only for grids of >= 640
-    workgroups; the parametrised cases are small, so half of the runs lower the threshold to reach it."""
-    if "upform1" in request.node.name:
+def _both_kernel_forms(request, monkeypatch):
+    """The fat-workgroup kernels (k_conv_q: quad tiles for stride-1 layers; k_dgrad_up2: sum-pool in the K loop) are selected
+    only for large grids (>= 2048 / 640 workgroups); the parametrised cases are small, so half of the runs lower the thresholds to
+    reach them (the other half exercises the one-tile kernels on the same shapes)."""
+    if "form1" in request.node.name:
         monkeypatch.setenv("COLVO_DGRAD_UP2_MIN_WGS", "0")
+        monkeypatch.setenv("COLVO_QUAD_MIN_WGS", "0")
+        monkeypatch.setenv("COLVO_QUAD_MAX_CHUNKS", "64")
 
 
-@pytest.mark.parametrize("upform", ["upform0", "upform1"])
+@pytest.mark.parametrize("form", ["form0", "form1"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CASES)
-def test_conv_fwd_dgrad_wgrad(case, dtype, upform):
+def test_conv_fwd_dgrad_wgrad(case, dtype, form):
     from coivo_amd import ops
-    if upform == "upform1" and not case[5]:
-        pytest.skip("only the up-sampled cases have a second input-gradient form")
     B, Hi, Wi, C0, C1, up0, up1, Cout, stride = case
     g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
     rt, at = _tols(dtype)
