@@ -1896,11 +1896,13 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
     k.w = (const char*)w_fwd; k.Ctot = d->C0 + d->C1; k.N = d->Cout;
     k.bias = bias; k.relu = d->relu; k.out = (char*)y; k.mask = nullptr; k.accumulate = 0; k.pool2 = 0;
     {
-        // single up-sampled source with at least two 32-channel chunks: four output pixels per source position (k_conv_up2)
+        // single up-sampled source in whole 32-channel chunks: four output pixels per source position (k_conv_up2; the one-chunk
+        // full-resolution layer up1 too: 23.2 -> 18.4 us against the weights-resident one-tile kernel)
         static const int up2_on = [] { const char* e = getenv("COLVO_NO_CONV_UP2"); return e ? 0 : 1; }();
         const int es = d->dtype == COLVO_F32 ? 4 : 2, ck = d->dtype == COLVO_F32 ? 16 : 32;
         const long long in_bytes = (long long)(d->Hi / 2) * (d->Wi / 2) * d->C0 * es, out_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
-        if (up2_on && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->C0 / ck >= 2 &&
+        static const int up2_min_chunks = [] { const char* e = getenv("COLVO_UP2_MIN_CHUNKS"); return e ? atoi(e) : 1; }();   // tuning knob
+        if (up2_on && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->C0 / ck >= up2_min_chunks &&
             in_bytes < 0x40000000LL && out_bytes < 0x40000000LL) {
             ConvK u = k;
             u.g.mode[0] = MODE_DIRECT;                    // read the stored half-size source as it is
