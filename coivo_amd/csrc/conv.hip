@@ -1003,10 +1003,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
 // tile of 128 SOURCE positions, stages the (2 toh + 2) x (2 tow + 2) patch of dy and the slab once per chunk, and runs the
 // 4 x 9 (class, tap) k-groups into ONE accumulator set: the pool is the accumulation.  Per MFMA a quarter of the weight staging,
 // 0.625 instead of 1.0 LDS fragment reads, no pooling epilogue.
-template <typename T, int BN, int DEPTH, int NCH = 0>
+// NG: 16-byte channel granules per chunk: 4 (a k-group of the MFMA phase is one tap) or 2 (dy with 16 bf16 channels -- the
+// full-resolution layer -- : a k-group covers two taps, lanes kg 0,1 the first and kg 2,3 the second; 18 granules per weight
+// row, padded to 20 with zeros).
+template <typename T, int BN, int DEPTH, int NCH = 0, int NG = 4>
 __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int CK = NG * G, NGR = 9 * NG, STEPS = (NGR + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4);
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
 
     constexpr int WTOT = BN * NGR;
     constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = 10;                             // host: (2 toh + 2)(2 tow + 2) x 4 granules <= 2560
+    constexpr int PPF = (10 * NG + 3) / 4;              // host: (2 toh + 2)(2 tow + 2) x NG granules <= PPF x 256
     const int ptotal = PH * PW * NG;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
     constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
@@ -1081,6 +1084,12 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
         const int n = i / NGR;
         wlds[it] = i * 16 + n * (WROW - NGR * 16);
     }
+    if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
+        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
+        }
+    }
     auto store_w = [&](const u32x4 (&w)[WIT]) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
@@ -1124,7 +1133,10 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
         }
 #pragma unroll
         for (int m = 0; m < STEPS; ++m) {
-            const int my = m / 3, mx = m - 3 * my;
+            // the tap(s) of this k-group: NG 4 -> tap m for every lane; NG 2 -> tap 2m (kg 0,1) and 2m + 1 (kg 2,3; beyond
+            // tap 8 the weights are the zero padding: any valid patch address will do)
+            const int ta = (NG == 4) ? m : 2 * m, tb = (NG == 4) ? m : (2 * m + 1 > 8 ? 8 : 2 * m + 1);
+            const int mya = ta / 3, mxa = ta - 3 * mya, myb = tb / 3, mxb = tb - 3 * myb;
             u32x4 bv[NF];
 #pragma unroll
             for (int nf = 0; nf < NF; ++nf) bv[nf] = ld16(sW + (nf * 16 + l15) * WROW + (4 * m + kg) * 16);
@@ -1132,7 +1144,13 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
             for (int q = 0; q < 2; ++q)
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
-                    const int aoff = ((q + my) * a.pwp + (pp + mx)) * PIXP + kg * 16;
+                    int aoff;
+                    if constexpr (NG == 4) {
+                        aoff = ((q + mya) * a.pwp + (pp + mxa)) * PIXP + kg * 16;
+                    } else {
+                        const int oa = ((q + mya) * a.pwp + (pp + mxa)) * PIXP, ob = ((q + myb) * a.pwp + (pp + mxb)) * PIXP;
+                        aoff = ((kg & 2) ? ob : oa) + (kg & 1) * 16;
+                    }
                     u32x4 av[2];
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) av[mf] = ld16(sP + pbase[mf] + aoff);
@@ -1815,14 +1833,14 @@ int launch_conv_up2_bn(const ConvK& k, int B, hipStream_t s) {
 }
 
 // input gradient w.r.t. an up-sampled source (k_dgrad_up2): tiles over the half-size source
-template <typename T, int BN, int DEPTH, int NCH>
+template <typename T, int BN, int DEPTH, int NCH, int NG = 4>
 int launch_dgrad_up2_inst(ConvK k, int B, hipStream_t s) {
-    constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
+    constexpr int WROW = wrow_bytes((9 * NG + 3) / 4 * 4), PIXP = pitch_bytes(NG * 16);
     const size_t lds = (size_t)BN * WROW + (size_t)(2 * k.toh + 2) * k.pwp * PIXP;
     COLVO_CHECK_ARG(lds <= 160 * 1024, "dgrad (up-sampled source): tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;
     if (lds > 48 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_up2<T, BN, DEPTH, NCH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dgrad_up2<T, BN, DEPTH, NCH, NG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { set_error("dgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
@@ -1832,13 +1850,14 @@ int launch_dgrad_up2_inst(ConvK k, int B, hipStream_t s) {
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
     COLVO_CHECK_ARG(nwg < (1ll << 30), "dgrad (up-sampled source): too many workgroups");
-    hipLaunchKernelGGL((k_dgrad_up2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    hipLaunchKernelGGL((k_dgrad_up2<T, BN, DEPTH, NCH, NG>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_dgrad_up2");
     return 0;
 }
 
 template <typename T, int BN>
 int launch_dgrad_up2_bn(const ConvK& k, int B, hipStream_t s) {
+    if (k.g.C[0] % (4 * TT<T>::G)) return launch_dgrad_up2_inst<T, BN, 1, 0, 2>(k, B, s);       // 2-granule chunks
     const int nch = k.g.C[0] / (4 * TT<T>::G);
     if (nch == 8) return launch_dgrad_up2_inst<T, BN, 2, 8>(k, B, s);
     if (nch == 16) return launch_dgrad_up2_inst<T, BN, 2, 16>(k, B, s);
@@ -1968,7 +1987,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
         static const int up2_on = [] { const char* e = getenv("COLVO_NO_DGRAD_UP2"); return e ? 0 : 1; }();
         const int ck = d->dtype == COLVO_F32 ? 16 : 32;
         const long long out_bytes = (long long)(d->Hi / 2) * (d->Wi / 2) * Csrc * es, in_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
-        if (up2_on && up && d->stride == 1 && d->Cout % ck == 0 && out_bytes < 0x40000000LL && in_bytes < 0x40000000LL) {
+        if (up2_on && up && d->stride == 1 && d->Cout % (ck / 2) == 0 && out_bytes < 0x40000000LL && in_bytes < 0x40000000LL) {
             ConvK u{};
             u.g.src[0] = (const char*)dy; u.g.src[1] = nullptr;
             u.g.C[0] = d->Cout; u.g.C[1] = 0;
@@ -1980,7 +1999,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
             u.bias = nullptr; u.relu = 0; u.out = (char*)dx; u.mask = (const char*)relu_mask;
             u.accumulate = accumulate; u.pool2 = 0;
             const Tile t = pick_tile(u.Ho, u.Wo, 2, false, 128, true, 4);   // patch rows of 2 tow + 2 pixels, pixel stride 2
-            if ((2 * t.toh + 2) * (2 * t.tow + 2) * 4 <= 10 * NT) {
+            if ((2 * t.toh + 2) * (2 * t.tow + 2) * 4 <= 10 * NT) {                 // (x NG / 4 granules <= PPF x 256 for either NG)
                 u.toh = t.toh; u.tow = t.tow; u.pwp = std::max(t.pwp, 2 * t.tow + 2);
                 u.tiles_x = (u.Wo + t.tow - 1) / t.tow; u.tiles_y = (u.Ho + t.toh - 1) / t.toh;
                 u.m_tow = mdiv_magic(t.tow); u.m_pw = mdiv_magic(2 * t.tow + 2);
