@@ -1,5 +1,7 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py -x -q > gpurun_out/r2_tests_33.log 2>&1 || { tail -30 gpurun_out/r2_tests_33.log; exit 1; }
-tail -2 gpurun_out/r2_tests_33.log
-CONV_BENCH_ITERS=30 timeout -k 10 200 python tools/bench_conv.py 16 bf16 > gpurun_out/r2_bench_conv_ng2.log 2>&1 || exit 1
-grep "^up1\|totals" gpurun_out/r2_bench_conv_ng2.log | cut -c1-8,40-100
+timeout -k 10 400 python bench.py > gpurun_out/r2_bench_final.log 2>&1 || exit 1
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r2_bench_final.log").read().strip().split("\n")[-1])
+print(d["value"], d["ms_per_step"], d["ms_per_step_hipevent_median"], d["ms_per_step_hipevent_max"], d["steps"], d["warmup"])
+PY
