@@ -16,7 +16,9 @@ namespace {
 // octets, i.e. the pitch is an ODD multiple of 32 bytes AND the 8 pixels are consecutive (see the pixel order in the kernel).
 // With the former pitch of 80 bytes and pixel order every such read took two passes (profiles/r2_conv_pmc.json: 43-48 % of the
 // weight-gradient kernels' LDS cycles were bank conflicts); removing them was worth 2 % of the kernels' time.
-// (Also measured this round and dropped: a two-tile register ring for the staging loads -- 12 % SLOWER, 208 registers.)
+// (Also measured this round and dropped: a two-tile register ring for the staging loads -- 12 % SLOWER, 208 registers;
+// 256-pixel tiles for the multi-chunk layers -- 2 % faster alone (534 -> 524 us), 0.7 % SLOWER inside the training step,
+// where the weight-gradient kernels share the CUs with the input-gradient chain.)
 template <typename T, int MT>
 constexpr int dy_pitch() {
 #ifdef COLVO_WGRAD_OLD_LAYOUT                     // developer A/B build only
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 
 template <typename T, int MT, int NG, bool TAIL, int KS>
 int launch_wgrad_teams(WgradK k, hipStream_t s) {
-    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int G = TT<T>::G;
     constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     constexpr int NFR = (9 * CK + 15) / 16, FPW = (NFR + 3) / 4;
     const int S = k.g.stride;
@@ -386,7 +388,7 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
 
 template <typename T, int MT, int NG, bool TAIL>
 int launch_wgrad_tail(WgradK k, hipStream_t s) {
-    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int G = TT<T>::G;
     constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
