@@ -1685,7 +1685,7 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
             if constexpr (BN == 32) {
                 // measured: pays only when the grid is about one workgroup per CU (it costs occupancy: ~190 VGPRs)
                 static const int depth2_min = [] { const char* e = getenv("COLVO_DEPTH2_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
-                static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 512L; }();
+                static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 1024L; }();
                 const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
                 if (wgs <= lone_max && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) {
                     return launch_conv<T, BN, 4, 2>(k, B, s);     // (a three-chunk ring measured no better)
@@ -1883,7 +1883,7 @@ template <typename T, int BN>
 int launch_dgrad_s2_bn(const ConvK& k, int B, hipStream_t s) {
     const int nch = k.g.C[0] / (4 * TT<T>::G);
     const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
-    static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 512L; }();
+    static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 1024L; }();
     if (wgs <= lone_max) {          // about one workgroup per CU: two chunks in flight, K loop unrolled (see launch_conv_ng)
         if (nch == 8) return launch_dgrad_s2_inst<T, BN, 2, 8>(k, B, s);
         if (nch == 16) return launch_dgrad_s2_inst<T, BN, 2, 16>(k, B, s);

@@ -1,14 +1,15 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_conv_gpu.py tests/test_nets_gpu.py tests/test_config1_gpu.py tests/test_large_gpu.py -x -q > gpurun_out/r2_tests_36.log 2>&1 || { tail -30 gpurun_out/r2_tests_36.log; exit 1; }
-tail -2 gpurun_out/r2_tests_36.log
-CONV_BENCH_ITERS=30 timeout -k 10 200 python tools/bench_conv.py 16 bf16 > gpurun_out/r2_bench_conv_tb2.log 2>&1 || exit 1
-tail -2 gpurun_out/r2_bench_conv_tb2.log | head -1
-for n in 1 0 1 0; do
-  if [ $n = 1 ]; then export COLVO_WGRAD_TB128=1; else unset COLVO_WGRAD_TB128; fi
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 60 > gpurun_out/r2_bench_tb_$n.log 2>&1 || exit 1
-  python - <<PY
+run() { tag=$1; shift; env "$@" timeout -k 10 300 python bench.py --no-cpu-baseline --steps 80 > gpurun_out/r2_sweep_$tag.log 2>&1 || exit 1
+python - <<PY
 import json
-d=json.loads(open("gpurun_out/r2_bench_tb_$n.log").read().strip().split("\n")[-1])
-print("tb128=$n:", d["ms_per_step"], d["ms_per_step_hipevent_median"])
+d=json.loads(open("gpurun_out/r2_sweep_$tag.log").read().strip().split("\n")[-1])
+print("$tag", round(d["ms_per_step"],4), round(d["ms_per_step_hipevent_median"],4))
 PY
+}
+for r in 1 2; do
+run l512_$r COLVO_LONE_MAX_WGS=512
+run l1024_$r COLVO_LONE_MAX_WGS=1024
+run l2048_$r COLVO_LONE_MAX_WGS=2048
+run l256_$r COLVO_LONE_MAX_WGS=256
+run l0_$r COLVO_LONE_MAX_WGS=0
 done
