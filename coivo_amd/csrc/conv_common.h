@@ -246,7 +246,8 @@ inline double patch_read_conflicts(int toh, int tow, int pwp, int S) {
 // (profiles/r2_conv_pmc.json: 26-48 % of the LDS-active cycles were conflicts).  ext = patch width - tile width at stride 1.
 // Results are cached: the search runs once per shape.
 inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool lds_aware = false, int ext = 3) {
-    static const bool aware_off = getenv("COLVO_NO_LDS_AWARE_TILES") != nullptr;      // A/B switch
+    static const bool aware_off = getenv("COLVO_NO_LDS_AWARE_TILES") != nullptr;      // A/B switches
+    static const int max_pad = [] { const char* e = getenv("COLVO_LDS_TILE_MAX_PAD"); return e ? atoi(e) : 8; }();
     if (aware_off) lds_aware = false;
     struct Key { int Ho, Wo, stride, even, BM, aware, ext; };
     static std::vector<std::pair<Key, Tile>> cache;
@@ -274,7 +275,7 @@ inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool 
             if (base < best_cost) { best_cost = base; best = Tile{toh, tow, pw}; }
             continue;
         }
-        for (int pad = 0; pad <= 8; ++pad) {
+        for (int pad = 0; pad <= max_pad; ++pad) {
             const double cf = patch_read_conflicts(toh, tow, pw + pad, stride);
             const double cost = base * (1.0 + 0.2 * (cf - 1.0)) * (1.0 + 0.002 * pad);
             if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow, pw + pad}; }
