@@ -31,22 +31,31 @@ hipEvent_t next_event() {
     return g_ev[g_ev_next.fetch_add(1, std::memory_order_relaxed) % NEV];
 }
 
-// A second side stream, owned by the library.  A weight-gradient kernel at its atomics-bound grid size puts ONE 4-wave
+// Further side streams (one by default), owned by the library.  A weight-gradient kernel at its atomics-bound grid size puts ONE 4-wave
 // workgroup on a CU; with a single side stream they run one after the other, and the backward pass ends ~90 us after the
 // input-gradient chain with only such kernels left (profiles/r2_bench_kernel_stats.csv, kernel trace).  Consecutive FORKs
 // alternate between the caller's side stream and this one, so two weight-gradient kernels overlap each other as well as
 // the main stream.  Every call ends with the caller's side stream waiting for this one: joining the caller's stream -- all
 // the host ever does -- covers both.  COLVO_SIDE_STREAMS=1 turns it off.
-hipStream_t g_aux = nullptr;
+constexpr int MAX_AUX = 3;
+hipStream_t g_aux[MAX_AUX] = {nullptr, nullptr, nullptr};
+int g_naux = 0;
 std::once_flag g_aux_once;
 
-hipStream_t aux_stream() {
+// number of library-owned side streams (COLVO_SIDE_STREAMS - 1, default 1); fills g_aux.  Measured (ms per step): 1 side
+// stream in all 1.582, 2 (default) 1.545, 3 -> 5.2, 4 -> 4.3: beyond the process's hardware queues the streams share queues and
+// the cross-stream event waits serialise the whole backward pass -- do not raise it.
+int aux_streams() {
     std::call_once(g_aux_once, [] {
         const char* e = getenv("COLVO_SIDE_STREAMS");
-        if (e && atoi(e) < 2) return;
-        if (hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking) != hipSuccess) g_aux = nullptr;
+        int want = e ? atoi(e) - 1 : 1;
+        if (want > MAX_AUX) want = MAX_AUX;
+        for (int i = 0; i < want; ++i) {
+            if (hipStreamCreateWithFlags(&g_aux[g_naux], hipStreamNonBlocking) != hipSuccess) break;
+            ++g_naux;
+        }
     });
-    return g_aux;
+    return g_naux;
 }
 
 int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
@@ -61,18 +70,19 @@ int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
 extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, colvo_stream_t side_stream) {
     COLVO_CHECK_ARG(cmds && n >= 0, "colvo_run_commands: bad arguments");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
-    hipStream_t aux = nullptr;
+    int naux = 0;
     if (ss) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) aux = aux_stream();
+        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) naux = aux_streams();
     }
     hipStream_t side_cur = ss;            // where stream-1 commands go until the next FORK
-    bool aux_dirty = false;               // aux holds work the caller's side stream has not been ordered after
+    int side_idx = 0;                     // 0: the caller's side stream, i > 0: g_aux[i - 1]
+    bool aux_dirty[MAX_AUX] = {false, false, false};   // aux i holds work the caller's side stream has not been ordered after
     for (int k = 0; k < n; ++k) {
         const ColvoCmd& c = cmds[k];
         COLVO_CHECK_ARG(c.stream == 0 || (c.stream == 1 && ss), "colvo_run_commands: command %d needs a side stream", k);
         colvo_stream_t s = c.stream ? (colvo_stream_t)side_cur : main_stream;
-        if (c.stream && side_cur == aux) aux_dirty = true;
+        if (c.stream && side_idx > 0) aux_dirty[side_idx - 1] = true;
         int rc = 0;
         switch (c.op) {
             case COLVO_CMD_CONV_FWD:
@@ -123,14 +133,15 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 break;
             case COLVO_CMD_FORK: {       // the side stream continues after everything enqueued so far on the main stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");
-                if (aux) side_cur = (side_cur == ss) ? aux : ss;
+                if (naux) { side_idx = (side_idx + 1) % (naux + 1); side_cur = side_idx ? g_aux[side_idx - 1] : ss; }
                 rc = order_after(side_cur, ms, "fork");
                 break;
             }
             case COLVO_CMD_JOIN: {       // the main stream continues after everything enqueued so far on the side stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: JOIN without a side stream");
                 rc = order_after(ms, ss, "join");
-                if (rc == 0 && aux_dirty) { rc = order_after(ms, aux, "join"); }
+                for (int i = 0; rc == 0 && i < naux; ++i)
+                    if (aux_dirty[i]) rc = order_after(ms, g_aux[i], "join");
                 break;
             }
             default:
@@ -139,6 +150,7 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
         }
         if (rc != 0) return rc;   // the failing entry point has set the message
     }
-    if (aux_dirty) return order_after(ss, aux, "side-stream hand-back");
+    for (int i = 0; i < naux; ++i)
+        if (aux_dirty[i]) { if (int rc = order_after(ss, g_aux[i], "side-stream hand-back")) return rc; }
     return 0;
 }
