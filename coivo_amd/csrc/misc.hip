@@ -253,6 +253,8 @@ __global__ __launch_bounds__(NT) void k_depth_head_fwd16(const void* __restrict_
     depth[(size_t)b * H * W + pix] = 1.0f / (lo + (hi - lo) * sig);
 }
 
+// (A four-pixels-per-thread variant -- 36 instead of 72 loads per four outputs, four independent accumulators -- measured
+// 35.9 us against this kernel's 24.7: a lane stride of 128 B costs more in the load path than the reuse saves.)
 // d(pre) from the saved depth:  sig = (1/depth - lo)/(hi-lo);  d depth/d pre = -(hi-lo) depth^2 sig (1-sig)
 __device__ __forceinline__ float head_dpre(float depth, float d_depth, float lo, float hi) {
     const float k = hi - lo;
@@ -316,17 +318,23 @@ __global__ __launch_bounds__(NT) void k_depth_head_dgrad(const void* __restrict_
 // Written from the input pixel's side: dw[t][c] = sum_q x[q][c] * dpre[q - tap].  Each thread walks a
 // strided set of pixels q, keeps all 9*C products in registers, and the workgroup reduces ONCE at the
 // end (wave shuffle + LDS) before one fp32 atomic per weight.
-template <int ES, int C>
+// ROWS = 3: a thread keeps all 9 x C products (145 accumulators: two waves per SIMD).  ROWS = 1: blockIdx.z selects the tap
+// row ky and a thread keeps 3 x C products -- three times the threads, each re-reading its pixel's C channels from L2, at a
+// third of the registers: more waves to hide the load latency this kernel is bound by.
+template <int ES, int C, int ROWS>
 __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict__ x, const float* __restrict__ dpre,
                                                          int H, int W, int px_per_block, float* __restrict__ dw,
                                                          float* __restrict__ db) {
-    __shared__ float red[4][9 * C + 1];
+    constexpr int NTAP = 3 * ROWS;
+    const int ky0 = (ROWS == 3) ? 0 : (int)blockIdx.z;
+    const bool with_bias = (ROWS == 3) || ky0 == 1;
+    __shared__ float red[4][NTAP * C + 1];
     const int b = blockIdx.y;
     const int HW = H * W;
     const int p0 = blockIdx.x * px_per_block, p1 = min(HW, p0 + px_per_block);
-    float acc[9][C];
+    float acc[NTAP][C];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[t][c] = 0.0f;
     float sb = 0.0f;
@@ -334,19 +342,20 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
     // without it every iteration waited out a full memory round trip; 54 -> us, profiles/r2_bench_kernel_stats.csv).
     typedef __attribute__((ext_vector_type(4))) unsigned int u4;
     constexpr int NV = C * ES / 16;              // the pixel's C channels as 16-byte vectors (C * ES is a multiple of 16)
-    struct Px { u4 raw[NV]; float d[9]; float dc; };
+    struct Px { u4 raw[NV]; float d[NTAP]; float dc; };
     auto fetch = [&](int q, Px& o) {
         const int qy = q / W, qx = q - qy * W;
         const u4* px = reinterpret_cast<const u4*>(reinterpret_cast<const char*>(x) + ((size_t)b * HW + q) * C * ES);
 #pragma unroll
         for (int v = 0; v < NV; ++v) o.raw[v] = px[v];
-        o.dc = dpre[(size_t)b * HW + q];
+        o.dc = with_bias ? dpre[(size_t)b * HW + q] : 0.0f;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int r = 0; r < ROWS; ++r)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
+                const int ky = ky0 + r;
                 const int oy = qy - ky + 1, ox = qx - kx + 1;      // output pixel whose tap (ky,kx) lands on q
-                o.d[ky * 3 + kx] = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dpre[((size_t)b * H + oy) * W + ox] : 0.0f;
+                o.d[r * 3 + kx] = (oy >= 0 && oy < H && ox >= 0 && ox < W) ? dpre[((size_t)b * H + oy) * W + ox] : 0.0f;
             }
     };
     int q = p0 + (int)threadIdx.x;
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
         }
         sb += cur.dc;
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
             for (int c = 0; c < C; ++c) acc[t][c] = fmaf(cur.d[t], xv[c], acc[t][c]);
         cur = nxt;
@@ -381,19 +390,19 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float v = wave_sum(acc[t][c]);
             if (lane == 0) red[wave][t * C + c] = v;
         }
     sb = wave_sum(sb);
-    if (lane == 0) red[wave][9 * C] = sb;
+    if (lane == 0) red[wave][NTAP * C] = sb;
     __syncthreads();
-    for (int k = threadIdx.x; k < 9 * C + 1; k += NT) {
+    for (int k = threadIdx.x; k < NTAP * C + 1; k += NT) {
         const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-        if (k < 9 * C) atomicAdd(dw + k, v);
-        else atomicAdd(db, v);
+        if (k < NTAP * C) atomicAdd(dw + ky0 * 3 * C + k, v);
+        else if (with_bias) atomicAdd(db, v);
     }
 }
 
@@ -681,8 +690,15 @@ extern "C" int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpr
         // pixels per workgroup: a multiple of 256, at least 8 per thread, and at most ~512 workgroups (two per CU resident)
         int ppb = 2048;
         while ((HW + ppb - 1) / ppb * B > 512 && ppb < 16384) ppb += 256;
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
-                                              dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+        // tap rows per thread: 1 (three workgroups per pixel range) measured 57 -> 45 us inside the step, step -1 %
+        static const int rows = [] { const char* e = getenv("COLVO_HEAD_WGRAD_ROWS"); return e ? atoi(e) : 1; }();   // A/B switch
+        if (rows == 3) {
+            DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 3>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
+                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+        } else {
+            DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 1>), dim3((unsigned)((HW + ppb - 1) / ppb), B, 3),
+                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+        }
     } else {
         const int rows = 4;
         DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
