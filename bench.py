@@ -30,7 +30,7 @@ LOSS_BYTES_PER_PIXEL = 60.0    # fwd 28 (tgt 12 + ref 12 + depth
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-per-gpu", type=int, default=8)
     ap.add_argument("--height", type=int, default=256)
