@@ -119,3 +119,31 @@ def test_full_loss_golden_and_step(golden_dir):
         go, gh = dict(dn_o.named_parameters())[name].grad, dict(dn.named_parameters())[name].grad
         assert_close_frac(gh, go, rtol=1e-2, atol_scale=5e-3, max_bad_frac=1e-3, what=name)
     assert_close_frac(pn.pred.weight.grad, pn_o.pred.weight.grad, rtol=1e-2, atol_scale=5e-3, max_bad_frac=0, what="pose pred")
+
+
+@pytest.mark.parametrize("B,H,W,geo,smooth,scales", [(2, 48, 64, 0.5, 0.1, 3), (1, 32, 32, 0.0, 0.1, 2), (3, 64, 96, 0.5, 0.0, 1),
+                                                     (8, 256, 320, 0.5, 0.1, 3)])
+def test_full_loss_one_node_equals_composite(B, H, W, geo, smooth, scales):
+    """The one-node form of the widened objective against the term-by-term form: same value, same gradients."""
+    from coivo_amd import functional as Fh
+    b = synth.make_batch(B, H, W, seed=90 + B)
+    d = to_dev(b)
+    args = dict(geo_weight=geo, smooth_weight=smooth, num_scales=scales)
+
+    def run(fn):
+        leaves = [d[k].clone().requires_grad_(True) for k in ("gt_depth", "gt_pose", "gt_a", "gt_b")]
+        d_r = (d["gt_depth"] * 1.07 + 0.05).clone().requires_grad_(True)
+        loss = fn(d["tgt"], d["ref"], leaves[0], d_r, leaves[1], d["K"], leaves[2], leaves[3], **args)
+        grads = torch.autograd.grad(loss * 3.0, leaves + [d_r], allow_unused=True)
+        return loss, grads
+
+    l1, g1 = run(Fh.dcdp_full_loss)
+    l2, g2 = run(Fh.dcdp_full_loss_composite)
+    assert abs(l1.item() - l2.item()) < 2e-6
+    for a, c, name in zip(g1, g2, ("d_t", "pose", "a", "b", "d_r")):
+        if c is None:
+            assert a is None or float(a.abs().max()) == 0.0, name
+            continue
+        scale = max(c.abs().max().item(), 1e-20)
+        # geometric-consistency tap gradients are float atomics: order-dependent in the last bits
+        assert (a - c).abs().max().item() <= 2e-5 * scale + 1e-9, (name, (a - c).abs().max().item(), scale)

@@ -1,4 +1,7 @@
 mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_full -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-cfg2 --full-loss > gpurun_out/prof_full.log 2>&1
-ls gpurun_out/prof_full/*/
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-roofline-cfg2 --full-loss --steps 60 > gpurun_out/r2_bench_full.log 2>&1 || { tail -20 gpurun_out/r2_bench_full.log; exit 1; }
+python - <<PY
+import json
+d=json.loads(open("gpurun_out/r2_bench_full.log").read().strip().split("\n")[-1])
+print(d["value"], d["ms_per_step"], d["ms_per_step_hipevent_median"], d["final_loss"])
+PY
