@@ -1,6 +1,5 @@
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r2_tests_full.log 2>&1 || { tail -40 gpurun_out/r2_tests_full.log; exit 1; }
-tail -3 gpurun_out/r2_tests_full.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
-timeout -k 10 400 python bench.py > gpurun_out/r2_bench_final.log 2>&1 || exit 1
-tail -1 gpurun_out/r2_bench_final.log | cut -c1-330
+timeout -k 10 300 python tools/host_profile.py 200 > gpurun_out/r2_host_profile2.log 2>&1 || { tail -20 gpurun_out/r2_host_profile2.log; exit 1; }
+grep -v "^$" gpurun_out/r2_host_profile2.log | sed -n 2,40p
+timeout -k 10 300 python tools/cpu_probe.py 60 > gpurun_out/r2_cpu_probe3.log 2>&1; grep rep gpurun_out/r2_cpu_probe3.log
+timeout -k 10 600 python -m pytest tests/test_nets_gpu.py tests/test_program_gpu.py tests/test_ddp_gpu.py tests/test_graph_gpu.py -x -q 2>&1 | tail -2
