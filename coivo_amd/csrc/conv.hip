@@ -603,6 +603,97 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 }
 
 // --------------------------------------------------------------------------------------------- //
+// staging helpers shared by the fat-workgroup kernels below (k_dgrad_s2, k_conv_up2, k_dgrad_up2, k_conv_q)  //
+// --------------------------------------------------------------------------------------------- //
+// The [BN][9][CK] weight slab of one channel chunk: global -> registers -> LDS, exactly as in k_conv3x3 (one per-thread offset
+// plus a scalar stride per staged granule; rows beyond N fall outside the descriptor and read as zero).
+template <typename T, int BN, int NG>
+struct SlabStage {
+    static constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    static constexpr int CK = NG * G, NGR = 9 * NG, STEPS = (NGR + 3) / 4;
+    static constexpr int WROW = wrow_bytes(STEPS * 4);
+    static constexpr int WTOT = BN * NGR, WIT = (WTOT + NT - 1) / NT;
+    int woff0, woffL, tapB;
+    int wlds[WIT];
+    __amdgpu_buffer_rsrc_t rw;
+
+    __device__ __forceinline__ void init(const ConvK& a, int n0, int tid) {
+        tapB = a.Ctot * ES;
+        const int n = tid / NGR, gi = tid - n * NGR;
+        const int tap = gi / NG, cg = gi - tap * NG;
+        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
+        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
+        rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    }
+    // (kept apart from init(): the kernels issue their first loads before they compute what only the LDS side needs)
+    __device__ __forceinline__ void lds_offsets(int tid) {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = it * NT + tid;
+            const int n = i / NGR;
+            wlds[it] = i * 16 + n * (WROW - NGR * 16);
+        }
+    }
+    __device__ __forceinline__ void load(int k, int dead, u32x4 (&w)[WIT]) const {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
+    }
+    __device__ __forceinline__ void store(char* sW, int tid, const u32x4 (&w)[WIT]) const {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
+    }
+    __device__ __forceinline__ void zero_padding(char* sW, int tid) const {      // weight rows of 9 * NG granules, padded to 4 * STEPS
+        if constexpr (STEPS * 4 != NGR) {
+            for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
+                const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
+                st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
+            }
+        }
+    }
+};
+
+// The input patch of one chunk from ONE directly stored source: patch pixel (py, px) = source pixel (y_org + py * 1, x_org + px),
+// zero outside the source; LDS rows at the padded pitch a.pwp.
+template <typename T, int NG, int PPF>
+struct PatchStage {
+    static constexpr int G = TT<T>::G, ES = TT<T>::ES, CK = NG * G;
+    static constexpr int PIXP = pitch_bytes(NG * 16);
+    int poff[PPF], plds[PPF];
+    int ptotal;
+    __amdgpu_buffer_rsrc_t rimg;
+
+    __device__ __forceinline__ void init(const ConvK& a, int b, int tid, int PH, int PW, int y_org, int x_org) {
+        const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
+        rimg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES,
+                                                 0x00020000);
+        ptotal = PH * PW * NG;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            const int pix = i / NG, cg = i - pix * NG;
+            const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+            const int vy = y_org + py, vx = x_org + px;
+            const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
+            poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
+            plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
+        }
+    }
+    __device__ __forceinline__ void load(int k, int dead, u32x4 (&pv)[PPF]) const {
+        const int so = dead ? 0 : k * CK * ES;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg, poff[it] | dead, so);
+    }
+    __device__ __forceinline__ void store(char* sP, int tid, const u32x4 (&pv)[PPF]) const {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it)
+            if (it * NT + tid < ptotal) st16(sP + plds[it], pv[it]);
+    }
+};
+
+// --------------------------------------------------------------------------------------------- //
 // input gradient of a STRIDE-2 conv, parity-decomposed                                           //
 // --------------------------------------------------------------------------------------------- //
 // dx[iy][ix][ci] = sum_{ky,kx,co} w[co][ky][kx][ci] * dy[oy][ox][co] with 2 oy + ky - 1 = iy: an even input row sees only
@@ -618,7 +709,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 template <typename T, int BN, int DEPTH, int NCH = 0>
 __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_dgrad_s2(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int NG = 4, CK = NG * G, STEPS = 9;
     constexpr int WROW = wrow_bytes(STEPS * 4);     // rows of 36 granules: nothing to zero-pad
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
@@ -638,73 +729,24 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
     const int PH = a.toh + 1, PW = a.tow + 1;
     const int npix = a.toh * a.tow;
 
-    constexpr int WTOT = BN * NGR;
-    constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = 3;                              // (toh+1)(tow+1) <= 9 x 17 pixels x 4 granules = 612 <= 768
-    const int ptotal = PH * PW * NG;
+    typedef SlabStage<T, BN, NG> Slab;
+    typedef PatchStage<T, NG, 3> Patch;
+    constexpr int WIT = Slab::WIT, PPF = 3;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
     constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
-
-    const int tapB = a.Ctot * ES;
-    int woff0, woffL;
-    {
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
-    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
-    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
-    int poff[PPF], plds[PPF];
+    Slab slab;
+    Patch patch;
+    slab.init(a, n0, tid);
+    patch.init(a, b, tid, PH, PW, oy0, ox0);
 #pragma unroll
-    for (int it = 0; it < PPF; ++it) {
-        const int i = it * NT + tid;
-        const int pix = i / NG, cg = i - pix * NG;
-        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-        const int vy = oy0 + py, vx = ox0 + px;           // the row / column past dy's edge reads zeros
-        const bool inb = (i < ptotal) && (vy < Hs) && (vx < Ws);
-        poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
-        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
-    }
-    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    };
-    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg, poff[it] | dead, so);
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
+    for (int d = 0; d < DEPTH; ++d) {                      // the first chunks are requested before anything the LDS side needs
         const int dead = (d < nch) ? 0 : OOB_OFF;
-        load_w(d, dead, wv[d]);
-        load_p(d, dead, pv[d]);
+        slab.load(d, dead, wv[d]);
+        patch.load(d, dead, pv[d]);
     }
-    int wlds[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
-    auto store_w = [&](const u32x4 (&w)[WIT]) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
-    };
-    auto store_p = [&](const u32x4 (&pvv)[PPF]) {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            if (i < ptotal) st16(sP + plds[it], pvv[it]);
-        }
-    };
+    slab.lds_offsets(tid);
+    slab.zero_padding(sW, tid);
     int pbase[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
@@ -728,13 +770,13 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
         const int k = k0 + d;
         if (DEPTH > 1 && k >= nch) break;
         __syncthreads();
-        store_w(wv[d]);
-        store_p(pv[d]);
+        slab.store(sW, tid, wv[d]);
+        patch.store(sP, tid, pv[d]);
         __syncthreads();
         {
             const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
-            load_w(k + DEPTH, dead, wv[d]);
-            load_p(k + DEPTH, dead, pv[d]);
+            slab.load(k + DEPTH, dead, wv[d]);
+            patch.load(k + DEPTH, dead, pv[d]);
         }
         u32x4 av[2][2], bv[2][NF];
         auto read_frags = [&](int m, u32x4 (&ar)[2], u32x4 (&br)[NF]) {
@@ -807,7 +849,7 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
 template <typename T, int BN, int DEPTH, int NCH = 0>
 __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int NG = 4, CK = NG * G, STEPS = 9;
     constexpr int WROW = wrow_bytes(STEPS * 4);
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
@@ -827,73 +869,24 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
     const int PH = a.toh + 2, PW = a.tow + 2;
     const int npix = a.toh * a.tow;
 
-    constexpr int WTOT = BN * NGR;
-    constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = 3;                              // host: (toh+2)(tow+2) x 4 granules <= 768
-    const int ptotal = PH * PW * NG;
+    typedef SlabStage<T, BN, NG> Slab;
+    typedef PatchStage<T, NG, 3> Patch;
+    constexpr int WIT = Slab::WIT, PPF = 3;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
     constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
-
-    const int tapB = a.Ctot * ES;
-    int woff0, woffL;
-    {
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
-    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
-    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
-    int poff[PPF], plds[PPF];
+    Slab slab;
+    Patch patch;
+    slab.init(a, n0, tid);
+    patch.init(a, b, tid, PH, PW, oy0 - 1, ox0 - 1);
 #pragma unroll
-    for (int it = 0; it < PPF; ++it) {
-        const int i = it * NT + tid;
-        const int pix = i / NG, cg = i - pix * NG;
-        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-        const int vy = oy0 - 1 + py, vx = ox0 - 1 + px;
-        const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
-        poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
-        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
-    }
-    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    };
-    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg, poff[it] | dead, so);
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
+    for (int d = 0; d < DEPTH; ++d) {                      // the first chunks are requested before anything the LDS side needs
         const int dead = (d < nch) ? 0 : OOB_OFF;
-        load_w(d, dead, wv[d]);
-        load_p(d, dead, pv[d]);
+        slab.load(d, dead, wv[d]);
+        patch.load(d, dead, pv[d]);
     }
-    int wlds[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
-    auto store_w = [&](const u32x4 (&w)[WIT]) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
-    };
-    auto store_p = [&](const u32x4 (&pvv)[PPF]) {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            if (i < ptotal) st16(sP + plds[it], pvv[it]);
-        }
-    };
+    slab.lds_offsets(tid);
+    slab.zero_padding(sW, tid);
     int pbase[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
@@ -924,13 +917,13 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
         const int k = k0 + d;
         if (DEPTH > 1 && k >= nch) break;
         __syncthreads();
-        store_w(wv[d]);
-        store_p(pv[d]);
+        slab.store(sW, tid, wv[d]);
+        patch.store(sP, tid, pv[d]);
         __syncthreads();
         {
             const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
-            load_w(k + DEPTH, dead, wv[d]);
-            load_p(k + DEPTH, dead, pv[d]);
+            slab.load(k + DEPTH, dead, wv[d]);
+            patch.load(k + DEPTH, dead, pv[d]);
         }
 #pragma unroll
         for (int m = 0; m < STEPS; ++m) {
@@ -1029,79 +1022,24 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
     const int PH = 2 * a.toh + 2, PW = 2 * a.tow + 2;   // dy patch
     const int npix = a.toh * a.tow;
 
-    constexpr int WTOT = BN * NGR;
-    constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = (10 * NG + 3) / 4;              // host: (2 toh + 2)(2 tow + 2) x NG granules <= PPF x 256
-    const int ptotal = PH * PW * NG;
+    typedef SlabStage<T, BN, NG> Slab;
+    typedef PatchStage<T, NG, (10 * NG + 3) / 4> Patch;
+    constexpr int WIT = Slab::WIT, PPF = (10 * NG + 3) / 4;
     const int nch = NCH ? NCH : a.g.C[0] / CK;
     constexpr int KUNROLL = NCH > 0 ? NCH / DEPTH : 1;     // full unroll of the K loop when the chunk count is a template constant
     u32x4 wv[DEPTH][WIT], pv[DEPTH][PPF];
-
-    const int tapB = a.Ctot * ES;
-    int woff0, woffL;
-    {
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
-    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
-    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES, 0x00020000);
-    int poff[PPF], plds[PPF];
+    Slab slab;
+    Patch patch;
+    slab.init(a, n0, tid);
+    patch.init(a, b, tid, PH, PW, 2 * oy0 - 1, 2 * ox0 - 1);
 #pragma unroll
-    for (int it = 0; it < PPF; ++it) {
-        const int i = it * NT + tid;
-        const int pix = i / NG, cg = i - pix * NG;
-        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-        const int vy = 2 * oy0 - 1 + py, vx = 2 * ox0 - 1 + px;
-        const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
-        poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
-        plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
-    }
-    auto load_w = [&](int k, int dead, u32x4 (&w)[WIT]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    };
-    auto load_p = [&](int k, int dead, u32x4 (&pvv)[PPF]) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) pvv[it] = bld16(rimg, poff[it] | dead, so);
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
+    for (int d = 0; d < DEPTH; ++d) {                      // the first chunks are requested before anything the LDS side needs
         const int dead = (d < nch) ? 0 : OOB_OFF;
-        load_w(d, dead, wv[d]);
-        load_p(d, dead, pv[d]);
+        slab.load(d, dead, wv[d]);
+        patch.load(d, dead, pv[d]);
     }
-    int wlds[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
-    if constexpr (STEPS * 4 != NGR) {                      // zero the padding granules of every weight row once
-        for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
-            const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
-            st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
-        }
-    }
-    auto store_w = [&](const u32x4 (&w)[WIT]) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
-    };
-    auto store_p = [&](const u32x4 (&pvv)[PPF]) {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            if (i < ptotal) st16(sP + plds[it], pvv[it]);
-        }
-    };
+    slab.lds_offsets(tid);
+    slab.zero_padding(sW, tid);
     int pbase[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
@@ -1123,13 +1061,13 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
         const int k = k0 + d;
         if (DEPTH > 1 && k >= nch) break;
         __syncthreads();
-        store_w(wv[d]);
-        store_p(pv[d]);
+        slab.store(sW, tid, wv[d]);
+        patch.store(sP, tid, pv[d]);
         __syncthreads();
         {
             const int dead = (k + DEPTH < nch) ? 0 : OOB_OFF;
-            load_w(k + DEPTH, dead, wv[d]);
-            load_p(k + DEPTH, dead, pv[d]);
+            slab.load(k + DEPTH, dead, wv[d]);
+            patch.load(k + DEPTH, dead, pv[d]);
         }
 #pragma unroll
         for (int m = 0; m < STEPS; ++m) {
@@ -1203,7 +1141,7 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
 template <typename T, int BN>
 __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    constexpr int NG = 4, CK = NG * G, NGR = 9 * NG, STEPS = 9;
+    constexpr int NG = 4, CK = NG * G, STEPS = 9;
     constexpr int WROW = wrow_bytes(STEPS * 4);
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
@@ -1223,22 +1161,15 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
     const int PH = 2 * a.toh + 2, PW = 2 * a.tow + 2;
     const int npix = a.toh * a.tow;
 
-    constexpr int WTOT = BN * NGR;
-    constexpr int WIT = (WTOT + NT - 1) / NT;
+    typedef SlabStage<T, BN, NG> Slab;
+    constexpr int WIT = Slab::WIT;
     constexpr int PPF = 10;                             // host: (2 toh + 2)(2 tow + 2) x 4 granules <= 2560
     const int ptotal = PH * PW * NG;
     const int nch0 = a.g.C[0] / CK, nch = nch0 + a.g.C[1] / CK;
     u32x4 wv[WIT], pv[PPF];
 
-    const int tapB = a.Ctot * ES;
-    int woff0, woffL;
-    {
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-    }
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
+    Slab slab;
+    slab.init(a, n0, tid);
     // both sources have the conv input's extent (direct mode): one pixel index per staged granule serves both
     const int Hs = a.g.Hi, Ws = a.g.Wi;
     const int C0 = a.g.C[0], C1 = a.g.C[1];
@@ -1258,12 +1189,6 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
         plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
     }
     const int cgoff = (tid & (NG - 1)) * 16;            // NT is a multiple of NG: a thread's granules all have cg = tid % NG
-    auto load_w = [&](int k, int dead) {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            wv[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    };
     auto load_p = [&](int k, int dead) {
         const bool second = !dead && k >= nch0;
         const int Cs = second ? C1 : C0;
@@ -1278,15 +1203,9 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
             for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg1, (pidx[it] >= 0) ? pidx[it] * pixB + cgoff : OOB_OFF, so);
         }
     };
-    load_w(0, 0);
+    slab.load(0, 0, wv);
     load_p(0, 0);
-    int wlds[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int i = it * NT + tid;
-        const int n = i / NGR;
-        wlds[it] = i * 16 + n * (WROW - NGR * 16);
-    }
+    slab.lds_offsets(tid);
     int pbase[2];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
@@ -1313,16 +1232,14 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
 
     for (int k = 0; k < nch; ++k) {
         __syncthreads();
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], wv[it]);
+        slab.store(sW, tid, wv);
 #pragma unroll
         for (int it = 0; it < PPF; ++it)
             if (it * NT + tid < ptotal) st16(sP + plds[it], pv[it]);
         __syncthreads();
         {
             const int dead = (k + 1 < nch) ? 0 : OOB_OFF;
-            load_w(k + 1, dead);
+            slab.load(k + 1, dead, wv);
             load_p(k + 1, dead);
         }
 #pragma unroll
