@@ -605,6 +605,22 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 // --------------------------------------------------------------------------------------------- //
 // staging helpers shared by the fat-workgroup kernels below (k_dgrad_s2, k_conv_up2, k_dgrad_up2, k_conv_q)  //
 // --------------------------------------------------------------------------------------------- //
+// logical workgroup id (1-D grid, XCD-contiguous) -> image, tile row / column, first output channel; channel tile fastest
+struct TileCoord { int b, ty, tx, n0; };
+template <int BN>
+__device__ __forceinline__ TileCoord tile_coord(const ConvK& a) {
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int tlin = lid / a.ntn;
+    const int tpi = a.tiles_x * a.tiles_y;
+    TileCoord c;
+    c.n0 = (lid - tlin * a.ntn) * BN;
+    c.b = tlin / tpi;
+    const int trem = tlin - c.b * tpi;
+    c.ty = trem / a.tiles_x;
+    c.tx = trem - c.ty * a.tiles_x;
+    return c;
+}
+
 // The [BN][9][CK] weight slab of one channel chunk: global -> registers -> LDS, exactly as in k_conv3x3 (one per-thread offset
 // plus a scalar stride per staged granule; rows beyond N fall outside the descriptor and read as zero).
 template <typename T, int BN, int NG>
@@ -719,12 +735,8 @@ __global__ __launch_bounds__(NT, (DEPTH == 1 && TT<T>::ES == 2) ? 3 : 2) void k_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
-    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
-    const int tlin = lid / a.ntn;
-    const int n0 = (lid - tlin * a.ntn) * BN;
-    const int tpi = a.tiles_x * a.tiles_y;
-    const int b = tlin / tpi, trem = tlin - b * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const TileCoord tc = tile_coord<BN>(a);
+    const int b = tc.b, ty = tc.ty, tx = tc.tx, n0 = tc.n0;
     const int oy0 = ty * a.toh, ox0 = tx * a.tow;       // tile origin in dy
     const int PH = a.toh + 1, PW = a.tow + 1;
     const int npix = a.toh * a.tow;
@@ -859,12 +871,8 @@ __global__ __launch_bounds__(NT, 2) void k_conv_up2(const ConvK a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
-    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
-    const int tlin = lid / a.ntn;
-    const int n0 = (lid - tlin * a.ntn) * BN;
-    const int tpi = a.tiles_x * a.tiles_y;
-    const int b = tlin / tpi, trem = tlin - b * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const TileCoord tc = tile_coord<BN>(a);
+    const int b = tc.b, ty = tc.ty, tx = tc.tx, n0 = tc.n0;
     const int oy0 = ty * a.toh, ox0 = tx * a.tow;       // tile origin in the stored (half-size) source
     const int PH = a.toh + 2, PW = a.tow + 2;
     const int npix = a.toh * a.tow;
@@ -1012,12 +1020,8 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
-    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
-    const int tlin = lid / a.ntn;
-    const int n0 = (lid - tlin * a.ntn) * BN;
-    const int tpi = a.tiles_x * a.tiles_y;
-    const int b = tlin / tpi, trem = tlin - b * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const TileCoord tc = tile_coord<BN>(a);
+    const int b = tc.b, ty = tc.ty, tx = tc.tx, n0 = tc.n0;
     const int oy0 = ty * a.toh, ox0 = tx * a.tow;       // tile origin in the half-size source = in dx
     const int PH = 2 * a.toh + 2, PW = 2 * a.tow + 2;   // dy patch
     const int npix = a.toh * a.tow;
@@ -1151,12 +1155,8 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
-    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
-    const int tlin = lid / a.ntn;
-    const int n0 = (lid - tlin * a.ntn) * BN;
-    const int tpi = a.tiles_x * a.tiles_y;              // quad tiles per image
-    const int b = tlin / tpi, trem = tlin - b * tpi;
-    const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
+    const TileCoord tc = tile_coord<BN>(a);              // (tiles_x, tiles_y count quad tiles)
+    const int b = tc.b, ty = tc.ty, tx = tc.tx, n0 = tc.n0;
     const int oy0 = ty * 2 * a.toh, ox0 = tx * 2 * a.tow;
     const int PH = 2 * a.toh + 2, PW = 2 * a.tow + 2;
     const int npix = a.toh * a.tow;
