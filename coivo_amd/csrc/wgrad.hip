@@ -471,7 +471,8 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
     static const int mt_max = [] { const char* e = getenv("COLVO_WGRAD_MT_MAX"); return e ? atoi(e) : 2; }();   // tuning knob
     // ... and 16 wide where the input is a single channel chunk (the high-resolution encoder layers: the (co tile, chunk) grid
     // is then 1-2 slabs; measured enc1a 27.0 -> 19.5, enc1b 30.9 -> 24.4, enc2a 26.3 -> 23.5 us; two-chunk layers lose)
-    const bool one_chunk = (k.g.C[0] + k.g.C[1]) == ng * G;
+    static const int one_chunk_rule = [] { const char* e = getenv("COLVO_WGRAD_NO_ONE_CHUNK_RULE"); return e ? 0 : 1; }();   // A/B switch
+    const bool one_chunk = one_chunk_rule && (k.g.C[0] + k.g.C[1]) == ng * G;
     if (k.Cout >= 64 && mt_max >= 4) return launch_wgrad_ng<T, 4>(k, ng, s);
     if (k.Cout >= 32 && mt_max >= 2 && !one_chunk) return launch_wgrad_ng<T, 2>(k, ng, s);
     return launch_wgrad_ng<T, 1>(k, ng, s);
