@@ -1,12 +1,3 @@
 mkdir -p gpurun_out
-run() { tag=$1; shift; env "$@" timeout -k 10 120 python bench.py --no-cpu-baseline --steps 80 > gpurun_out/r2_abl_$tag.log 2>&1 || { tail -5 gpurun_out/r2_abl_$tag.log; return 1; }
-python - <<PY
-import json
-d=json.loads(open("gpurun_out/r2_abl_$tag.log").read().strip().split("\n")[-1])
-print("$tag", round(d["ms_per_step"],4), round(d["ms_per_step_hipevent_median"],4))
-PY
-}
-for r in 1 2 3; do
-run rule_$r A=1
-run norule_$r COLVO_WGRAD_NO_ONE_CHUNK_RULE=1
-done
+bash tools/collect_profiles.sh r2 && bash tools/pmc_conv.sh r2 && CONV_BENCH_ITERS=30 timeout -k 10 200 python tools/bench_conv.py 16 bf16 > gpurun_out/r2_bench_conv_final.log 2>&1 && CONV_BENCH_HW=512x640 CONV_BENCH_ITERS=8 timeout -k 10 400 python tools/bench_conv.py 64 bf16 > gpurun_out/r2_bench_conv_cfg2.log 2>&1 && timeout -k 10 400 python bench.py > gpurun_out/r2_bench_final.log 2>&1
+tail -2 gpurun_out/r2_bench_conv_final.log; tail -2 gpurun_out/r2_bench_conv_cfg2.log; tail -1 gpurun_out/r2_bench_final.log | cut -c1-330
