@@ -8,6 +8,7 @@
 //
 // The host side (coivo_amd/program.py) records the commands once per (network, shape) with persistent activation
 // buffers, patches the few per-call pointers (input images, output, incoming gradients) and replays.
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 
@@ -40,22 +41,24 @@ hipEvent_t next_event() {
 constexpr int MAX_AUX = 3;
 hipStream_t g_aux[MAX_AUX] = {nullptr, nullptr, nullptr};
 int g_naux = 0;
-std::once_flag g_aux_once;
+std::atomic<int> g_aux_limit{MAX_AUX};      // colvo_set_aux_side_streams(): how many of them colvo_run_commands may use
 
-// number of library-owned side streams (COLVO_SIDE_STREAMS - 1, default 1); fills g_aux.  Measured (ms per step): 1 side
-// stream in all 1.582, 2 (default) 1.545, 3 -> 5.2, 4 -> 4.3: beyond the process's hardware queues the streams share queues and
-// the cross-stream event waits serialise the whole backward pass -- do not raise it.
+// number of library-owned side streams in use: min(COLVO_SIDE_STREAMS - 1 (default 1), colvo_set_aux_side_streams()); they are
+// created on first use, so a process that limits them to 0 before its first backward pass never creates one (an extra stream,
+// even idle, changes how the runtime deals its streams onto hardware queues).  Measured (ms per step): 1 side stream in all
+// 1.582, 2 (default) 1.545, 3 -> 5.2, 4 -> 4.3: with four or more hardware queues active and cross-queue dependencies between
+// them the whole backward pass serialises -- do not raise it.
+std::mutex g_aux_mu;
 int aux_streams() {
-    std::call_once(g_aux_once, [] {
-        const char* e = getenv("COLVO_SIDE_STREAMS");
-        int want = e ? atoi(e) - 1 : 1;
-        if (want > MAX_AUX) want = MAX_AUX;
-        for (int i = 0; i < want; ++i) {
-            if (hipStreamCreateWithFlags(&g_aux[g_naux], hipStreamNonBlocking) != hipSuccess) break;
-            ++g_naux;
-        }
-    });
-    return g_naux;
+    static const int want = [] { const char* e = getenv("COLVO_SIDE_STREAMS"); int w = e ? atoi(e) - 1 : 1; return w < 0 ? 0 : (w > MAX_AUX ? MAX_AUX : w); }();
+    const int n = std::min(want, g_aux_limit.load(std::memory_order_relaxed));
+    if (n <= g_naux) return n;
+    std::lock_guard<std::mutex> lock(g_aux_mu);
+    while (g_naux < n) {
+        if (hipStreamCreateWithFlags(&g_aux[g_naux], hipStreamNonBlocking) != hipSuccess) break;
+        ++g_naux;
+    }
+    return std::min(n, g_naux);
 }
 
 int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
@@ -67,13 +70,20 @@ int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
 }
 }  // namespace
 
+extern "C" int colvo_set_aux_side_streams(int n) {
+    COLVO_CHECK_ARG(n >= 0, "colvo_set_aux_side_streams: n must be >= 0");
+    g_aux_limit.store(n > MAX_AUX ? MAX_AUX : n, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, colvo_stream_t side_stream) {
     COLVO_CHECK_ARG(cmds && n >= 0, "colvo_run_commands: bad arguments");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
     int naux = 0;
     if (ss) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) naux = aux_streams();
+        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
+            naux = aux_streams();
     }
     hipStream_t side_cur = ss;            // where stream-1 commands go until the next FORK
     int side_idx = 0;                     // 0: the caller's side stream, i > 0: g_aux[i - 1]

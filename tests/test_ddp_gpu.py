@@ -40,3 +40,25 @@ def test_bench_multiprocess_path():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_rccl_path_with_one_rank():
+    """The REAL multi-GPU code path with world_size 1: init_process_group('nccl'), GradBuckets, all-reduces issued from the
+    weight-gradient side stream (bench.py --rccl-single).  The collectives are trivial but the plumbing is not: this is the
+    only way to execute it on a one-GPU box.  The step must produce the same loss as the plain run and not fall into the
+    serialised mode (several times the plain step time) that too many active hardware queues cause."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
+    common = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline-cfg2", "--steps", "30", "--warmup", "5"]
+    out = {}
+    for tag, extra in (("plain", []), ("rccl", ["--rccl-single"]), ("rccl_bf16", ["--rccl-single", "--grad-transport", "bf16"])):
+        r = subprocess.run(common + extra, capture_output=True, text=True, env=env, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = json.loads(r.stdout.strip().split("\n")[-1])
+    assert abs(out["rccl"]["final_loss"] - out["plain"]["final_loss"]) < 2e-3
+    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) < 2e-3
+    assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
+    assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]

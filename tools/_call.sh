@@ -1,7 +1,4 @@
 mkdir -p gpurun_out
-timeout -k 10 400 python bench.py > gpurun_out/r2_bench_final.log 2>&1 || { tail -5 gpurun_out/r2_bench_final.log; exit 1; }
-python - <<PY
-import json
-d=json.loads(open("gpurun_out/r2_bench_final.log").read().strip().split("\n")[-1])
-print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["fwd_us"], d["roofline"]["bwd_us"], d["roofline_cfg2"]["frac"], d["roofline_cfg2"]["fwd_us"], d["roofline_cfg2"]["bwd_us"])
-PY
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 600 python -m pytest tests/test_ddp_gpu.py tests/test_program_gpu.py tests/test_nets_gpu.py tests/test_graph_gpu.py -x -q > gpurun_out/r2_tests_43.log 2>&1 || { tail -30 gpurun_out/r2_tests_43.log; exit 1; }
+tail -2 gpurun_out/r2_tests_43.log
