@@ -1,4 +1,6 @@
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout -k 10 600 python -m pytest tests/test_ddp_gpu.py tests/test_program_gpu.py tests/test_nets_gpu.py tests/test_graph_gpu.py -x -q > gpurun_out/r2_tests_43.log 2>&1 || { tail -30 gpurun_out/r2_tests_43.log; exit 1; }
-tail -2 gpurun_out/r2_tests_43.log
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/prof_rccl
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_rccl -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-cfg2 --rccl-single > gpurun_out/prof_rccl.log 2>&1
+ls gpurun_out/prof_rccl/*/ | head
