@@ -32,7 +32,7 @@ class Cmd(C.Structure):
 
 (CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
  CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN,
- CMD_DEPTH_HEAD_BWD_PARTS) = range(1, 14)
+ CMD_DEPTH_HEAD_BWD_PARTS, CMD_CONV_DGRAD_BOTH) = range(1, 15)
 NPTR = 12      # pointer slots of a ColvoCmd
 
 SIGNATURES = {
@@ -54,6 +54,7 @@ SIGNATURES = {
     "colvo_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "colvo_conv_dgrad_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_relu_bwd_inplace": (_i, [_i, _vp, _vp, _sz, _vp]),
     "colvo_pack_weights": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),

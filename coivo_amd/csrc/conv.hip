@@ -578,15 +578,25 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
 #endif
     TRACE(4);
     if (!a.pool2) {
-        const int img_bytes = a.Ho * a.Wo * a.N * ES;
+        // two-output form (input gradient of a concat layer): this workgroup's channel tile lies in exactly one of the sources
+        ConvK e = a;
+        int n0e = n0;
+        if (a.nsplit > 0) {
+            const bool second = n0 >= a.nsplit;           // wave-uniform
+            e.out = second ? a.out2 : a.out;
+            e.mask = second ? a.mask2 : a.mask;
+            e.N = second ? a.N - a.nsplit : a.nsplit;
+            n0e = second ? n0 - a.nsplit : n0;
+        }
+        const int img_bytes = e.Ho * e.Wo * e.N * ES;
         const __amdgpu_buffer_rsrc_t rout =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(e.out + (size_t)b * img_bytes), 0, img_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rmask = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.mask ? a.mask + (size_t)b * img_bytes : a.out), 0, a.mask ? img_bytes : 0, 0x00020000);
+            (void*)(e.mask ? e.mask + (size_t)b * img_bytes : e.out), 0, e.mask ? img_bytes : 0, 0x00020000);
         Epi<T, NF> ep;
-        ep.offsets(a, oy0, ox0, n0, wave, l15, kg);
-        ep.prefetch(a, rout, rmask, 0);
-        ep.finish(a, acc, biasv, rout, 0);
+        ep.offsets(e, oy0, ox0, n0e, wave, l15, kg);
+        ep.prefetch(e, rout, rmask, 0);
+        ep.finish(e, acc, biasv, rout, 0);
         TRACE(5);
         return;
     }
@@ -1585,7 +1595,7 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
         const long long out_bytes = (long long)B * k.Ho * k.Wo * k.N * TT<T>::ES / (k.pool2 ? 4 : 1);
         const long long tpi = (long long)k.tiles_x * k.tiles_y;
         static const long res_min_tiles = [] { const char* e = getenv("COLVO_RES_MIN_TILES"); return e ? atol(e) : 2048L; }();   // tuning knob
-        if (k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL && out_bytes < 0x40000000LL &&
+        if (k.nsplit == 0 && k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL && out_bytes < 0x40000000LL &&
             tpi >= 2 && k.tiles_x >= 2 && tpi * tpi * B < 0x100000000LL &&        // magic-division ranges
             tpi * B >= res_min_tiles) {
             switch (ng) {
@@ -1652,7 +1662,7 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
         static const long wide_min_wgs = [] { const char* e = getenv("COLVO_WIDE_MIN_WGS"); return e ? atol(e) : 192L; }();   // tuning knob
         static const int wide_min_chunks = [] { const char* e = getenv("COLVO_WIDE_MIN_CHUNKS"); return e ? atoi(e) : 2; }();
         const int nch = (k.g.C[0] + k.g.C[1]) / (ng * G);
-        if (wide_on && k.g.stride == 1 && k.N >= 32 && nch >= wide_min_chunks) {
+        if (wide_on && k.nsplit == 0 && k.g.stride == 1 && k.N >= 32 && nch >= wide_min_chunks) {
             const Tile tw = pick_tile(k.Ho, k.Wo, 1, even, 256);
             const long patch = (long)(tw.toh + 2) * (tw.tow + 2) * ng;
             const int bn = k.N >= 64 ? 64 : 32;
@@ -1669,7 +1679,8 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     const long tiles = (long)k.tiles_x * k.tiles_y * B;
     static const long bn64_min_wgs = [] { const char* e = getenv("COLVO_BN64_MIN_WGS"); return e ? atol(e) : 1024L; }();   // tuning knob
     static const long bn32_min_wgs = [] { const char* e = getenv("COLVO_BN32_MIN_WGS"); return e ? atol(e) : 0L; }();      // tuning knob (16-wide tiles: measured ~neutral)
-    if (k.N >= 64 && tiles * ((k.N + 63) / 64) >= bn64_min_wgs) return launch_conv_ng<T, 64>(k, B, ng, s);
+    // (two-output form: a channel tile must not straddle the two sources -- nsplit is a multiple of 32)
+    if (k.nsplit == 0 && k.N >= 64 && tiles * ((k.N + 63) / 64) >= bn64_min_wgs) return launch_conv_ng<T, 64>(k, B, ng, s);
     if (k.N >= 32 && tiles * ((k.N + 31) / 32) >= bn32_min_wgs) return launch_conv_ng<T, 32>(k, B, ng, s);
     return launch_conv_ng<T, 16>(k, B, ng, s);
 }
@@ -1955,3 +1966,36 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, up != 0, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, up != 0, (hipStream_t)stream);
 }
+
+// Input gradient w.r.t. BOTH sources of a stride-1 concat layer in ONE launch: the two calls of colvo_conv_dgrad stage the
+// same dy patches and differ only in the rows of w_bwd they read and the tensor they write; merged, the grid has the channel
+// tiles of both sources (better fill at small batch) and half the launches.  Needs C0 to be a multiple of the channel tile
+// (32) and direct (not up-sampled) sources; otherwise -- and for anything colvo_conv_dgrad would route to a special kernel --
+// it falls back to two calls.
+extern "C" int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* relu_mask0,
+                                     const void* relu_mask1, void* dx0, void* dx1, colvo_stream_t stream) {
+    if (int e = check_desc(d, "colvo_conv_dgrad_both")) return e;
+    COLVO_CHECK_ARG(dy && w_bwd && dx0 && dx1 && d->C1 > 0, "colvo_conv_dgrad_both: needs a two-source layer and both outputs");
+    static const int on = [] { const char* e = getenv("COLVO_NO_DGRAD_BOTH"); return e ? 0 : 1; }();
+    const int es = d->dtype == COLVO_F32 ? 4 : 2;
+    const long long cmax = std::max(d->C0, d->C1);
+    const bool fits = (long long)d->Hi * d->Wi * cmax * es < 0x40000000LL && (long long)d->Ho * d->Wo * d->Cout * es < 0x40000000LL;
+    if (!on || d->stride != 1 || d->up0 || d->up1 || d->C0 % 32 != 0 || !fits) {
+        if (int e = colvo_conv_dgrad(d, 0, dy, w_bwd, relu_mask0, dx0, 0, stream)) return e;
+        return colvo_conv_dgrad(d, 1, dy, w_bwd, relu_mask1, dx1, 0, stream);
+    }
+    ConvK k{};
+    k.g.src[0] = (const char*)dy; k.g.src[1] = nullptr;
+    k.g.C[0] = d->Cout; k.g.C[1] = 0;
+    k.g.Hs[0] = d->Ho; k.g.Ws[0] = d->Wo; k.g.Hs[1] = k.g.Ws[1] = 0;
+    k.g.mode[0] = k.g.mode[1] = MODE_DIRECT;
+    k.g.Hi = d->Ho; k.g.Wi = d->Wo; k.g.stride = 1;
+    k.Ho = d->Hi; k.Wo = d->Wi;
+    k.w = (const char*)w_bwd; k.Ctot = d->Cout; k.N = d->C0 + d->C1;
+    k.bias = nullptr; k.relu = 0; k.accumulate = 0; k.pool2 = 0;
+    k.out = (char*)dx0; k.mask = (const char*)relu_mask0;
+    k.out2 = (char*)dx1; k.mask2 = (const char*)relu_mask1; k.nsplit = d->C0;
+    return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
+                                 : launch_conv_t<bf16_t>(k, d->B, false, (hipStream_t)stream);
+}
+

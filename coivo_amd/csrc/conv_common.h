@@ -61,6 +61,11 @@ struct ConvK {
     int relu;
     char* out;                // [B][Ho(/2)][Wo(/2)][N]
     const char* mask;         // same shape as out or null
+    // input gradient w.r.t. BOTH sources of a concat layer in one launch (colvo_conv_dgrad_both): output channels >= nsplit
+    // (a multiple of the channel tile) belong to the second source and go to out2 / mask2 with N - nsplit channels per pixel
+    char* out2;
+    const char* mask2;
+    int nsplit;               // 0: single output
     int accumulate, pool2;
     int toh, tow, tiles_x, tiles_y;
     int pwp;                  // LDS pitch of a patch row, in pixels (>= patch width: padded against bank conflicts, pick_tile)

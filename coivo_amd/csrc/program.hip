@@ -101,6 +101,9 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
             case COLVO_CMD_CONV_DGRAD:
                 rc = colvo_conv_dgrad(&c.desc, c.i[0], c.p[0], c.p[1], c.p[2], (void*)c.p[3], c.i[1], s);
                 break;
+            case COLVO_CMD_CONV_DGRAD_BOTH:
+                rc = colvo_conv_dgrad_both(&c.desc, c.p[0], c.p[1], c.p[2], c.p[3], (void*)c.p[4], (void*)c.p[5], s);
+                break;
             case COLVO_CMD_CONV_WGRAD:
                 rc = colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
                 break;

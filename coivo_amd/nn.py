@@ -544,9 +544,12 @@ class DepthNet(_ArenaModule):
                 u = A[f"up{i}"]
                 skip = A[f"enc{i - 1}b"] if i >= 2 else None
                 wgrad(f"iconv{i}", u, skip, g)
-                d_u = dgrad(f"iconv{i}", 0, g, u)
-                if skip is not None:
-                    d_skip[i - 1] = dgrad(f"iconv{i}", 1, g, skip)
+                if skip is not None:                    # both sources' input gradients in one launch
+                    L = getattr(self, f"iconv{i}")
+                    d_u, d_skip[i - 1] = torch.empty_like(u), torch.empty_like(skip)
+                    ops.conv_dgrad_both(P[f"iconv{i}"], g, L.w_bwd, u, skip, d_u, d_skip[i - 1])
+                else:
+                    d_u = dgrad(f"iconv{i}", 0, g, u)
                 below = A[f"iconv{i + 1}"] if i < 5 else A["enc5b"]
                 wgrad(f"up{i}", below, None, d_u)
                 g = dgrad(f"up{i}", 0, d_u, below)

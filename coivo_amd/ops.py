@@ -62,6 +62,17 @@ def conv_dgrad(d: ConvDesc, src: int, dy, w_bwd, relu_mask, dx, accumulate: bool
                                     _lib.ptr(dx), int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad")
 
 
+def conv_dgrad_both(d: ConvDesc, dy, w_bwd, relu_mask0, relu_mask1, dx0, dx1) -> None:
+    """Input gradients w.r.t. both sources of a concat layer in one launch (colvo_conv_dgrad_both)."""
+    _need_cuda(dy, w_bwd, relu_mask0, relu_mask1, dx0, dx1)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_DGRAD_BOTH, d, (dy, w_bwd, relu_mask0, relu_mask1, dx0, dx1), ())
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_dgrad_both(C.byref(d), _lib.ptr(dy), _lib.ptr(w_bwd), _lib.ptr(relu_mask0), _lib.ptr(relu_mask1),
+                                         _lib.ptr(dx0), _lib.ptr(dx1), _lib.stream_ptr()), "colvo_conv_dgrad_both")
+
+
 def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db) -> None:
     _need_cuda(x0, x1, dy, dw, db)
     rec = program.recording()

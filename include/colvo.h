@@ -149,6 +149,11 @@ int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void* x1, const
  * accumulate: 0 = overwrite dx, 1 = dx += (fan-out of skip connections). */
 int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy, const void* w_bwd,
                      const void* relu_mask, void* dx, int accumulate, colvo_stream_t stream);
+/* The input gradients w.r.t. BOTH sources of a two-source (concat) layer in one launch: dx0 [B][Hi][Wi][C0], dx1 [..][C1];
+ * relu_mask0 / relu_mask1 as in colvo_conv_dgrad (may be NULL).  Same results as two colvo_conv_dgrad calls (which it falls
+ * back to for strided / up-sampled layers or when C0 is not a multiple of 32). */
+int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* relu_mask0,
+                          const void* relu_mask1, void* dx0, void* dx1, colvo_stream_t stream);
 
 /* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
  * (the caller zeroes them once per step). */
@@ -264,7 +269,8 @@ enum {
     COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db scale_a scale_b */
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
     COLVO_CMD_JOIN,              /* main stream waits for the side stream's work so far */
-    COLVO_CMD_DEPTH_HEAD_BWD_PARTS /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx */
+    COLVO_CMD_DEPTH_HEAD_BWD_PARTS, /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx */
+    COLVO_CMD_CONV_DGRAD_BOTH     /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
 };
 
 typedef struct ColvoCmd {

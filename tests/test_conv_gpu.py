@@ -302,3 +302,30 @@ def test_pack_weights_multi_matches_permute(dtype):
         ref_b = w.flip(1).permute(2, 1, 0).contiguous().to(dtype)
         assert torch.equal(bwd[off:off + n].cpu().view(ci, 9, co), ref_b), (co, ci, "bwd")
         off += n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout", [(2, 16, 20, 32, 32, 32), (2, 32, 40, 64, 64, 64), (1, 24, 24, 64, 32, 48),
+                                              (2, 16, 16, 24, 40, 32)])
+def test_dgrad_both_sources_equals_two_calls(B, H, W, C0, C1, Cout, dtype):
+    """colvo_conv_dgrad_both (one launch, two outputs) against colvo_conv_dgrad per source; the last case (C0 not a
+    multiple of 32) takes the documented fallback."""
+    from coivo_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(B * 1000 + C0 + C1)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    x0 = torch.relu(rnd(B, H, W, C0)).to(d)
+    x1 = torch.relu(rnd(B, H, W, C1)).to(d)
+    dy = rnd(B, H, W, Cout).to(d)
+    w = (torch.randn(Cout, 9, C0 + C1, generator=g) * (2.0 / (9 * (C0 + C1))) ** 0.5).to(d)
+    w_fwd = torch.empty(Cout, 9, C0 + C1, device=d, dtype=dtype)
+    w_bwd = torch.empty(C0 + C1, 9, Cout, device=d, dtype=dtype)
+    ops.pack_weights(w, dtype, w_fwd, w_bwd)
+    desc = ops.conv_desc(dtype, B, H, W, C0, Cout, C1=C1)
+    for masks in ((None, None), (x0, x1)):
+        a0, a1 = torch.full_like(x0, 3.0), torch.full_like(x1, 3.0)
+        ops.conv_dgrad(desc, 0, dy, w_bwd, masks[0], a0, False)
+        ops.conv_dgrad(desc, 1, dy, w_bwd, masks[1], a1, False)
+        b0, b1 = torch.full_like(x0, 5.0), torch.full_like(x1, 5.0)
+        ops.conv_dgrad_both(desc, dy, w_bwd, masks[0], masks[1], b0, b1)
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
