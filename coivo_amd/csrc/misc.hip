@@ -510,8 +510,8 @@ __global__ __launch_bounds__(NT) void k_pose_head_bwd(const void* __restrict__ x
 // ---------------------------------------------------------------- Adam ----------------------- //
 __global__ __launch_bounds__(NT) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
-                                             float gscale, const int32_t* __restrict__ step_count) {
-    const int t = step_count[0] + 1;
+                                             float gscale, const int32_t* __restrict__ step_count, int t_host) {
+    const int t = step_count ? step_count[0] + 1 : t_host;
     const float bc1 = 1.0f - powf(b1, (float)t);
     const float bc2 = 1.0f - powf(b2, (float)t);
     const float step_size = lr / bc1;
@@ -738,11 +738,25 @@ extern "C" int colvo_adam_step(float* param, const float* grad, float* exp_avg, 
         unsigned blocks = nblk(n);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                           eps, grad_scale, step_count);
+                           eps, grad_scale, step_count, 0);
         COLVO_CHECK_LAUNCH("k_adam");
     }
     hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
     COLVO_CHECK_LAUNCH("k_inc_step");
+    return 0;
+}
+
+// The same with the step number t (1-based) supplied by the host: no device counter, no second launch.  For callers that count
+// steps themselves; a step captured into a hipGraph needs the device counter of colvo_adam_step (a baked-in t would repeat).
+extern "C" int colvo_adam_step_t(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                                 float beta1, float beta2, float eps, float grad_scale, int t, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && t >= 1, "colvo_adam_step_t: bad arguments");
+    if (n == 0) return 0;
+    unsigned blocks = nblk(n);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+                       beta2, eps, grad_scale, (const int32_t*)nullptr, t);
+    COLVO_CHECK_LAUNCH("k_adam");
     return 0;
 }
 

@@ -58,6 +58,7 @@ class GraphedTrainStep:
     def capture(self) -> None:
         """Warm up (kernel attribute setup, side streams, allocator pools) without side effects, then capture."""
         nets = (self.depth_net, self.pose_net)
+        self.opt.use_device_step_counter()          # a captured host-side step number would repeat at every replay
         snap_p = [n.flat_param.clone() for n in nets]
         snap_o = [{k: v.clone() for k, v in st.items()} for st in self.opt.state]
         side = torch.cuda.Stream(device=self.frames.device)

@@ -234,6 +234,14 @@ def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a=None, scale_b=None
                "colvo_pose_head_bwd")
 
 
+def adam_step_t(param, grad, exp_avg, exp_avg_sq, t: int, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:
+    """Adam with the 1-based step number from the host (colvo_adam_step_t): one launch, no device counter."""
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    lib = _lib.load()
+    _lib.check(lib.colvo_adam_step_t(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), param.numel(),
+                                     lr, beta1, beta2, eps, grad_scale, int(t), _lib.stream_ptr()), "colvo_adam_step_t")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_count, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:
     _need_cuda(param, grad, exp_avg, exp_avg_sq, step_count)
     lib = _lib.load()

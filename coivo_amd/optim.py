@@ -24,6 +24,9 @@ class FusedAdam:
                 raise TypeError("FusedAdam takes the HIP-backed networks (coivo_amd.nn.DepthNet / PoseNet)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.grad_scale = 1.0
+        # Step numbers live on the host (one launch per network); while a hipGraph is being captured the device counters of
+        # the state are used instead (a captured step number would repeat at every replay) and kept in step with the host's.
+        self._t = 0
         self.state = []
         for m in self.modules:
             dev = m.flat_param.device
@@ -36,14 +39,39 @@ class FusedAdam:
 
     @torch.no_grad()
     def step(self) -> None:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and not self._device_steps:
+            raise RuntimeError("FusedAdam: call use_device_step_counter() before capturing a step into a graph")
+        self._t += 1
         for m, st in zip(self.modules, self.state):
             m.join_side()
             m.attach_grads()
-            ops.adam_step(m.flat_param, m.flat_grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=self.lr,
-                          beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
+            if self._device_steps:
+                ops.adam_step(m.flat_param, m.flat_grad, st["exp_avg"], st["exp_avg_sq"], st["step"], lr=self.lr,
+                              beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
+            else:
+                ops.adam_step_t(m.flat_param, m.flat_grad, st["exp_avg"], st["exp_avg_sq"], self._t, lr=self.lr,
+                                beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
             m.mark_params_changed()
 
+    _device_steps = False
+
+    def use_device_step_counter(self) -> None:
+        """Switch to the device-side step counters (needed when steps are replayed from a hipGraph: graph.py)."""
+        if not self._device_steps:
+            for st in self.state:
+                st["step"].fill_(self._t)
+            self._device_steps = True
+
+    def _sync_step_state(self) -> None:
+        if self._device_steps:
+            self._t = int(self.state[0]["step"].item()) if self.state else self._t
+        else:
+            for st in self.state:
+                st["step"].fill_(self._t)
+
     def state_dict(self):
+        self._sync_step_state()
         return dict(lr=self.lr, betas=self.betas, eps=self.eps,
                     state=[{k: v.clone() for k, v in st.items()} for st in self.state])
 
@@ -52,3 +80,4 @@ class FusedAdam:
         for st, src in zip(self.state, sd["state"]):
             for k in st:
                 st[k].copy_(src[k])
+        self._t = int(self.state[0]["step"].item()) if self.state else 0

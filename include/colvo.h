@@ -222,6 +222,10 @@ int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d
 int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     int32_t* step_count, colvo_stream_t stream);
+/* The same with the 1-based step number supplied by the host (no device counter, one launch).  Not for steps captured into a
+ * hipGraph: the captured t would repeat at every replay -- use colvo_adam_step there. */
+int colvo_adam_step_t(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                      float lr, float beta1, float beta2, float eps, float grad_scale, int t, colvo_stream_t stream);
 /* Zero `bytes` bytes of device memory on `stream` (the gradient arenas, once per step). */
 int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream);
 

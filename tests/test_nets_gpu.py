@@ -191,3 +191,31 @@ def test_networks_reject_cpu_input():
         dn(torch.zeros(1, 3, 32, 32))
     with pytest.raises(ValueError):
         dn(torch.zeros(1, 3, 30, 32, device=dev()))
+
+
+def test_fused_adam_step_counter_survives_state_dict():
+    """Step numbers are counted on the host (one launch per arena); state_dict() / load_state_dict() carry them, and an
+    optimizer restored after 2 steps takes the same third step as one that never stopped."""
+    from coivo_amd import nn as hnn
+    from coivo_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    nets = [hnn.PoseNet() for _ in range(2)]
+    nets[1].load_state_dict(nets[0].state_dict())
+    opts = [FusedAdam([n], lr=1e-3) for n in nets]
+    g = torch.Generator().manual_seed(3)
+    grads = [torch.randn(nets[0].flat_grad.shape, generator=g).to(dev()) for _ in range(3)]
+    for k in range(2):
+        for n, o in zip(nets, opts):
+            n.attach_grads()
+            n.flat_grad.copy_(grads[k])
+            o.step()
+    sd = opts[1].state_dict()
+    assert int(sd["state"][0]["step"].item()) == 2
+    restored = FusedAdam([nets[1]], lr=1e-3)
+    restored.load_state_dict(sd)
+    for n, o in ((nets[0], opts[0]), (nets[1], restored)):
+        n.attach_grads()
+        n.flat_grad.copy_(grads[2])
+        o.step()
+    assert torch.equal(nets[0].flat_param, nets[1].flat_param)
+    assert int(restored.state_dict()["state"][0]["step"].item()) == 3
