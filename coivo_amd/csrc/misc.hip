@@ -253,6 +253,58 @@ __global__ __launch_bounds__(NT) void k_depth_head_fwd16(const void* __restrict_
     depth[(size_t)b * H * W + pix] = 1.0f / (lo + (hi - lo) * sig);
 }
 
+// bf16: LDS-tiled form.  The kernel above pulls every input pixel through the L1 nine times (18 x 16 B per output: ~10 us of
+// texture-path time for 16 frames of 256x320 before any latency); here a workgroup stages the (4 + 2) x (64 + 2) input pixels
+// of its 4 x 64 output tile ONCE (coalesced 16-byte loads, zero outside the image) and the nine taps read LDS.  Pixel pitch
+// 48 B: 16 consecutive pixels of a ds_read_b128 group start on 16 different 16-byte slots.
+__global__ __launch_bounds__(NT) void k_depth_head_fwd16_lds(const void* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int H, int W, float lo, float hi,
+                                                             float* __restrict__ depth) {
+    constexpr int C = 16, TH = 4, TW = 64, PH = TH + 2, PW = TW + 2, PITCH = 48;
+    __shared__ float sw[9 * C];
+    __shared__ __attribute__((aligned(16))) char tile[PH * PW * PITCH];
+    const int tid = threadIdx.x;
+    if (tid < 9 * C) sw[tid] = w[tid];
+    const int b = blockIdx.z, y0 = blockIdx.y * TH, x0 = blockIdx.x * TW;
+    const char* img = reinterpret_cast<const char*>(x) + (size_t)b * H * W * C * 2;
+    for (int i = tid; i < PH * PW * 2; i += NT) {          // 2 granules of 16 B per pixel
+        const int pix = i >> 1, h = i & 1;
+        const int py = pix / PW, px = pix - py * PW;
+        const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const uint4*>(img + ((size_t)yy * W + xx) * C * 2 + 16 * h);
+        *reinterpret_cast<uint4*>(tile + pix * PITCH + 16 * h) = v;
+    }
+    __syncthreads();
+    const int ty = tid >> 6, tx = tid & 63;
+    const int yy = y0 + ty, xx = x0 + tx;
+    if (yy >= H || xx >= W) return;
+    float acc0 = bias[0], acc1 = 0.0f, acc2 = 0.0f;        // one chain per tap row
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float a = 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const char* p = tile + ((ty + ky) * PW + tx + kx) * PITCH;
+            const float* wt = sw + (ky * 3 + kx) * C;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 q = *reinterpret_cast<const uint4*>(p + 16 * h);
+                const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a = fmaf(__uint_as_float(u[k] << 16), wt[8 * h + 2 * k], a);
+                    a = fmaf(__uint_as_float(u[k] & 0xFFFF0000u), wt[8 * h + 2 * k + 1], a);
+                }
+            }
+        }
+        if (ky == 0) acc0 += a; else if (ky == 1) acc1 = a; else acc2 = a;
+    }
+    const float pre = acc0 + (acc1 + acc2);
+    const float sig = 1.0f / (1.0f + expf(-pre));
+    depth[(size_t)b * H * W + (size_t)yy * W + xx] = 1.0f / (lo + (hi - lo) * sig);
+}
+
 // (A four-pixels-per-thread variant -- 36 instead of 72 loads per four outputs, four independent accumulators -- measured
 // 35.9 us against this kernel's 24.7: a lane stride of 128 B costs more in the load path than the reuse saves.)
 // d(pre) from the saved depth:  sig = (1/depth - lo)/(hi-lo);  d depth/d pre = -(hi-lo) depth^2 sig (1-sig)
@@ -618,7 +670,11 @@ extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, co
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
                     "colvo_depth_head_fwd: bad shape / range");
     const size_t HW = (size_t)H * W;
-    if (C == 16) {
+    static const int head_lds = [] { const char* e = getenv("COLVO_HEAD_FWD_NO_LDS"); return e ? 0 : 1; }();   // A/B switch
+    if (C == 16 && dtype == COLVO_BF16 && head_lds && (H + 3) / 4 <= 65535) {
+        hipLaunchKernelGGL(k_depth_head_fwd16_lds, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, x, w,
+                           bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth);
+    } else if (C == 16) {
         DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd16<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, x,
                                               w, bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth));
     } else {
