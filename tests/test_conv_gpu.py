@@ -70,6 +70,11 @@ CASES = [
     (2, 32, 64, 64, 64, False, False, 64, 1),     # concat of two sources, exact 16 x 32 quad tiles, two N tiles
     (1, 40, 72, 128, 0, False, False, 48, 1),     # ragged quad tiles and ragged N
     (2, 20, 12, 64, 32, False, False, 32, 1),     # sources of different width, narrow image (8-wide sub-tiles, padded rows)
+    # deep layers on few workgroups (the shapes of enc5b / iconv5 / enc4b at small batch)
+    (1, 8, 10, 512, 0, False, False, 512, 1),     # 16 chunks (bf16)
+    (2, 16, 20, 256, 256, False, False, 256, 1),  # concat, 16 chunks from two sources
+    (2, 16, 20, 256, 0, False, False, 256, 1),    # 8 chunks
+    (1, 8, 10, 288, 0, False, False, 64, 1),      # 9 (bf16) / 18 (f32) chunks: odd count on the two-chunk ring
 ]
 
 
