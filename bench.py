@@ -333,14 +333,29 @@ def main():
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
+    # developer probes (tools/README.md): COLVO_BENCH_HOST_SPIN_US burns host time in every step (does the step time move? then
+    # the host is the limit), COLVO_BENCH_HOST_LEAD prints how far the host ran ahead of the GPU (host enqueue time per step)
+    spin_us = float(os.environ.get("COLVO_BENCH_HOST_SPIN_US", "0"))
+    host_t = []
     for i in range(args.steps):
         step_ev[i].record()
+        h0 = time.perf_counter()
         loss = step(not use_graph)
+        if spin_us > 0:
+            t_end = time.perf_counter() + spin_us * 1e-6
+            while time.perf_counter() < t_end:
+                pass
+        host_t.append(time.perf_counter() - h0)
     step_ev[args.steps].record()
+    host_done = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
     ev_raw = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    if os.environ.get("COLVO_BENCH_HOST_LEAD") and rank == 0:
+        hs = sorted(host_t)
+        print(f"host: enqueue of {args.steps} steps took {host_done * 1e3:.2f} ms of the {elapsed * 1e3:.2f} ms until the GPU "
+              f"finished; per step median {hs[len(hs) // 2] * 1e3:.3f} ms, max {hs[-1] * 1e3:.3f} ms", file=sys.stderr)
     if os.environ.get("COLVO_BENCH_DUMP_STEPS") and rank == 0:
         print("step ms:", " ".join(f"{v:.2f}" for v in ev_raw), file=sys.stderr)
     ev_ms = sorted(ev_raw)

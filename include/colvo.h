@@ -218,7 +218,7 @@ int colvo_pose_head_bwd(int dtype, const void* x, const float* w, const float* d
  * a8  Adam over the flat parameter arena (torch.optim.Adam semantics, no weight decay)         *
  * ------------------------------------------------------------------------------------------- */
 /* step_count: device int32 holding t BEFORE this step (incremented by the kernel, graph-safe).
- * grad_scale multiplies the gradient first (1/world_size for data-parallel sums). */
+ * grad_scale multiplies the gradient first (1/world_size for data-parallel sums).  The four arenas must be 16-byte aligned. */
 int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     int32_t* step_count, colvo_stream_t stream);
