@@ -14,8 +14,14 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r1"
 SRC = f"gpurun_out/prof_{R}"
 os.makedirs("profiles", exist_ok=True)
 
+
+def newest(pattern):
+    # gpurun merges every call's output into the same directory: earlier runs' files stay, so take the latest
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 # 1) kernel stats of the bench command
-f = glob.glob(f"{SRC}/bench_trace/*/*_kernel_stats.csv")[0]
+f = newest(f"{SRC}/bench_trace/*/*_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 with open(f"profiles/{R}_bench_kernel_stats.csv", "w", newline="") as o:
     w = csv.writer(o)
@@ -27,7 +33,7 @@ with open(f"profiles/{R}_bench_kernel_stats.csv", "w", newline="") as o:
 
 
 def counters(d):
-    f = glob.glob(f"{SRC}/{d}/*/*_counter_collection.csv")[0]
+    f = newest(f"{SRC}/{d}/*/*_counter_collection.csv")
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         nm = r["Kernel_Name"].replace("colvo::(anonymous namespace)::", "").split("(")[0]
@@ -36,7 +42,7 @@ def counters(d):
 
 
 def durations(d):
-    f = glob.glob(f"{SRC}/{d}/*/*_kernel_trace.csv")[0]
+    f = newest(f"{SRC}/{d}/*/*_kernel_trace.csv")
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         nm = r["Kernel_Name"].replace("colvo::(anonymous namespace)::", "").split("(")[0]
@@ -54,7 +60,7 @@ cal_f = (16.0 * N / 1024.0) / adam_f       # true KiB read / counter
 cal_w = (12.0 * N / 1024.0) / adam_w
 out = {"round": R, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes (tools/collect_profiles.sh); "
        "counters are KiB at the L2's memory-side interface; corrected by the factor measured in the same process on k_adam "
-       "(dword-per-lane streaming of known size: 16 B read + 12 B written per element, 64 Mi elements)",
+       "(coalesced streaming of known size: 16 B read + 12 B written per element, 64 Mi elements)",
        "calibration": {"fetch_factor": cal_f, "write_factor": cal_w,
                        "note": "MI355X_MICROARCH.md §HBM: FETCH_SIZE reports 1/2 of a coalesced streaming read on gfx950; WRITE_SIZE exact"},
        "kernels": []}
