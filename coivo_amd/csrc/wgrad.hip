@@ -16,7 +16,16 @@ namespace {
 // octets, i.e. the pitch is an ODD multiple of 32 bytes AND the 8 pixels are consecutive (see the pixel order in the kernel).
 // With the former pitch of 80 bytes and pixel order every such read took two passes (profiles/r2_conv_pmc.json: 43-48 % of the
 // weight-gradient kernels' LDS cycles were bank conflicts); removing them was worth 2 % of the kernels' time.
-// (Also measured this round and dropped: a two-tile register ring for the staging loads -- 12 % SLOWER, 208 registers;
+// (Also measured this round and dropped, all parity-green: requesting ALL fragments of k-step ks+1 before the MFMAs of step ks
+// (two register sets; hipcc alone keeps one fragment pair of look-ahead): 534 -> 537 us over the DepthNet stack, no change;
+// LDS-DMA staging (`buffer_load_dwordx4 ... offen lds` into 2 / 3 rotating stage buffers, one raw barrier per tile, counted
+// vmcnt -- tools/ubench/lds_dma.hip holds the hardware check of the addressing rules): 528 -> 558 / 563 us, every stride-1 layer
+// ~10 % slower (the padded LDS image costs 8 DMA instructions per thread and tile instead of 5 loads, and the third buffer
+// bought nothing: the tile loop is not waiting for memory).  A compile-time phase ablation says the same: without the global
+// loads -17 %, without fragment reads + MFMAs -25 %, without the LDS stores (and the then dead loads) -26 %, everything off
+// still 45 % (launch, set-up, the atomics of the flush).  Per tile the loop moves ~134 KB through LDS (114 KB of transposed
+// fragment reads) = 0.45 us at 128 B/clk against 0.27 us of MFMA time and ~0.95 us measured.
+// Also: a two-tile register ring for the staging loads -- 12 % SLOWER, 208 registers;
 // 256-pixel tiles for the multi-chunk layers -- 2 % faster alone (534 -> 524 us), 0.7 % SLOWER inside the training step,
 // where the weight-gradient kernels share the CUs with the input-gradient chain.)
 template <typename T, int MT>
