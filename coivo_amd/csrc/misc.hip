@@ -366,6 +366,66 @@ __global__ __launch_bounds__(NT) void k_depth_head_dgrad(const void* __restrict_
     }
 }
 
+// The same for C = 16 (the DepthNet head) with whole-pixel accesses: a thread reads its pixel's 16 channels as 16-byte granules,
+// and writes them back the same way -- the generic kernel above issues 16 two-byte loads and stores per pixel.
+template <int ES>
+__global__ __launch_bounds__(NT) void k_depth_head_dgrad16(const void* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ dpre, int H, int W, void* __restrict__ dx) {
+    constexpr int C = 16, NGR = C * ES / 16;       // granules per pixel: 2 (bf16) / 4 (f32)
+    __shared__ float sw[9 * C];
+    if (threadIdx.x < 9 * C) sw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)H * W) return;
+    const int yy = (int)(pix / W), xx = (int)(pix - (size_t)yy * W);
+    float g[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int y2 = yy - ky + 1, x2 = xx - kx + 1;
+            g[ky * 3 + kx] = (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) ? dpre[((size_t)b * H + y2) * W + x2] : 0.0f;
+        }
+    const size_t o = ((size_t)b * H * W + pix) * NGR;
+    const uint4* xin = reinterpret_cast<const uint4*>(x) + o;
+    uint4* out = reinterpret_cast<uint4*>(dx) + o;
+    uint4 xv[NGR];
+#pragma unroll
+    for (int q = 0; q < NGR; ++q) xv[q] = xin[q];
+    float v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float a = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) a += g[t] * sw[t * C + c];
+        v[c] = a;
+    }
+    if constexpr (ES == 2) {
+#pragma unroll
+        for (int q = 0; q < NGR; ++q) {
+            const unsigned xw[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+            unsigned ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 8 * q + 2 * j;
+                const float x0 = bf2f((uint16_t)(xw[j] & 0xffffu)), x1 = bf2f((uint16_t)(xw[j] >> 16));
+                ow[j] = (unsigned)f2bf(x0 > 0.0f ? v[c] : 0.0f) | ((unsigned)f2bf(x1 > 0.0f ? v[c + 1] : 0.0f) << 16);
+            }
+            out[q] = uint4{ow[0], ow[1], ow[2], ow[3]};
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NGR; ++q) {
+            const unsigned xw[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+            unsigned ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ow[j] = __float_as_uint(__uint_as_float(xw[j]) > 0.0f ? v[4 * q + j] : 0.0f);
+            out[q] = uint4{ow[0], ow[1], ow[2], ow[3]};
+        }
+    }
+}
+
 // dw[t][c] += sum_pix dpre[pix] * x[pix + tap][c];  db += sum dpre.
 // Written from the input pixel's side: dw[t][c] = sum_q x[q][c] * dpre[q - tap].  Each thread walks a
 // strided set of pixels q, keeps all 9*C products in registers, and the workgroup reduces ONCE at the
@@ -610,6 +670,7 @@ __global__ __launch_bounds__(NT) void k_adam(float* __restrict__ p, const float*
 __global__ void k_inc_step(int32_t* step_count) { step_count[0] += 1; }
 
 inline unsigned nblk(size_t n) { return (unsigned)((n + NT - 1) / NT); }
+inline bool head_dgrad_generic() { static const bool v = getenv("COLVO_HEAD_DGRAD_GENERIC") != nullptr; return v; }   // A/B switch
 
 }  // namespace
 }  // namespace colvo
@@ -730,8 +791,12 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
     if (dw) {
         if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
     }
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
-                                          x, w, scratch, H, W, C, dx));
+    if (C == 16 && ((uintptr_t)x | (uintptr_t)dx) % 16 == 0 && !head_dgrad_generic()) {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
+    } else {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+                                              x, w, scratch, H, W, C, dx));
+    }
     COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
     return 0;
 }
@@ -755,8 +820,12 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
     if (dw) {
         if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
     }
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
-                                          x, w, scratch, H, W, C, dx));
+    if (C == 16 && ((uintptr_t)x | (uintptr_t)dx) % 16 == 0 && !head_dgrad_generic()) {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
+    } else {
+        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+                                              x, w, scratch, H, W, C, dx));
+    }
     COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
     return 0;
 }
