@@ -71,6 +71,7 @@ SIGNATURES = {
     "colvo_adam_step_t": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
     "colvo_zero": (_i, [_vp, _sz, _vp]),
     "colvo_frames_u8_to_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "colvo_read_npy_u8_frames": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "colvo_backproject": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "colvo_stitch_workspace_ints": (_sz, [_i, _i, _i, _i]),
     "colvo_stitch_point_cloud": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),

@@ -255,6 +255,11 @@ int colvo_stitch_point_cloud(const float* depths, const float* K, const float* c
 int colvo_frames_u8_to_f32(const uint8_t* frames, int B, int h, int w, int H, int W, float* out,
                            colvo_stream_t stream);
 
+/* Host side of the same row (no GPU work): n raw frames -- `.npy` files holding [h,w,3] uint8 arrays in C order -- read into
+ * dst[n][h][w][3] (the caller's staging buffer, normally pinned) by up to `nthreads` threads; every header is checked against
+ * (h, w).  Returns non-zero with the first failing file in colvo_last_error(). */
+int colvo_read_npy_u8_frames(const char* const* paths, int n, int h, int w, uint8_t* dst, int nthreads);
+
 /* ------------------------------------------------------------------------------------------- *
  * Command lists: ONE call enqueues a recorded sequence of the entry points above (a network's  *
  * forward or backward) on a main and a side stream -- the host's per-launch cost, not the GPU, *

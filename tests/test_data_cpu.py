@@ -100,3 +100,56 @@ def test_loader_refuses_cpu(tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             D.PairLoader(ds, 2, (64, 96), device="cpu")
+
+
+def test_native_npy_frame_reader_matches_numpy_and_rejects_bad_files(tmp_path):
+    """colvo_read_npy_u8_frames (host-only entry point of the C-ABI: no GPU needed): payloads equal np.load, every header is
+    checked against the expected frame shape, and a failing file is named in the error."""
+    from coivo_amd.data import read_npy_frames
+    rng = np.random.default_rng(3)
+    h, w = 37, 52
+    paths, ref = [], []
+    for k in range(11):
+        a = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / f"f{k:02d}.npy")
+        np.save(p, a)
+        paths.append(p)
+        ref.append(a)
+    for threads in (1, 4, 32):
+        out = np.full((len(paths), h, w, 3), 7, dtype=np.uint8)
+        read_npy_frames(paths, out, threads)
+        assert np.array_equal(out, np.stack(ref))
+    # version-2 header
+    p2 = str(tmp_path / "v2.npy")
+    with open(p2, "wb") as f:
+        np.lib.format.write_array(f, ref[0], version=(2, 0))
+    out = np.zeros((1, h, w, 3), dtype=np.uint8)
+    read_npy_frames([p2], out)
+    assert np.array_equal(out[0], ref[0])
+
+    def expect_fail(path, what):
+        with pytest.raises(RuntimeError, match=what):
+            read_npy_frames([paths[0], path], np.zeros((2, h, w, 3), dtype=np.uint8), 2)
+
+    bad = str(tmp_path / "shape.npy")
+    np.save(bad, np.zeros((h, w + 1, 3), dtype=np.uint8))
+    expect_fail(bad, "shape.npy")
+    bad = str(tmp_path / "dtype.npy")
+    np.save(bad, np.zeros((h, w, 3), dtype=np.float32))
+    expect_fail(bad, "dtype.npy")
+    bad = str(tmp_path / "fortran.npy")
+    np.save(bad, np.asfortranarray(np.zeros((h, w, 3), dtype=np.uint8)))
+    expect_fail(bad, "fortran.npy")
+    bad = str(tmp_path / "short.npy")
+    with open(paths[1], "rb") as f:
+        blob = f.read()
+    with open(bad, "wb") as f:
+        f.write(blob[:-100])
+    expect_fail(bad, "truncated")
+    expect_fail(str(tmp_path / "missing.npy"), "missing.npy")
+    bad = str(tmp_path / "junk.npy")
+    with open(bad, "wb") as f:
+        f.write(b"not a numpy file at all")
+    expect_fail(bad, "junk.npy")
+    with pytest.raises(ValueError):
+        read_npy_frames(paths[:2], np.zeros((3, h, w, 3), dtype=np.uint8))
