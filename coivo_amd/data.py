@@ -5,13 +5,17 @@ Reference: README.md:13 (the dataset is an external download; its on-disk layout
 one H2D copy on a copy stream followed by csrc/frames.hip (resize + de-interleave + /255); `prefetch` batches are being
 decoded while the current one trains.  Raw `.npy` frames take the library's native reader (colvo_read_npy_u8_frames: parallel
 pread() straight into the pinned buffer, no interpreter lock): 15-30 k pairs/s at 320x256 on a 16-core box against ~4.5 k through
-the interpreter; PNG / JPEG frames are decoded by PIL on the thread pool (~1.5 k pairs/s for 320x256 PNGs).  One process per GPU: `rank` / `world_size` shard the pairs
+the interpreter; PNG / JPEG frames are decoded by PIL on the thread pool (~1.0 k pairs/s beside a training loop) or, with
+`decoders=N`, by N worker processes writing into shared pinned staging buffers (~3 k pairs/s beside a training loop, N = 10).  One process per GPU: `rank` / `world_size` shard the pairs
 with no communication (a seeded permutation every rank computes identically).
 """
 from __future__ import annotations
 
 import collections
 import os
+import queue
+import subprocess
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
@@ -189,7 +193,7 @@ class PairLoader:
 
     def __init__(self, dataset: SequenceFolder, batch_size: int, size: Tuple[int, int], *, rank: int = 0,
                  world_size: int = 1, shuffle: bool = True, seed: int = 0, device="cuda", workers: int = 8, prefetch: int = 2,
-                 own_copy_stream: Optional[bool] = None):
+                 own_copy_stream: Optional[bool] = None, decoders: int = 0):
         if size[0] % 32 or size[1] % 32:
             raise ValueError("size (H, W) must be multiples of 32 (DepthNet)")
         self.ds, self.B, self.size = dataset, batch_size, tuple(size)
@@ -202,7 +206,7 @@ class PairLoader:
         # with a single batch in flight the rate is one batch per decode latency, whatever the number of cores
         self.prefetch = max(1, int(prefetch))
         self.workers = max(1, int(workers))
-        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+        self.pool = ThreadPoolExecutor(max_workers=max(self.workers, int(decoders)))
         self._stager = ThreadPoolExecutor(max_workers=self.prefetch)
         # The upload (H2D copy + conversion kernel) runs on a copy stream of the loader's own, behind the previous step -- but that
         # is one more active hardware queue, and beside the training step's three (main, the weight-gradient side stream, the
@@ -221,6 +225,76 @@ class PairLoader:
             _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
         self._pinned: Dict[Tuple[int, int, int, int], torch.Tensor] = {}      # (slot, 2B, h, w) -> pinned staging buffer
         self._uploaded: Dict[int, torch.cuda.Event] = {}
+        # decoders > 0: PNG / JPEG frames are decoded by that many worker PROCESSES (coivo_amd/_decode_worker.py) writing into
+        # shared-memory staging buffers registered as pinned memory -- the interpreter lock caps in-process decoding at ~1.5 k
+        # pairs/s.  Raw .npy frames never need them (native reader).
+        self._shm: Dict[Tuple[int, int, int, int], object] = {}
+        self._idle: "queue.Queue" = queue.Queue()
+        self._procs: List[subprocess.Popen] = []
+        for _ in range(max(0, int(decoders))):
+            p = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_decode_worker.py")],
+                                 stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+            self._procs.append(p)
+            self._idle.put(p)
+
+    def close(self) -> None:
+        """Stop the decoder processes and release the shared staging buffers (also called when the loader is collected)."""
+        for p in self._procs:
+            try:
+                p.stdin.close()
+                p.wait(timeout=5)
+            except Exception:           # noqa: BLE001
+                p.kill()
+        self._procs = []
+        for key, shm in list(self._shm.items()):
+            buf = self._pinned.pop(key, None)
+            if buf is not None:
+                torch.cuda.cudart().cudaHostUnregister(buf.data_ptr())
+            del buf
+            for fin in (shm.close, shm.unlink):       # unlink even when a view of the block is still alive somewhere
+                try:
+                    fin()
+                except Exception:       # noqa: BLE001
+                    pass
+        self._shm = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:               # noqa: BLE001
+            pass
+
+    def _staging_buffer(self, key) -> torch.Tensor:
+        """The pinned [2n,h,w,3] uint8 buffer of ring slot key[0]; with decoder processes it lives in shared memory."""
+        buf = self._pinned.get(key)
+        if buf is not None:
+            return buf
+        _, n, h, w = key
+        if not self._procs:
+            buf = torch.empty(2 * n, h, w, 3, dtype=torch.uint8).pin_memory()
+        else:
+            from multiprocessing import shared_memory
+            nbytes = 2 * n * h * w * 3
+            shm = shared_memory.SharedMemory(create=True, size=nbytes)
+            buf = torch.frombuffer(shm.buf, dtype=torch.uint8, count=nbytes).view(2 * n, h, w, 3)
+            rc = torch.cuda.cudart().cudaHostRegister(buf.data_ptr(), nbytes, 0)
+            if int(rc) != 0:
+                shm.close(); shm.unlink()
+                raise RuntimeError(f"PairLoader: cudaHostRegister of the shared staging buffer failed ({rc})")
+            self._shm[key] = shm
+        self._pinned[key] = buf
+        return buf
+
+    def _decode_remote(self, shm_name: str, offset: int, h: int, w: int, path: str) -> None:
+        p = self._idle.get()
+        try:
+            p.stdin.write(f"{shm_name}\t{offset}\t{h}\t{w}\t{path}\n")
+            p.stdin.flush()
+            reply = p.stdout.readline().rstrip("\n")
+        finally:
+            self._idle.put(p)
+        if reply != "ok":
+            raise ValueError(f"{path}: {reply[4:] if reply.startswith('err ') else 'decoder process died'}")
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = epoch
@@ -239,9 +313,7 @@ class PairLoader:
                 raise ValueError(f"batch mixes frame sizes: {info[4]} is {info[3]}, expected {(h, w)}")
         n = len(infos)
         key = (slot, n, h, w)
-        buf = self._pinned.get(key)
-        if buf is None:
-            buf = self._pinned[key] = torch.empty(2 * n, h, w, 3, dtype=torch.uint8).pin_memory()
+        buf = self._staging_buffer(key)
         ev = self._uploaded.pop(buf.data_ptr(), None)
         if ev is not None:
             ev.synchronize()          # the H2D copy that last read this pinned buffer (a ring turn ago) must be over
@@ -250,6 +322,15 @@ class PairLoader:
         paths = [info[0] for info in infos] + [info[1] for info in infos]
         if all(p.endswith(".npy") for p in paths):
             read_npy_frames(paths, view, self.workers)      # native: headers checked and payloads read in C, no interpreter lock
+            K = resize_intrinsics(torch.stack([info[2] for info in infos]), (h, w), self.size)
+            return buf, K, (h, w)
+        if self._procs:                   # one frame per request to whichever decoder process is idle
+            shm_name, fb = self._shm[key].name, h * w * 3
+            todo = [(j, p) for j, p in enumerate(paths) if not p.endswith(".npy")]
+            for j, p in enumerate(paths):
+                if p.endswith(".npy"):
+                    read_frame_into(p, view[j])
+            list(self.pool.map(lambda jp: self._decode_remote(shm_name, jp[0] * fb, h, w, jp[1]), todo))
             K = resize_intrinsics(torch.stack([info[2] for info in infos]), (h, w), self.size)
             return buf, K, (h, w)
         jobs = [(p, view[j]) for j, p in enumerate(paths)]

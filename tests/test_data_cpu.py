@@ -153,3 +153,43 @@ def test_native_npy_frame_reader_matches_numpy_and_rejects_bad_files(tmp_path):
     expect_fail(bad, "junk.npy")
     with pytest.raises(ValueError):
         read_npy_frames(paths[:2], np.zeros((3, h, w, 3), dtype=np.uint8))
+
+
+def test_decode_worker_process_protocol(tmp_path):
+    """coivo_amd/_decode_worker.py (the image-decoding worker of PairLoader(decoders=N)) on its own: frames land in the shared-memory
+    block at the requested offset, a wrong size or a missing file is reported, and the worker exits when stdin closes."""
+    import subprocess
+    import sys
+    from multiprocessing import shared_memory
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    h, w = 24, 40
+    frames = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(3)]
+    paths = []
+    for k, a in enumerate(frames):
+        p = str(tmp_path / f"{k}.png")
+        Image.fromarray(a).save(p)
+        paths.append(p)
+    worker = os.path.join(os.path.dirname(D.__file__), "_decode_worker.py")
+    shm = shared_memory.SharedMemory(create=True, size=3 * h * w * 3)
+    proc = subprocess.Popen([sys.executable, worker], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        def ask(off, hh, ww, path):
+            proc.stdin.write(f"{shm.name}\t{off}\t{hh}\t{ww}\t{path}\n")
+            proc.stdin.flush()
+            return proc.stdout.readline().rstrip("\n")
+        for k in (2, 0, 1):
+            assert ask(k * h * w * 3, h, w, paths[k]) == "ok"
+        got = np.ndarray((3, h, w, 3), dtype=np.uint8, buffer=shm.buf)
+        assert np.array_equal(got, np.stack(frames))
+        del got
+        assert ask(0, h + 1, w, paths[0]).startswith("err ValueError")
+        assert ask(0, h, w, str(tmp_path / "missing.png")).startswith("err FileNotFoundError")
+        assert ask(0, h, w, paths[1]) == "ok"                   # still alive after errors
+        proc.stdin.close()
+        assert proc.wait(timeout=20) == 0
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+        shm.close()
+        shm.unlink()

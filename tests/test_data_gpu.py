@@ -83,3 +83,49 @@ def test_mixed_frame_sizes_are_refused(tmp_path):
     ld = D.PairLoader(ds, 4, (64, 64), shuffle=False)
     with pytest.raises(ValueError):
         next(iter(ld))
+
+
+@pytest.mark.parametrize("fmt", ["png", "npy"])
+def test_decoder_processes_deliver_the_same_batches(tmp_path, fmt):
+    """PairLoader(decoders=N): frames decoded by worker processes into shared, host-registered staging buffers -- the batches must
+    equal the in-process loader's bit for bit, over two epochs (ring slots reused), and close() must leave nothing behind."""
+    from coivo_amd import data as D
+    ds = D.SequenceFolder(make_tree(str(tmp_path), seqs=(("a", 9, (60, 80)), ("b", 7, (60, 80))), fmt=fmt))
+    ref = D.PairLoader(ds, 2, (64, 96), shuffle=True, seed=5, workers=2)
+    rem = D.PairLoader(ds, 2, (64, 96), shuffle=True, seed=5, workers=2, decoders=3)
+    try:
+        for ep in range(2):
+            ref.set_epoch(ep)
+            rem.set_epoch(ep)
+            n = 0
+            for a, b in zip(ref, rem):
+                assert torch.equal(a["tgt"], b["tgt"]) and torch.equal(a["ref"], b["ref"]) and torch.equal(a["K"], b["K"])
+                n += 1
+            assert n == len(ref) == 7
+        names = [shm.name for shm in rem._shm.values()]
+        assert names
+    finally:
+        procs = list(rem._procs)
+        rem.close()
+    assert all(p.poll() is not None for p in procs)
+    from multiprocessing import shared_memory
+    for nm in names:
+        with pytest.raises(FileNotFoundError):
+            shared_memory.SharedMemory(name=nm)
+
+
+def test_decoder_process_errors_reach_the_caller(tmp_path):
+    from coivo_amd import data as D
+    root = make_tree(str(tmp_path), seqs=(("a", 4, (48, 64)),))
+    ds = D.SequenceFolder(root)
+    import os
+    victim = sorted(os.listdir(os.path.join(root, "a")))[1]
+    with open(os.path.join(root, "a", victim), "wb") as f:
+        f.write(b"not an image")
+    ld = D.PairLoader(ds, 1, (64, 96), shuffle=False, decoders=2)
+    try:
+        with pytest.raises(ValueError, match=victim):
+            for _ in ld:
+                pass
+    finally:
+        ld.close()

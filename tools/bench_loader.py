@@ -4,7 +4,7 @@
 Writes a temporary dataset (under $TMPDIR), iterates two epochs and prints pairs/s of the second one -- with nothing else on
 the GPU, so this is the rate the loader can deliver, to be read against the training step's rate.  With a sixth argument
 `train` every batch is also trained on (bf16 DCDP+LCC step, random weights): the end-to-end rate of loader + step in one process.
-OWN_COPY_STREAM=0 / 1 overrides the loader's choice of stream for the upload (see data.PairLoader)."""
+DECODERS=n decodes images in n worker processes; OWN_COPY_STREAM=0 / 1 overrides the loader's choice of stream for the upload (see data.PairLoader)."""
 import os
 import shutil
 import sys
@@ -41,7 +41,8 @@ def main():
                     Image.fromarray(a).save(os.path.join(d, f"{k:05d}.png"), compress_level=1)
         ds = SequenceFolder(root)
         ld = PairLoader(ds, B, (256, 320), shuffle=True, workers=workers, prefetch=prefetch,
-                        own_copy_stream={None: None, "0": False, "1": True}[os.environ.get("OWN_COPY_STREAM")])
+                        own_copy_stream={None: None, "0": False, "1": True}[os.environ.get("OWN_COPY_STREAM")],
+                        decoders=int(os.environ.get("DECODERS", "0")))
         step = None
         if train:
             from coivo_amd import functional as Fh, nn as hnn
