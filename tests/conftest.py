@@ -26,3 +26,15 @@ def _ensure_library_built():
     without a GPU)."""
     from coivo_amd import build
     build.ensure()
+
+
+@pytest.fixture(autouse=True)
+def _restore_aux_stream_limit(request):
+    """data.PairLoader and ddp.GradBuckets switch the library's auxiliary side stream off for the process
+    (colvo_set_aux_side_streams(0): they bring a third hardware queue of their own).  Tests share one process: put the default
+    back after each GPU test so that the ones that follow still exercise the two-side-stream schedule."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from coivo_amd import _lib
+        if _lib._lib is not None:
+            _lib._lib.colvo_set_aux_side_streams(3)
