@@ -220,9 +220,13 @@ class PairLoader:
             import torch.distributed as dist
             own_copy_stream = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         self.copy_stream = None
+        # (With GPU_MAX_HW_QUEUES=2 in the environment before HIP initialises, the runtime folds all streams onto two hardware
+        # queues: four streams are then harmless -- measured 5210 pairs/s with the auxiliary stream left on, the resident-tensor
+        # rate -- so the auxiliary stream stays.)
         if own_copy_stream:
             self.copy_stream = torch.cuda.Stream(device=self.device)
-            _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
+            if os.environ.get("GPU_MAX_HW_QUEUES") not in ("1", "2"):
+                _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
         self._pinned: Dict[Tuple[int, int, int, int], torch.Tensor] = {}      # (slot, 2B, h, w) -> pinned staging buffer
         self._uploaded: Dict[int, torch.cuda.Event] = {}
         # decoders > 0: PNG / JPEG frames are decoded by that many worker PROCESSES (coivo_amd/_decode_worker.py) writing into

@@ -17,6 +17,8 @@ fused Adam kernel (grad_scale) instead of a separate pass.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence
 
 import torch
@@ -58,7 +60,8 @@ class GradBuckets:
             # active hardware queues as this GPU schedules well.  With the library's second side stream on top the step measured
             # 5.2 ms instead of 1.7 (bench.py --rccl-single): keep the weight gradients on ONE side stream.
             from . import _lib
-            _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
+            if os.environ.get("COLVO_DDP_KEEP_AUX") is None:        # A/B switch
+                _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
         self.transport_dtype = transport_dtype
         self.states: List[_ArenaState] = []
         self._pending = []
