@@ -41,15 +41,38 @@ def _stale(out, srcs):
     return any(os.path.getmtime(s) > t for s in srcs)
 
 
+def _object_stamp(src) -> str:
+    """sha256 of everything one object is built from: its source, every header it may include, its flags.  Kept in a
+    sidecar file beside the object; an object is reused only when its stamp matches (mtimes do not survive a copy of the
+    tree, and a cached object NEWER than an edited source must not be linked)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in [src] + sorted(_deps()):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update((" ".join(FLAGS) + " " + " ".join(FILE_FLAGS.get(os.path.basename(src), []))).encode())
+    return h.hexdigest()
+
+
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
-    if _stale(obj, [src] + _deps()):
+    stamp_file, stamp = obj + ".stamp", _object_stamp(src)
+    try:
+        current = os.path.exists(obj) and open(stamp_file).read().strip() == stamp
+    except OSError:
+        current = False
+    if not current:
+        if os.path.exists(stamp_file):
+            os.remove(stamp_file)
         cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
+        with open(stamp_file, "w") as f:
+            f.write(stamp)
     return obj
 
 
@@ -100,19 +123,16 @@ def build(force: bool = False) -> str:
     if not srcs:
         raise RuntimeError("no HIP sources found")
     if force:
-        for f in glob.glob(os.path.join(OBJDIR, "*.o")):
+        for f in glob.glob(os.path.join(OBJDIR, "*.o")) + glob.glob(os.path.join(OBJDIR, "*.stamp")):
             os.remove(f)
-    # objects are keyed by the hash of their own inputs (mtimes do not survive a copy of the tree)
-    stamp = os.path.join(OBJDIR, "flags.txt")
-    flags_now = " ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))
-    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
-        for f in glob.glob(os.path.join(OBJDIR, "*.o")):
-            os.remove(f)
-        with open(stamp, "w") as f:
-            f.write(flags_now)
+    # every object carries a sidecar stamp = hash of its own inputs (_object_stamp): edited sources, headers or flags recompile
+    # exactly the objects they affect, whatever the files' mtimes say
+    for f in glob.glob(os.path.join(OBJDIR, "*.o")):
+        if os.path.basename(f)[:-2] + ".hip" not in {os.path.basename(x) for x in srcs}:
+            os.remove(f)            # object of a source file that no longer exists
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(_compile, srcs))
-    if force or _stale(LIB, objs) or not is_current():
+    if force or _stale(LIB, objs) or not is_current():       # (a relink is cheap; the objects above are already exact)
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -223,10 +223,13 @@ class PairLoader:
         # (With GPU_MAX_HW_QUEUES=2 in the environment before HIP initialises, the runtime folds all streams onto two hardware
         # queues: four streams are then harmless -- measured 5210 pairs/s with the auxiliary stream left on, the resident-tensor
         # rate -- so the auxiliary stream stays.)
+        self._queue_claim = None
         if own_copy_stream:
             self.copy_stream = torch.cuda.Stream(device=self.device)
-            if os.environ.get("GPU_MAX_HW_QUEUES") not in ("1", "2"):
-                _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
+            from . import streams
+            self._queue_claim = streams.claim_external_queue("loader copy stream")      # given back by close()
+        self._slot_seq = 0                  # ring-slot counter, monotonic across iterations (see __iter__)
+        self._inflight: "collections.deque" = collections.deque()
         self._pinned: Dict[Tuple[int, int, int, int], torch.Tensor] = {}      # (slot, 2B, h, w) -> pinned staging buffer
         self._uploaded: Dict[int, torch.cuda.Event] = {}
         # decoders > 0: PNG / JPEG frames are decoded by that many worker PROCESSES (coivo_amd/_decode_worker.py) writing into
@@ -242,7 +245,12 @@ class PairLoader:
             self._idle.put(p)
 
     def close(self) -> None:
-        """Stop the decoder processes and release the shared staging buffers (also called when the loader is collected)."""
+        """Stop the decoder processes, release the shared staging buffers and give the copy stream's hardware queue back to
+        the stream policy (also called when the loader is collected)."""
+        self._drain()
+        if getattr(self, "_queue_claim", None) is not None:
+            self._queue_claim.release()
+            self._queue_claim = None
         for p in self._procs:
             try:
                 p.stdin.close()
@@ -372,28 +380,47 @@ class PairLoader:
         # decode of batches k+1 .. k+prefetch (staging threads + the decoder pool) overlaps the upload and the training step
         # of batch k; ring of prefetch + 2 pinned buffers: `prefetch` being filled, one being uploaded, one of margin
         ring = self.prefetch + 2
-        futs = collections.deque()
+        # An iterator abandoned mid-epoch (break) may have left staging tasks running: wait for them before handing out slots
+        # again, and number the slots with a counter that never restarts, so that a new iteration cannot stage into a pinned
+        # buffer an old task -- or an upload still in flight -- is using.
+        self._drain()
+        futs = self._inflight
         submitted = 0
 
         def submit():
             nonlocal submitted
             if submitted < len(batches):
-                futs.append(self._stager.submit(self._stage, batches[submitted], submitted % ring))
+                futs.append(self._stager.submit(self._stage, batches[submitted], self._slot_seq % ring))
+                self._slot_seq += 1
                 submitted += 1
-        for _ in range(self.prefetch):
-            submit()
-        pending = None
-        for step in range(len(batches) + 1):
-            nxt = None
-            if step < len(batches):
-                staged = futs.popleft().result()
+        try:
+            for _ in range(self.prefetch):
                 submit()
-                nxt = self._upload(staged)
-            if pending is not None:
-                out, Kd, done, raw = pending
-                torch.cuda.current_stream(self.device).wait_event(done)
-                for t in (out, Kd, raw):
-                    t.record_stream(torch.cuda.current_stream(self.device))
-                B = out.shape[0] // 2
-                yield {"tgt": out[:B], "ref": out[B:], "K": Kd}
-            pending = nxt
+            pending = None
+            for step in range(len(batches) + 1):
+                nxt = None
+                if step < len(batches):
+                    staged = futs.popleft().result()
+                    submit()
+                    nxt = self._upload(staged)
+                if pending is not None:
+                    out, Kd, done, raw = pending
+                    torch.cuda.current_stream(self.device).wait_event(done)
+                    for t in (out, Kd, raw):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+                    B = out.shape[0] // 2
+                    yield {"tgt": out[:B], "ref": out[B:], "K": Kd}
+                pending = nxt
+        finally:
+            self._drain()           # generator closed early (break / exception): no staging task outlives its iterator
+
+    def _drain(self) -> None:
+        """Wait for every outstanding staging task (their results are dropped; errors of abandoned tasks are not raised)."""
+        q = getattr(self, "_inflight", None)
+        while q:
+            f = q.popleft()
+            if not f.cancel():
+                try:
+                    f.result()
+                except Exception:           # noqa: BLE001
+                    pass

@@ -55,13 +55,17 @@ class GradBuckets:
             raise RuntimeError("GradBuckets needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self._queue_claim = None
         if any(getattr(m, "flat_grad", None) is not None and m.flat_grad.is_cuda for m in modules):
             # The communicator brings a stream of its own: main + weight-gradient side stream + communicator is as many
             # active hardware queues as this GPU schedules well.  With the library's second side stream on top the step measured
-            # 5.2 ms instead of 1.7 (bench.py --rccl-single): keep the weight gradients on ONE side stream.
-            from . import _lib
+            # 5.2 ms instead of 1.7 (bench.py --rccl-single): the claim keeps the weight gradients on ONE
+            # side stream while this object is attached (streams.py; detach() gives the queue back).
+            from . import streams
+            if dist.get_backend(process_group) == "nccl":
+                streams.check_environment(self.world)
             if os.environ.get("COLVO_DDP_KEEP_AUX") is None:        # A/B switch
-                _lib.check(_lib.load().colvo_set_aux_side_streams(0), "colvo_set_aux_side_streams")
+                self._queue_claim = streams.claim_external_queue("rccl")
         self.transport_dtype = transport_dtype
         self.states: List[_ArenaState] = []
         self._pending = []
@@ -74,6 +78,7 @@ class GradBuckets:
                 st.staging = torch.empty(m.flat_grad.numel(), device=m.flat_grad.device, dtype=transport_dtype)
             self.states.append(st)
             m.grad_ready_hook = self._make_hook(st)
+        self.attached = True
 
     @property
     def grad_scale(self) -> float:
@@ -132,5 +137,10 @@ class GradBuckets:
             st.next, st.low, st.calls = 1, st.module.flat_grad.numel(), 0
 
     def detach(self) -> None:
+        """Unhook from the networks and give the communicator's hardware queue back to the stream policy."""
         for st in self.states:
             st.module.grad_ready_hook = None
+        self.attached = False
+        if self._queue_claim is not None:
+            self._queue_claim.release()
+            self._queue_claim = None

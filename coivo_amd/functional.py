@@ -58,24 +58,35 @@ class GradHandover:
 
     def __init__(self):
         self.scale_a = self.scale_b = None
-        self.raw_ptrs = None
+        self.raws = None
+        self.versions = None
 
     def post(self, raws, scale_a: torch.Tensor, scale_b: torch.Tensor) -> None:
-        self.raw_ptrs, self.scale_a, self.scale_b = tuple(r.data_ptr() for r in raws), scale_a, scale_b
+        # The mailbox keeps the raw tensors THEMSELVES, not their addresses: while it holds a reference autograd cannot
+        # accumulate a second gradient into one of them in place (its input buffer does `old.add_(new)` only when it is the
+        # sole owner, which it would be -- the loss node's saved variables are released by then -- and the address would not
+        # change), so a gradient that was summed with others arrives as a NEW tensor and take() sees it.  The version counters
+        # catch any other in-place update.
+        self.raws, self.versions = tuple(raws), tuple(r._version for r in raws)
+        self.scale_a, self.scale_b = scale_a, scale_b
 
     def take(self, grads):
         """-> (scale_a, scale_b) for the incoming gradients `grads` (tuple, in post order); (None, None) when nothing was
         posted, i.e. the gradients are ordinary ones."""
-        if self.raw_ptrs is None:
+        if self.raws is None:
             return None, None
-        ok = len(grads) == len(self.raw_ptrs) and all(g is not None and g.data_ptr() == p for g, p in zip(grads, self.raw_ptrs))
+        ok = len(grads) == len(self.raws) and all(
+            g is not None and g.data_ptr() == r.data_ptr() and g.shape == r.shape and g._version == v and r._version == v
+            for g, r, v in zip(grads, self.raws, self.versions))
+        raws, self.raws, self.versions = self.raws, None, None
         if not ok:
+            self.scale_a = self.scale_b = None
             raise RuntimeError("a tensor reserved for photometric_loss (DepthNet.forward_pair_split's third output, or "
                                "PoseNet's outputs) was also used elsewhere: its gradient arrived summed with others, which "
                                "the deferred normalisation cannot undo; route other uses through an ordinary tensor "
                                "(e.g. `pose * 1`) so that the loss takes its general path")
         a, b = self.scale_a, self.scale_b
-        self.raw_ptrs = self.scale_a = self.scale_b = None
+        self.scale_a = self.scale_b = None
         return a, b
 
 

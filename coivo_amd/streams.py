@@ -1,0 +1,133 @@
+"""Stream / hardware-queue policy of the training step: ONE place that decides how many library-owned side streams
+`colvo_run_commands` may use, from who else drives hardware queues in this process.
+
+Why a policy at all (measured on MI355X, ROCm 7.2): the step runs its input-gradient chain
+on the caller's stream and the weight gradients on one or two side streams.  With FOUR or more hardware queues active and
+cross-queue dependencies between them the runtime serialises the backward pass (1.5 ms -> 4-5 ms per step).  The budget is
+therefore three active queues: main + side + ONE more -- the library's auxiliary side stream when nobody else needs it, or an
+external party's stream: RCCL's communicator stream (ddp.GradBuckets), a loader's copy stream (data.PairLoader).
+
+    claim = streams.claim_external_queue("rccl")   # the auxiliary stream is switched off while any claim is held
+    ...
+    claim.release()                                # the last release switches it back on
+
+Two environment facts are read once (they bind at HIP initialisation, before this module can change them):
+  * GPU_MAX_HW_QUEUES <= 2 folds every stream onto two hardware queues: extra streams are harmless and claims change nothing;
+  * data parallel (WORLD_SIZE > 1) needs GPU_MAX_HW_QUEUES >= 8, otherwise the side stream lands on the main stream's queue
+    once the communicator exists: `check_environment()` raises instead of letting the step run 25 % slower.
+"""
+from __future__ import annotations
+
+import os
+import threading
+from typing import Dict, Optional
+
+_DEFAULT_AUX = 3            # library default: up to MAX_AUX, the effective number is min(COLVO_SIDE_STREAMS - 1, this)
+_lock = threading.Lock()
+_claims: Dict[int, str] = {}
+_next_id = 0
+_base_aux = _DEFAULT_AUX    # what configure() asked for when no external queue is claimed
+
+
+def hw_queue_limit(env=None) -> Optional[int]:
+    """GPU_MAX_HW_QUEUES as the HIP runtime read it at initialisation (None: unset = the runtime's default of 4)."""
+    v = (os.environ if env is None else env).get("GPU_MAX_HW_QUEUES")
+    try:
+        return int(v) if v is not None else None
+    except ValueError:
+        return None
+
+
+def folded(env=None) -> bool:
+    """True when the runtime folds all streams onto <= 2 hardware queues (extra streams then cost nothing)."""
+    q = hw_queue_limit(env)
+    return q is not None and q <= 2
+
+
+def _apply() -> int:
+    n = _base_aux if (not _claims or folded()) else 0
+    from . import _lib
+    _lib.check(_lib.load().colvo_set_aux_side_streams(n), "colvo_set_aux_side_streams")
+    return n
+
+
+def configure(n_external_queues: int = 0, aux_side_streams: int = _DEFAULT_AUX) -> int:
+    """Explicit form for hosts that drive streams of their own without going through GradBuckets / PairLoader: declare how
+    many hardware queues OTHER than the step's main and side stream the process keeps busy.  Returns the number of auxiliary
+    side streams colvo_run_commands may use from now on.  Replaces every earlier claim."""
+    global _base_aux, _next_id
+    if n_external_queues < 0 or aux_side_streams < 0:
+        raise ValueError("streams.configure: counts must be >= 0")
+    with _lock:
+        _claims.clear()
+        _base_aux = aux_side_streams
+        for _ in range(n_external_queues):
+            _claims[_next_id] = "configured"
+            _next_id += 1
+        return _apply()
+
+
+class QueueClaim:
+    """One external hardware queue in use; release() (idempotent, also on garbage collection) gives it back."""
+
+    def __init__(self, cid: int, who: str):
+        self._cid, self.who = cid, who
+
+    def release(self) -> None:
+        cid, self._cid = self._cid, None
+        if cid is None:
+            return
+        with _lock:
+            if _claims.pop(cid, None) is not None:
+                try:
+                    _apply()
+                except Exception:           # noqa: BLE001 -- interpreter shutdown: the library may be gone
+                    pass
+
+    def __del__(self):
+        self.release()
+
+
+def claim_external_queue(who: str) -> QueueClaim:
+    global _next_id
+    with _lock:
+        cid = _next_id
+        _next_id += 1
+        _claims[cid] = who
+        _apply()
+    return QueueClaim(cid, who)
+
+
+def external_queues() -> int:
+    with _lock:
+        return len(_claims)
+
+
+def aux_side_streams() -> int:
+    """The limit currently handed to the library."""
+    with _lock:
+        return _base_aux if (not _claims or folded()) else 0
+
+
+def reset() -> None:
+    """Drop every claim and restore the library default (tests)."""
+    configure(0, _DEFAULT_AUX)
+
+
+def check_environment(world_size: int, env=None) -> None:
+    """Raise when this process is a data-parallel rank whose HIP runtime was initialised with fewer than 8 hardware queues."""
+    if world_size <= 1:
+        return
+    q = hw_queue_limit(env)
+    if q is None or q < 8:
+        raise RuntimeError(
+            f"data parallel (world size {world_size}) needs GPU_MAX_HW_QUEUES >= 8 in the environment BEFORE the process "
+            f"initialises HIP (found {'unset = 4' if q is None else q}): with fewer the weight-gradient side stream shares a "
+            "hardware queue with the main stream once the RCCL communicator exists and the backward pass serialises "
+            "(measured 1.96 ms per step against 1.68); export it in the launcher, as bench.py does")
+
+
+def multi_stream_capture_allowed(env=None) -> bool:
+    """A hipGraph capture that spans the main AND the side stream under GPU_MAX_HW_QUEUES <= 2 aborted the runtime in round 2
+    (the log was not kept, the cause is unknown): refuse that combination."""
+    return not folded(env)

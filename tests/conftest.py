@@ -29,12 +29,12 @@ def _ensure_library_built():
 
 
 @pytest.fixture(autouse=True)
-def _restore_aux_stream_limit(request):
-    """data.PairLoader and ddp.GradBuckets switch the library's auxiliary side stream off for the process
-    (colvo_set_aux_side_streams(0): they bring a third hardware queue of their own).  Tests share one process: put the default
-    back after each GPU test so that the ones that follow still exercise the two-side-stream schedule."""
+def _restore_stream_policy(request):
+    """data.PairLoader and ddp.GradBuckets claim a hardware queue from the stream policy (coivo_amd/streams.py), which switches
+    the library's auxiliary side stream off while a claim is held.  Tests share one process: drop whatever a test left claimed
+    so that the ones that follow still exercise the two-side-stream schedule."""
     yield
     if request.node.get_closest_marker("gpu") is not None:
-        from coivo_amd import _lib
+        from coivo_amd import _lib, streams
         if _lib._lib is not None:
-            _lib._lib.colvo_set_aux_side_streams(3)
+            streams.reset()

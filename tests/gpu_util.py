@@ -56,22 +56,26 @@ def grad_parity_table(named_hip, named_o32, named_o64, out_path=None):
 
 
 # SPEC.md §7: the yardstick for a parameter gradient is the fp64 evaluation of the spec.  These are heavily cancelling
-# sums: the fp32 ORACLE itself sits up to a few 1e-3 (of a tensor's largest element) away from it, more on some layers
-# than on others and more at batch 1 than at batch 8 -- which implementation is closer varies per layer.  A gradient
-# passes when its error is at most GRAD_K x the fp32 oracle's error on the same tensor, or within what the fp32 oracle
-# shows on its own worst tensor of this step (floors: GRAD_L2_FLOOR relative L2, GRAD_MAX_FLOOR x the largest element).
-# The floors are what the HIP path's fp32 summation order delivers: its weight gradients are sequential fp32 MFMA chains
-# over a pixel range, combined by fp32 atomics (measured worst tensors: 1.4e-3 / 2.4e-3 at B=2 64x96, 1.2e-3 / 3.0e-3 at
-# B=1 256x320, 6e-4 / 1.2e-3 at B=8 256x320 -- while torch's CPU conv backward reaches 3e-6 on the small case).
-GRAD_K, GRAD_L2_FLOOR, GRAD_MAX_FLOOR = 3.0, 2.5e-3, 5e-3
+# sums, so the fp32 ORACLE itself sits some way from it -- 2e-6 (relative L2) at B=2 64x96, 5e-4 at B=8 256x320, 2e-3 at
+# B=1 256x320 -- and that distance, measured in the same step, is the only scale the bar uses: there is NO absolute floor.
+# A gradient tensor passes when
+#   * its relative L2 error is at most GRAD_K x the fp32 oracle's on the same tensor, or at most the fp32 oracle's own
+#     worst tensor of this step; and
+#   * its largest element error (relative to the tensor's largest element) is at most GRAD_K x the fp32 oracle's on the same
+#     tensor, or at most GRAD_MAX_SLACK x the fp32 oracle's worst tensor of this step (the maximum over up to 2.4 M elements
+#     is an extreme-value statistic: two fp32 summation orders differ by more in it than in the L2 norm).
+# Round-3 tables of the final round-2 build (gpurun_out/grad_parity_*.txt): HIP / fp32-oracle worst tensors 2.1e-6 / 1.6e-6
+# (B=2 64x96), 7.8e-4 / 4.9e-4 (configs[1]), 2.0e-3 / 1.9e-3 (B=1 256x320); a gradient 3x worse than the oracle's own
+# rounding noise fails at every shape.
+GRAD_K, GRAD_MAX_SLACK = 3.0, 2.0
 
 
 def grad_parity_failures(rows):
-    worst_l2 = max([GRAD_L2_FLOOR] + [r[6] for r in rows])
-    worst_max = max([GRAD_MAX_FLOOR] + [r[4] / r[2] for r in rows])
+    worst_l2 = max(r[6] for r in rows)
+    worst_max = max(r[4] / r[2] for r in rows)
     bad = []
     for name, n, scale, eh, eo, lh, lo in rows:
-        if lh > max(GRAD_K * lo, worst_l2) or eh > max(GRAD_K * eo, worst_max * scale):
+        if lh > max(GRAD_K * lo, worst_l2) or eh > max(GRAD_K * eo, GRAD_MAX_SLACK * worst_max * scale):
             bad.append(f"{name}: relL2 hip {lh:.3e} vs o32 {lo:.3e} (worst o32 {worst_l2:.3e}); max err/scale hip "
                        f"{eh / scale:.3e} vs o32 {eo / scale:.3e} (worst o32 {worst_max:.3e})")
     return bad

@@ -24,6 +24,7 @@ def test_plan_single_gpu_defaults():
     import bench
     a = _args([])
     assert (a.gpus, a.batch_per_gpu, a.height, a.width, a.dtype) == (1, 8, 256, 320, "bf16")
+    assert a.config_id == "1" and a.graph == "auto" and not a.custom_shape and not a.spec_calls
     p = bench.plan_distributed(a, {})
     assert p["world"] == 1 and p["backend"] is None and p["device"] == ("cuda", 0) and p["global_batch"] == 8
     assert p["grad_transport"] is None
@@ -38,13 +39,69 @@ def test_plan_rccl_branch(n):
     p = bench.plan_distributed(a, env)
     assert p["backend"] == "nccl" and p["world"] == n and p["rank"] == n - 1
     assert p["device"] == ("cuda", n - 1) and p["init_kwargs"] == {"rank": n - 1, "world_size": n, "device_id": ("cuda", n - 1)}
-    assert p["global_batch"] == 8 * n and p["seed"] == 1234 + n - 1 and p["grad_transport"] == "bf16"
+    # N > 1 defaults to BASELINE configs[3]: 32 pairs per GPU (batch 256 on 8 GPUs), 320x256
+    assert a.config_id == "3" and (a.batch_per_gpu, a.height, a.width) == (32, 256, 320)
+    assert p["global_batch"] == 32 * n and p["seed"] == 1234 + n - 1 and p["grad_transport"] == "bf16"
     # the keyword set init_process_group accepts
     import inspect
     import torch.distributed as dist
     sig = inspect.signature(dist.init_process_group)
     for k in p["init_kwargs"]:
         assert k in sig.parameters, k
+
+
+def test_baseline_configs_map_to_bench_flags():
+    """BASELINE.json configs[1..4] -> what bench.py runs (per-GPU pairs, shape, gradient transport, hipGraph)."""
+    import bench
+    a = _args(["--gpus", "8"])
+    assert (a.config_id, a.batch_per_gpu, a.grad_transport, a.graph) == ("3", 32, "f32", "auto")
+    assert bench.plan_distributed(a, {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "8"})["global_batch"] == 256
+    a = _args(["--gpus", "8", "--config", "4"])
+    assert (a.batch_per_gpu, a.grad_transport, a.graph) == (64, "bf16", "on")
+    assert bench.plan_distributed(a, {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8"})["global_batch"] == 512
+    a = _args(["--config", "3"])                       # the scaling denominator: 32 pairs on ONE GPU
+    assert (a.gpus, a.batch_per_gpu) == (1, 32) and "configs[3]" in bench.workload_name(a, 32, 256, 320)
+    a = _args(["--config", "2"])
+    assert (a.batch_per_gpu, a.height, a.width) == (32, 512, 640)
+    a = _args(["--gpus", "2", "--batch-per-gpu", "8"])  # explicit flags win and are reported as a custom shape
+    assert a.batch_per_gpu == 8 and a.custom_shape and bench.workload_name(a, 8, 256, 320).startswith("custom shape")
+    a = _args(["--config", "4", "--graph", "off", "--grad-transport", "f32"])
+    assert (a.graph, a.grad_transport) == ("off", "f32")
+
+
+def test_stream_policy_environment_check():
+    """coivo_amd/streams.py: a data-parallel rank refuses to start with fewer than 8 hardware queues; <= 2 queues fold every
+    stream onto two queues (extra streams are harmless, multi-stream graph capture is refused)."""
+    from coivo_amd import streams
+    streams.check_environment(1, {})
+    streams.check_environment(8, {"GPU_MAX_HW_QUEUES": "8"})
+    for env in ({}, {"GPU_MAX_HW_QUEUES": "4"}, {"GPU_MAX_HW_QUEUES": "2"}):
+        with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES"):
+            streams.check_environment(8, env)
+    assert streams.folded({"GPU_MAX_HW_QUEUES": "2"}) and not streams.folded({}) and not streams.folded({"GPU_MAX_HW_QUEUES": "8"})
+    assert not streams.multi_stream_capture_allowed({"GPU_MAX_HW_QUEUES": "2"}) and streams.multi_stream_capture_allowed({})
+
+
+def test_stream_policy_claims(monkeypatch):
+    """Claims switch the library's auxiliary side stream off, the last release switches it back on (the call into the library
+    only stores a number: no GPU needed)."""
+    from coivo_amd import streams
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    streams.reset()
+    assert streams.aux_side_streams() == 3 and streams.external_queues() == 0
+    c1 = streams.claim_external_queue("rccl")
+    c2 = streams.claim_external_queue("loader")
+    assert streams.aux_side_streams() == 0 and streams.external_queues() == 2
+    c1.release(); c1.release()
+    assert streams.aux_side_streams() == 0
+    c2.release()
+    assert streams.aux_side_streams() == 3 and streams.external_queues() == 0
+    assert streams.configure(1) == 0 and streams.configure(0) == 3
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    c = streams.claim_external_queue("x")
+    assert streams.aux_side_streams() == 3          # folded onto two queues: the claim changes nothing
+    c.release()
+    streams.reset()
 
 
 def test_plan_rejects_mismatched_launch():
@@ -59,6 +116,7 @@ def test_json_contract_keys_are_built():
     """The keys the driver parses are all present in the dictionary bench.py assembles (static check of the source)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     for k in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"', '"higher_is_better"',
-              '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+              '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"',
+              '"single_gpu_same_batch"', '"spec_sequence_ms"', '"frac_real_bytes"'):
         assert k in src, k
     assert json.dumps({"ok": True})

@@ -77,7 +77,8 @@ def test_golden_net_fixture(golden_dir, name):
     loss.backward()
     # EVERY parameter gradient against its digest in the fixture (oracle/make_golden.py grad_digest: a strided sample
     # from the fp32 oracle and from its fp64 evaluation, plus [sum, L2 norm, max|.|] of the fp64 gradient).  Bar
-    # (SPEC.md §7): as close to the fp64 truth as the fp32 oracle is (x4), floor 1e-3 of the largest element.
+    # (SPEC.md §7, tests/gpu_util.py): the fp32 oracle's own distance from the fp64 truth in this very step is the scale;
+    # no absolute floor.
     from oracle.make_golden import grad_digest
     n_checked, rows, bad = 0, [], []
     for tag, net in (("depth", dn), ("pose", pn)):
@@ -90,7 +91,10 @@ def test_golden_net_fixture(golden_dir, name):
             sn = max(s64.norm().item(), 1e-30)
             rows.append((f"{tag}.{pname}", smp.numel(), scale, (smp.double() - s64).abs().max().item(),
                          (s32 - s64).abs().max().item(), (smp.double() - s64).norm().item() / sn, (s32 - s64).norm().item() / sn))
-            if abs(nrm[1].item() - n64[1].item()) > 2e-3 * n64[1].item() + 1e-12:
+            # whole-tensor L2 norm: the sampled fp32-oracle error bounds what rounding does to it (x GRAD_K, and never
+            # looser than 5e-5 relative -- these two fixtures sit at ~2e-6)
+            o32_rel = (s32 - s64).norm().item() / sn
+            if abs(nrm[1].item() - n64[1].item()) > min(5e-5, max(3.0 * o32_rel, 1e-6)) * n64[1].item() + 1e-12:
                 bad.append(f"{tag}.{pname}: L2 norm {nrm[1].item():.6e} vs {n64[1].item():.6e}")
             n_checked += 1
     bad += grad_parity_failures(rows)

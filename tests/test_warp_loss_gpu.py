@@ -207,3 +207,30 @@ def test_deferred_normalisation_handover():
     graw = torch.autograd.grad(loss, leaves)[0]
     with pytest.raises(RuntimeError):
         hand.take((graw + 0.0,))
+
+
+def test_handover_refuses_second_use_created_before_the_loss():
+    """d_l (forward_pair_split's third output) used in a second term that was created BEFORE the loss.  The loss node
+    runs first in backward, so its raw gradient is the first arrival in the producer's input buffer -- where autograd would add
+    the second gradient IN PLACE (same address) if the mailbox did not hold the raw tensor.  Must raise, never scale (raw + other)."""
+    from coivo_amd import functional as Fh
+    from coivo_amd import nn as hnn
+    from coivo_amd import synth
+    dn, pn = hnn.DepthNet(compute_dtype=torch.float32), hnn.PoseNet(compute_dtype=torch.float32)
+    d = to_dev(synth.make_batch(1, 32, 64, seed=5))
+    frames = torch.cat([d["tgt"], d["ref"]])
+    d_t, d_r, d_l = dn.forward_pair_split(frames)
+    extra = (d_l * d_l).mean()
+    pose, a, b = pn(d["tgt"], d["ref"], d_t, d_r)
+    loss = Fh.photometric_loss(d["tgt"], d["ref"], d_l, pose, d["K"], a, b)
+    with pytest.raises(RuntimeError, match="reserved for photometric_loss"):
+        (loss + extra).backward()
+    torch.cuda.synchronize()
+    # the networks stay usable: the ordinary route (a plain tensor for the second use) gives finite gradients
+    dn.zero_grad(); pn.zero_grad()
+    d_t, d_r, d_l = dn.forward_pair_split(frames)
+    pose, a, b = pn(d["tgt"], d["ref"], d_t, d_r)
+    loss = Fh.photometric_loss(d["tgt"], d["ref"], d_l, pose, d["K"], a, b) + (d_t * d_t).mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(dn.flat_grad).all() and dn.flat_grad.abs().max() > 0

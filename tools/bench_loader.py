@@ -43,9 +43,9 @@ def main():
         ld = PairLoader(ds, B, (256, 320), shuffle=True, workers=workers, prefetch=prefetch,
                         own_copy_stream={None: None, "0": False, "1": True}[os.environ.get("OWN_COPY_STREAM")],
                         decoders=int(os.environ.get("DECODERS", "0")))
-        if os.environ.get("KEEP_AUX"):       # probe: undo the loader's colvo_set_aux_side_streams(0)
-            from coivo_amd import _lib
-            _lib.load().colvo_set_aux_side_streams(3)
+        if os.environ.get("KEEP_AUX"):       # probe: keep the auxiliary side stream although the loader claimed a queue
+            from coivo_amd import streams
+            streams.configure(0)
         step = None
         if train:
             from coivo_amd import functional as Fh, nn as hnn
