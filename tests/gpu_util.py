@@ -79,3 +79,83 @@ def grad_parity_failures(rows):
             bad.append(f"{name}: relL2 hip {lh:.3e} vs o32 {lo:.3e} (worst o32 {worst_l2:.3e}); max err/scale hip "
                        f"{eh / scale:.3e} vs o32 {eo / scale:.3e} (worst o32 {worst_max:.3e})")
     return bad
+
+
+# ---------------------------------------------------------------------------------------------------------------------- #
+# Matched ReLU decisions.                                                                                                  #
+# A ReLU whose pre-activation lies within rounding distance of zero is decided by the summation order: the HIP kernels and  #
+# torch's CPU conv (and the fp32 and fp64 oracle between themselves) may disagree on it, and ONE such element moves every    #
+# upstream parameter gradient by ~1e-3 at B=2 64x96 -- a thousand times the rounding noise of everything else (round 3:      #
+# tests/golden/net_b2_64x96, pre-activation 4.5e-7 in `up1`; profiles/r3_relu_flip.md).  At 256x320 there are hundreds of    #
+# them, which is what the fp32 oracle's own 5e-4 ... 2e-3 distance from its fp64 evaluation consists of.  Gradient parity    #
+# is therefore judged against oracles whose ReLU decisions are FORCED to the HIP path's wherever they differ -- allowed only #
+# where the oracle's own pre-activation is below RELU_MARGIN in magnitude, anything larger is a genuine forward mismatch     #
+# and fails.  With the decisions matched all three evaluations differ by rounding only.                                      #
+# ---------------------------------------------------------------------------------------------------------------------- #
+RELU_MARGIN = 1e-5
+
+
+def hip_relu_masks(dn, pn):
+    """{'depth.enc1a': bool [2B,C,h,w], ..., 'pose.conv7': ...}: which activations of the LAST recorded forward of the two
+    HIP networks are positive (read from the persistent activation buffers of the recorded passes: call right after the step)."""
+    masks = {}
+    for tag, net in (("depth", dn), ("pose", pn)):
+        pools = [p for p in net._insts.values() if p]
+        assert len(pools) == 1 and pools[0], "expected exactly one recorded shape (and COLVO_NO_PROGRAM unset)"
+        A = pools[0][-1].passes["fwd"][1]
+        for k, t in A.items():
+            if k == "in":
+                continue
+            name = k if isinstance(k, str) else f"conv{k}"
+            masks[f"{tag}.{name}"] = (t.float().permute(0, 3, 1, 2) > 0).cpu()
+    return masks
+
+
+def oracle_step(seed, batch, dtype=torch.float32, masks=None, weights_seed=None):
+    """The oracle's coupled step (spec init `weights_seed`, default = seed) in `dtype`; with `masks` the ReLU decisions are
+    forced to them.  -> dict(loss, d_t, d_r, pose, a, b, grads [(name, tensor)], flips, flip_worst)."""
+    from oracle import colvo_spec as S
+    dn, pn = S.make_models(seed if weights_seed is None else weights_seed, dtype=dtype)
+    stats = {"flips": 0, "worst": 0.0}
+    if masks is not None:
+        for tag, net in (("depth", dn), ("pose", pn)):
+            for name, mod in net.named_children():
+                m = masks.get(f"{tag}.{name}")
+                if m is None:
+                    continue
+
+                def hook(mod, inp, out, m=m):
+                    flip = (out > 0) != m
+                    n = int(flip.sum())
+                    if not n:
+                        return None
+                    stats["flips"] += n
+                    stats["worst"] = max(stats["worst"], out[flip].abs().max().item())
+                    o = out.detach()
+                    # -o has the other sign (exactly); an exact zero becomes +-1e-30.  Added as a CONSTANT: the gradient still
+                    # flows through the element, the ReLU behind it now takes the HIP path's decision
+                    delta = torch.where(o == 0, torch.where(m, torch.full_like(o, 1e-30), torch.full_like(o, -1e-30)), -2 * o)
+                    return out + torch.where(flip, delta, torch.zeros_like(o))
+                mod.register_forward_hook(hook)
+    t = lambda v: v.to(dtype)
+    loss, d_t, d_r, pose, a, b = S.dcdp_forward(dn, pn, t(batch["tgt"]), t(batch["ref"]), t(batch["K"]))
+    loss.backward()
+    grads = [("depth." + n, p.grad) for n, p in dn.named_parameters()] + [("pose." + n, p.grad) for n, p in pn.named_parameters()]
+    return dict(loss=loss.item(), d_t=d_t.detach(), d_r=d_r.detach(), pose=pose.detach(), a=a.detach(), b=b.detach(),
+                grads=grads, flips=stats["flips"], flip_worst=stats["worst"])
+
+
+def matched_grad_rows(seed, batch, dn, pn, out_path=None, weights_seed=None):
+    """Gradient parity rows (grad_parity_table) of the HIP networks' current .grad against the fp32 / fp64 oracle evaluated at
+    the HIP path's ReLU decisions.  Asserts that decisions were only ever forced at marginal pre-activations."""
+    masks = hip_relu_masks(dn, pn)
+    o32 = oracle_step(seed, batch, torch.float32, masks, weights_seed)
+    o64 = oracle_step(seed, batch, torch.float64, masks, weights_seed)
+    for tag, o in (("fp32", o32), ("fp64", o64)):
+        assert o["flip_worst"] < RELU_MARGIN, \
+            f"a HIP activation has the other sign than the {tag} oracle's pre-activation of magnitude {o['flip_worst']:.3e}: " \
+            f"not a rounding-distance ReLU decision but a forward mismatch"
+    print(f"matched ReLU decisions: {o32['flips']} forced in the fp32 oracle (largest |pre| {o32['flip_worst']:.2e}), "
+          f"{o64['flips']} in the fp64 oracle ({o64['flip_worst']:.2e})")
+    hip = [("depth." + n, p.grad) for n, p in dn.named_parameters()] + [("pose." + n, p.grad) for n, p in pn.named_parameters()]
+    return grad_parity_table(hip, o32["grads"], o64["grads"], out_path), o32, o64
