@@ -71,9 +71,12 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: all ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks on one device)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from one captured hipGraph; auto = off: measured 2.94 ms replayed vs 2.69 ms eager at "
-                         "B=8 (the step is bound by per-kernel latency, not by the host, and replay loses part of the "
-                         "two-stream overlap)")
+                    help="replay the step from one captured hipGraph (coivo_amd/graph.py); auto = the configuration's setting: on "
+                         "for configs[4], off otherwise")
+    ap.add_argument("--graph-policy", type=int, choices=[0, 1, 2, 3], default=2,
+                    help="how the weight-gradient chain hangs off the main chain in the graph (include/colvo.h "
+                         "colvo_set_capture_policy): 0 one branch, 1 one edge per layer, 2 segments of --graph-group commands")
+    ap.add_argument("--graph-group", type=int, default=2)
     return resolve_config(ap.parse_args())
 
 
@@ -339,7 +342,8 @@ def main():
     if args.graph == "on":
         from coivo_amd.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(dn, pn, opt, B, H, W, ddp=ddp)
+            graphed = GraphedTrainStep(dn, pn, opt, B, H, W, ddp=ddp, capture_policy=args.graph_policy,
+                                       capture_group=args.graph_group)
             graphed.frames.copy_(frames)
             graphed.K.copy_(K)
             graphed.capture()
@@ -514,7 +518,9 @@ def main():
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},
-               "final_loss": final_loss, "hipgraph": use_graph, "roofline": roof}
+               "final_loss": final_loss, "hipgraph": use_graph,
+               "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group} if use_graph else None),
+               "roofline": roof}
         out.update(side)
         if not args.spec_calls and "spec_sequence_ms" in side:
             out["spec_sequence_value"] = world * B / (side["spec_sequence_ms"] * 1e-3)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -77,6 +77,7 @@ SIGNATURES = {
     "colvo_stitch_point_cloud": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
     "colvo_set_aux_side_streams": (_i, [_i]),
+    "colvo_set_capture_policy": (_i, [_i, _i]),
 }
 
 _lib = None

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -76,15 +77,176 @@ extern "C" int colvo_set_aux_side_streams(int n) {
     return 0;
 }
 
+// one recorded command on stream `s` (FORK / JOIN are handled by the callers)
+static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
+    switch (c.op) {
+        case COLVO_CMD_CONV_FWD:
+            return colvo_conv_fwd(&c.desc, c.p[0], c.p[1], c.p[2], (const float*)c.p[3], (void*)c.p[4], s);
+        case COLVO_CMD_CONV_DGRAD:
+            return colvo_conv_dgrad(&c.desc, c.i[0], c.p[0], c.p[1], c.p[2], (void*)c.p[3], c.i[1], s);
+        case COLVO_CMD_CONV_DGRAD_BOTH:
+            return colvo_conv_dgrad_both(&c.desc, c.p[0], c.p[1], c.p[2], c.p[3], (void*)c.p[4], (void*)c.p[5], s);
+        case COLVO_CMD_CONV_WGRAD:
+            return colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
+        case COLVO_CMD_PACK_NCHW: {
+            const float* src[4] = {(const float*)c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3]};
+            return colvo_pack_nchw(c.i[0], src, &c.i[1], c.i[5], c.i[6], c.i[7], c.i[8], c.i[9], (void*)c.p[4], s);
+        }
+        case COLVO_CMD_UNPACK_NHWC_GRAD:
+            return colvo_unpack_nhwc_grad(c.i[0], c.p[0], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5], c.i[6], (float*)c.p[1], c.i[7], s);
+        case COLVO_CMD_DEPTH_HEAD_FWD:
+            return colvo_depth_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3], c.i[4],
+                                        c.f[0], c.f[1], (float*)c.p[3], s);
+        case COLVO_CMD_DEPTH_HEAD_BWD:
+            return colvo_depth_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3], c.i[1],
+                                        c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[4], (void*)c.p[5], (float*)c.p[6],
+                                        (float*)c.p[7], s);
+        case COLVO_CMD_DEPTH_HEAD_BWD_PARTS:
+            return colvo_depth_head_bwd_parts(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
+                                              (const float*)c.p[4], (const float*)c.p[5], (const float*)c.p[6], (const float*)c.p[7],
+                                              c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[8], (void*)c.p[9], nullptr,
+                                              nullptr, s);
+        case COLVO_CMD_DEPTH_HEAD_WGRAD:
+            return colvo_depth_head_wgrad(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4], (float*)c.p[2],
+                                          (float*)c.p[3], s);
+        case COLVO_CMD_POSE_HEAD_FWD:
+            return colvo_pose_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3], c.f[0],
+                                       c.f[1], (float*)c.p[3], s);
+        case COLVO_CMD_POSE_HEAD_BWD:
+            return colvo_pose_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
+                                       (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2], c.i[3],
+                                       c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
+        default:
+            set_error("colvo_run_commands: unknown op %d in command %d", c.op, k);
+            return (int)hipErrorInvalidValue;
+    }
+}
+
+// ---- hipGraph form ------------------------------------------------------------------------------------------------------------ //
+// While `main_stream` is being captured (hipStreamBeginCapture -- torch.cuda.graph) the command list is turned into graph nodes with
+// EXPLICIT dependencies on that ONE capturing stream: no side stream, no events.  hipStreamGetCaptureInfo_v2 reads the dependency
+// set the next captured node would get, hipStreamUpdateCaptureDependencies replaces it.  The main-stream commands form one chain;
+// the side-stream commands (weight gradients) form a second chain whose segments hang off the main chain:
+//   policy 0 (serial):  one branch -- side commands are captured in list order on the main chain;
+//   policy 1 (fine):    every FORK is an edge main -> side (the eager schedule, node for node);
+//   policy 2 (grouped): side commands are collected and flushed `group` at a time; a flushed segment depends on the main chain
+//                       AS FAR AS IT HAS BEEN CAPTURED at the flush and on the previous side segment -- few cross-branch edges,
+//                       the weight gradients of one segment run beside the input-gradient chain that follows it;
+//   policy 3:           policy 2 with the segments alternating between TWO side chains (the eager schedule's auxiliary stream).
+// (ROCm 7.2 replays a graph's branches on streams of its own; every cross-branch edge costs a marker with a signal -- the
+// two-stream capture of round 2, one edge per layer, replayed 2.4 x slower than eager.)  Each call ends joined: the next captured
+// node depends on both chains.  Commands are re-ordered only within what the eager schedule already allows: a side command never
+// runs before the main-chain node it was forked from, nothing but the join depends on it, and every buffer it reads is private to
+// its recorded pass (coivo_amd/program.py keeps them alive for the life of the program).
+static std::atomic<int> g_capture_policy{2};
+static std::atomic<int> g_capture_group{2};
+
+struct CaptureTail {
+    std::vector<hipGraphNode_t> nodes;
+    int get(hipStream_t s) {
+        hipStreamCaptureStatus st;
+        const hipGraphNode_t* deps = nullptr;
+        size_t n = 0;
+        hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, nullptr, nullptr, &deps, &n);
+        if (e != hipSuccess || st != hipStreamCaptureStatusActive) {
+            set_error("colvo_run_commands: hipStreamGetCaptureInfo_v2 failed under capture: %s", hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : (int)hipErrorIllegalState;
+        }
+        nodes.assign(deps, deps + n);
+        return 0;
+    }
+    int set(hipStream_t s) {
+        hipError_t e = hipStreamUpdateCaptureDependencies(s, nodes.data(), nodes.size(), hipStreamSetCaptureDependencies);
+        if (e != hipSuccess) set_error("colvo_run_commands: hipStreamUpdateCaptureDependencies failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    void merge(const CaptureTail& o) {
+        for (hipGraphNode_t n : o.nodes)
+            if (std::find(nodes.begin(), nodes.end(), n) == nodes.end()) nodes.push_back(n);
+    }
+};
+
+static int run_commands_captured(const ColvoCmd* cmds, int n, hipStream_t ms) {
+    const int policy = g_capture_policy.load(std::memory_order_relaxed);
+    const int group = std::max(1, g_capture_group.load(std::memory_order_relaxed));
+    const int nchains = policy == 3 ? 2 : 1;   // policy 3 = policy 2 with the segments alternating between TWO side chains
+    CaptureTail sides[2], fork_at, cur;
+    int seg = 0;
+    std::vector<int> pending;               // side commands not yet captured
+    // Capture the pending side commands as one segment of the side chain: it depends on `at` (a point of the main chain) and on the
+    // previous segment.  ORDER MATTERS: ROCm's graph executor keeps a node's FIRST child on the node's stream and opens a new
+    // stream for every further child, so a segment is captured AFTER the main command that follows its fork point -- the main
+    // chain then stays on one stream and the side chain (each segment the first child of the previous one) on a second.  Captured
+    // the other way round every fork moved the main chain to a fresh stream: four or more hardware queues, the serialised
+    // mode of DESIGN.md section 3.4 (profiles/r3_graph_replay.md).
+    auto flush = [&](const CaptureTail& at) -> int {
+        if (pending.empty()) return 0;
+        if (int rc = cur.get(ms)) return rc;                    // the main chain as far as it has been captured
+        CaptureTail& side = sides[seg++ % nchains];
+        CaptureTail deps = at;
+        deps.merge(side);
+        if (int rc = deps.set(ms)) return rc;
+        for (int k : pending)
+            if (int rc = run_one(cmds[k], k, (colvo_stream_t)ms)) return rc;
+        pending.clear();
+        if (int rc = side.get(ms)) return rc;
+        return cur.set(ms);                                     // back on the main chain
+    };
+    for (int k = 0; k < n; ++k) {
+        const ColvoCmd& c = cmds[k];
+        if (c.op == COLVO_CMD_FORK) {
+            // policy 1: the side commands that follow depend on the main chain as it stands NOW (consecutive forks without a
+            // main command in between share the point)
+            if (policy == 1 && pending.empty()) { if (int rc = fork_at.get(ms)) return rc; }
+            continue;
+        }
+        if (c.op == COLVO_CMD_JOIN) {
+            if (policy == 0) continue;
+            if (policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }
+            if (int rc = flush(fork_at)) return rc;
+            if (int rc = cur.get(ms)) return rc;
+            for (CaptureTail& sd : sides) { cur.merge(sd); sd.nodes.clear(); }
+            if (int rc = cur.set(ms)) return rc;
+            continue;
+        }
+        if (c.stream == 1 && policy != 0) {
+            pending.push_back(k);
+            continue;
+        }
+        const bool due = !pending.empty() && (policy == 1 || (int)pending.size() >= group);
+        if (due && policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }   // every pending command's inputs exist by now
+        if (int rc = run_one(c, k, (colvo_stream_t)ms)) return rc;             // first child of the fork point: stays on its stream
+        if (due) { if (int rc = flush(fork_at)) return rc; }
+    }
+    if (policy != 0) {                      // the call ends joined
+        if (!pending.empty()) {
+            if (policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }
+            if (int rc = flush(fork_at)) return rc;
+        }
+        if (!sides[0].nodes.empty() || !sides[1].nodes.empty()) {
+            if (int rc = cur.get(ms)) return rc;
+            for (CaptureTail& sd : sides) cur.merge(sd);
+            if (int rc = cur.set(ms)) return rc;
+        }
+    }
+    return 0;
+}
+
+extern "C" int colvo_set_capture_policy(int policy, int group) {
+    COLVO_CHECK_ARG(policy >= 0 && policy <= 3 && group >= 1, "colvo_set_capture_policy: policy 0..3, group >= 1");
+    g_capture_policy.store(policy, std::memory_order_relaxed);
+    g_capture_group.store(group, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, colvo_stream_t side_stream) {
     COLVO_CHECK_ARG(cmds && n >= 0, "colvo_run_commands: bad arguments");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
-    int naux = 0;
-    if (ss) {
+    {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone)
-            naux = aux_streams();
+        if (hipStreamIsCapturing(ms, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return run_commands_captured(cmds, n, ms);
     }
+    const int naux = ss ? aux_streams() : 0;
     hipStream_t side_cur = ss;            // where stream-1 commands go until the next FORK
     int side_idx = 0;                     // 0: the caller's side stream, i > 0: g_aux[i - 1]
     bool aux_dirty[MAX_AUX] = {false, false, false};   // aux i holds work the caller's side stream has not been ordered after
@@ -95,55 +257,6 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
         if (c.stream && side_idx > 0) aux_dirty[side_idx - 1] = true;
         int rc = 0;
         switch (c.op) {
-            case COLVO_CMD_CONV_FWD:
-                rc = colvo_conv_fwd(&c.desc, c.p[0], c.p[1], c.p[2], (const float*)c.p[3], (void*)c.p[4], s);
-                break;
-            case COLVO_CMD_CONV_DGRAD:
-                rc = colvo_conv_dgrad(&c.desc, c.i[0], c.p[0], c.p[1], c.p[2], (void*)c.p[3], c.i[1], s);
-                break;
-            case COLVO_CMD_CONV_DGRAD_BOTH:
-                rc = colvo_conv_dgrad_both(&c.desc, c.p[0], c.p[1], c.p[2], c.p[3], (void*)c.p[4], (void*)c.p[5], s);
-                break;
-            case COLVO_CMD_CONV_WGRAD:
-                rc = colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
-                break;
-            case COLVO_CMD_PACK_NCHW: {
-                const float* src[4] = {(const float*)c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3]};
-                rc = colvo_pack_nchw(c.i[0], src, &c.i[1], c.i[5], c.i[6], c.i[7], c.i[8], c.i[9], (void*)c.p[4], s);
-                break;
-            }
-            case COLVO_CMD_UNPACK_NHWC_GRAD:
-                rc = colvo_unpack_nhwc_grad(c.i[0], c.p[0], c.i[1], c.i[2], c.i[3], c.i[4], c.i[5], c.i[6], (float*)c.p[1],
-                                            c.i[7], s);
-                break;
-            case COLVO_CMD_DEPTH_HEAD_FWD:
-                rc = colvo_depth_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3],
-                                          c.i[4], c.f[0], c.f[1], (float*)c.p[3], s);
-                break;
-            case COLVO_CMD_DEPTH_HEAD_BWD:
-                rc = colvo_depth_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
-                                          c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[4], (void*)c.p[5],
-                                          (float*)c.p[6], (float*)c.p[7], s);
-                break;
-            case COLVO_CMD_DEPTH_HEAD_BWD_PARTS:
-                rc = colvo_depth_head_bwd_parts(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
-                                                (const float*)c.p[4], (const float*)c.p[5], (const float*)c.p[6],
-                                                (const float*)c.p[7], c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1],
-                                                (float*)c.p[8], (void*)c.p[9], nullptr, nullptr, s);
-                break;
-            case COLVO_CMD_DEPTH_HEAD_WGRAD:
-                rc = colvo_depth_head_wgrad(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4],
-                                            (float*)c.p[2], (float*)c.p[3], s);
-                break;
-            case COLVO_CMD_POSE_HEAD_FWD:
-                rc = colvo_pose_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3],
-                                         c.f[0], c.f[1], (float*)c.p[3], s);
-                break;
-            case COLVO_CMD_POSE_HEAD_BWD:
-                rc = colvo_pose_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
-                                         (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2],
-                                         c.i[3], c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
-                break;
             case COLVO_CMD_FORK: {       // the side stream continues after everything enqueued so far on the main stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");
                 if (naux) { side_idx = (side_idx + 1) % (naux + 1); side_cur = side_idx ? g_aux[side_idx - 1] : ss; }
@@ -158,8 +271,7 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 break;
             }
             default:
-                set_error("colvo_run_commands: unknown op %d in command %d", c.op, k);
-                return (int)hipErrorInvalidValue;
+                rc = run_one(c, k, s);
         }
         if (rc != 0) return rc;   // the failing entry point has set the message
     }

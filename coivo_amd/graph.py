@@ -1,17 +1,19 @@
-"""hipGraph-captured DCDP training step (BASELINE configs[4]: "hipGraph-captured train step").
+"""hipGraph-captured DCDP training step (BASELINE configs[4]: "hipGraph-captured train step and bucketed all-reduce").
 
-Every entry point of libcolvo only enqueues on the given stream (no allocation, no sync, step counter and loss state on
-the device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused loss, backward with its weight-gradient
-side stream (fork/join by events), optional RCCL buckets, fused Adam -- can be captured once into a hipGraph
-(torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch: no host cost at all.
+Every entry point of libcolvo only enqueues on the given stream (no allocation, no sync, step counter and loss state on the
+device), so the whole step -- zero-grad, DepthNet + PoseNet forward, fused loss, backward, RCCL buckets, fused Adam -- is
+captured once (torch.cuda.CUDAGraph is the capture plumbing) and replayed as a single launch.
 
-Measured on MI355X (ROCm 7.2, round 2, gpurun_out/r2_graph_env*.log): a capture that contains the weight-gradient side
-stream (fork / join by events) replays in 4.2-4.4 ms per step -- 2.4 x the eager step -- whatever
-DEBUG_CLR_GRAPH_PACKET_CAPTURE / DEBUG_HIP_FORCE_GRAPH_QUEUES say, while a single-stream capture replays in 1.97 ms =
-the eager single-stream time (the step is GPU-bound: the host enqueues it in 1.15 ms through the recorded command
-lists of coivo_amd/program.py).  The graphed step is therefore captured WITHOUT the side stream (`overlap_wgrad` is
-switched off on the two networks while this object owns them); eager launches with the two-stream overlap (1.77 ms)
-stay bench.py's default and this class is the option for hosts that are otherwise busy.
+How the two-stream backward gets into the graph (round 3): NOT by capturing two streams.  While the stream is being captured,
+`colvo_run_commands` builds the graph natively from the recorded command lists: the main-stream commands become one chain of
+kernel nodes, the weight-gradient commands a second chain, tied together by explicit dependencies on the ONE capturing stream
+(hipStreamGetCaptureInfo_v2 / hipStreamUpdateCaptureDependencies; csrc/program.hip).  The policy decides how many cross-branch
+edges there are: ROCm 7.2 replays each branch on a stream of its own and pays for every edge between them -- round 2's
+two-stream capture (one edge per layer) replayed at 2.99 ms against 1.52 ms eager, a single branch at 1.71 ms.
+  capture_policy 0: one branch;  1: one edge per layer (the eager schedule);  2 (default): the weight gradients in segments of
+  `capture_group` commands, each hanging off the main chain as captured so far.
+The collectives of data parallelism (ddp.GradBuckets) are captured by stream capture as torch issues them (RCCL calls are
+capturable), behind the weight-gradient chain joined at that point.
 
 Inputs live in static device buffers (`frames` = [2B,3,H,W]: target frames then reference frames, `K`); the caller
 writes the next batch into them (or passes tensors to __call__, which copies) and replays.
@@ -27,12 +29,10 @@ from .functional import photometric_loss
 
 class GraphedTrainStep:
     def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
-                 warmup: int = 2):
+                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
-        for n in (depth_net, pose_net):          # single-stream capture (see the module docstring)
-            n.overlap_wgrad = False
-            n.clear_programs()
+        self.capture_policy, self.capture_group = int(capture_policy), int(capture_group)
         self.B, self.ssim_weight = B, ssim_weight
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
@@ -78,6 +78,8 @@ class GraphedTrainStep:
                     for k in st:
                         st[k].copy_(src[k])
         restore()
+        from . import _lib
+        _lib.check(_lib.load().colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = self._step()

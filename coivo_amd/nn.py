@@ -234,8 +234,12 @@ class _ArenaModule(nn.Module):
             # layer's kernels.  The first replay splits the program after EVERY layer and notes which hook calls launched
             # something (a hook that returns None is assumed to); later replays split only there and run the hooks of the
             # layers in between together, still in order.  A launch at an unexpected place re-arms the learning pass.
+            capturing = torch.cuda.is_current_stream_capturing()
+
             def call(L, on_side):
-                if on_side:
+                # (under hipGraph capture there is no side stream: colvo_run_commands has joined the weight-gradient chain at
+                # the end of the segment, the collective is captured behind it on the main stream)
+                if on_side and not capturing:
                     with torch.cuda.stream(self._side):
                         return self.grad_ready_hook(self, L.span[0], L.span[1])
                 return self.grad_ready_hook(self, L.span[0], L.span[1])
@@ -316,12 +320,12 @@ class _ArenaModule(nn.Module):
                 self._queue_join()
             elif self._rec is not None:
                 self._rec.join()
-            else:
+            elif not torch.cuda.is_current_stream_capturing():
                 self._main.wait_stream(self._side)
 
     def _queue_join(self) -> None:
         """Join the side stream when the running backward pass ends (falls back to joining now outside the engine)."""
-        if self._join_pending:
+        if self._join_pending or torch.cuda.is_current_stream_capturing():      # (a captured pass ends joined: program.hip)
             return
         self._join_pending = True
         main = torch.cuda.current_stream()
@@ -337,7 +341,7 @@ class _ArenaModule(nn.Module):
 
     def join_side(self) -> None:
         """Make the current stream wait for the weight gradients still running on this network's side stream."""
-        if self._join_pending and self._side is not None:
+        if self._join_pending and self._side is not None and not torch.cuda.is_current_stream_capturing():
             torch.cuda.current_stream().wait_stream(self._side)
         self._join_pending = False
 

@@ -23,7 +23,7 @@ import threading
 from typing import Dict, Optional
 
 _DEFAULT_AUX = 3            # library default: up to MAX_AUX, the effective number is min(COLVO_SIDE_STREAMS - 1, this)
-_lock = threading.Lock()
+_lock = threading.RLock()      # re-entrant: a QueueClaim collected while the lock is held releases itself
 _claims: Dict[int, str] = {}
 _next_id = 0
 _base_aux = _DEFAULT_AUX    # what configure() asked for when no external queue is claimed
@@ -125,9 +125,3 @@ def check_environment(world_size: int, env=None) -> None:
             f"initialises HIP (found {'unset = 4' if q is None else q}): with fewer the weight-gradient side stream shares a "
             "hardware queue with the main stream once the RCCL communicator exists and the backward pass serialises "
             "(measured 1.96 ms per step against 1.68); export it in the launcher, as bench.py does")
-
-
-def multi_stream_capture_allowed(env=None) -> bool:
-    """A hipGraph capture that spans the main AND the side stream under GPU_MAX_HW_QUEUES <= 2 aborted the runtime in round 2
-    (the log was not kept, the cause is unknown): refuse that combination."""
-    return not folded(env)

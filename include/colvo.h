@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 4
+#define COLVO_ABI_VERSION 5
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -299,6 +299,15 @@ int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t main_stream, 
  * communicator stream in data-parallel training -- must set n = 0: with four or more hardware queues active and cross-queue
  * dependencies between them the step measured 5.2 ms instead of 1.7. */
 int colvo_set_aux_side_streams(int n);
+/* hipGraph form.  While main_stream is being CAPTURED (hipStreamBeginCapture) colvo_run_commands turns the list into graph nodes
+ * with explicit dependencies on that one stream (hipStreamUpdateCaptureDependencies): the main-stream commands as one chain, the
+ * side-stream commands as a second chain -- side_stream itself is not used and no event is recorded.  policy: 0 = one branch (side
+ * commands captured in list order on the main chain), 1 = one cross-branch edge per FORK (the eager schedule node for node),
+ * 2 (default) = side commands flushed `group` at a time (default 2), each segment depending on the main chain as captured at the
+ * flush and on the previous segment, 3 = as 2 with the segments alternating between two side chains.  Every call ends joined.
+ * Nodes are created so that the main chain stays the FIRST child of every fork point: ROCm's executor keeps the first child on the
+ * parent's stream and opens a stream per further child. */
+int colvo_set_capture_policy(int policy, int group);
 
 #ifdef __cplusplus
 }

@@ -71,7 +71,7 @@ def test_baseline_configs_map_to_bench_flags():
 
 def test_stream_policy_environment_check():
     """coivo_amd/streams.py: a data-parallel rank refuses to start with fewer than 8 hardware queues; <= 2 queues fold every
-    stream onto two queues (extra streams are harmless, multi-stream graph capture is refused)."""
+    stream onto two queues (extra streams are harmless)."""
     from coivo_amd import streams
     streams.check_environment(1, {})
     streams.check_environment(8, {"GPU_MAX_HW_QUEUES": "8"})
@@ -79,7 +79,6 @@ def test_stream_policy_environment_check():
         with pytest.raises(RuntimeError, match="GPU_MAX_HW_QUEUES"):
             streams.check_environment(8, env)
     assert streams.folded({"GPU_MAX_HW_QUEUES": "2"}) and not streams.folded({}) and not streams.folded({"GPU_MAX_HW_QUEUES": "8"})
-    assert not streams.multi_stream_capture_allowed({"GPU_MAX_HW_QUEUES": "2"}) and streams.multi_stream_capture_allowed({})
 
 
 def test_stream_policy_claims(monkeypatch):
