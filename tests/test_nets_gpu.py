@@ -91,10 +91,10 @@ def test_golden_net_fixture(golden_dir, name):
             sn = max(s64.norm().item(), 1e-30)
             rows.append((f"{tag}.{pname}", smp.numel(), scale, (smp.double() - s64).abs().max().item(),
                          (s32 - s64).abs().max().item(), (smp.double() - s64).norm().item() / sn, (s32 - s64).norm().item() / sn))
-            # whole-tensor L2 norm: the sampled fp32-oracle error bounds what rounding does to it (x GRAD_K, and never
-            # looser than 5e-5 relative -- these two fixtures sit at ~2e-6)
+            # whole-tensor L2 norm (the sample above is strided): 3x what the sampled fp32-oracle error says rounding does to it,
+            # between 1e-5 and 5e-5 relative (these two fixtures sit at ~2e-6; round 2 allowed 2e-3)
             o32_rel = (s32 - s64).norm().item() / sn
-            if abs(nrm[1].item() - n64[1].item()) > min(5e-5, max(3.0 * o32_rel, 1e-6)) * n64[1].item() + 1e-12:
+            if abs(nrm[1].item() - n64[1].item()) > min(5e-5, max(3.0 * o32_rel, 1e-5)) * n64[1].item() + 1e-12:
                 bad.append(f"{tag}.{pname}: L2 norm {nrm[1].item():.6e} vs {n64[1].item():.6e}")
             n_checked += 1
     bad += grad_parity_failures(rows)
