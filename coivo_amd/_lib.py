@@ -56,6 +56,11 @@ SIGNATURES = {
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "colvo_conv_dgrad_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
+    "colvo_conv_wgrad_scratch_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "colvo_conv_wgrad_det": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6 + [_sz, _vp]),
+    "colvo_depth_head_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "colvo_depth_head_wgrad_det": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "colvo_pose_head_bwd_det": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_relu_bwd_inplace": (_i, [_i, _vp, _vp, _sz, _vp]),
     "colvo_pack_weights": (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "colvo_pack_weights_multi": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _vp]),

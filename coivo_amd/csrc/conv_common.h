@@ -101,6 +101,14 @@ struct WgradK {
     int toh, tow, tiles_x, tiles_y, ntiles, tiles_per_split;
     uint32_t m_pw, m_tow;     // see ConvK
     int nsplit, cot, xcd;     // 1-D grid: (co tile, chunk) fastest, pixel-range split slowest; XCD remap on/off
+    // Deterministic form (colvo_conv_wgrad_det): every pixel-range split STORES its sums into a slab of its own instead of
+    // adding them to dw / db with float atomics; k_wgrad_reduce then adds the slabs in split order.  null: atomics.
+    float* slabs;             // [nsplit][Cout * 9 * Ctot]
+    float* db_slabs;          // [nsplit][Cout]
+    // host side only
+    const char* scratch;
+    long long scratch_bytes;
+    int* plan_out;            // non-null: write the number of splits the launch WOULD use and do not launch
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (private L2s): give each XCD a CONTIGUOUS range of the logical work ids,

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NT) void k_depth_head_dgrad16(const void* __restric
 template <int ES, int C, int ROWS>
 __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict__ x, const float* __restrict__ dpre,
                                                          int H, int W, int px_per_block, float* __restrict__ dw,
-                                                         float* __restrict__ db) {
+                                                         float* __restrict__ db, float* __restrict__ partials) {
     constexpr int NTAP = 3 * ROWS;
     const int ky0 = (ROWS == 3) ? 0 : (int)blockIdx.z;
     const bool with_bias = (ROWS == 3) || ky0 == 1;
@@ -513,9 +513,25 @@ __global__ __launch_bounds__(NT) void k_depth_head_wgrad(const void* __restrict_
     __syncthreads();
     for (int k = threadIdx.x; k < NTAP * C + 1; k += NT) {
         const float v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-        if (k < NTAP * C) atomicAdd(dw + ky0 * 3 * C + k, v);
+        if (partials) {
+            // deterministic form: row (image, pixel range) of a [rows][9 C + 1] table, every entry written by exactly one workgroup
+            float* row = partials + ((size_t)b * gridDim.x + blockIdx.x) * (9 * C + 1);
+            if (k < NTAP * C) row[ky0 * 3 * C + k] = v;
+            else if (with_bias) row[9 * C] = v;
+        } else if (k < NTAP * C) atomicAdd(dw + ky0 * 3 * C + k, v);
         else if (with_bias) atomicAdd(db, v);
     }
+}
+
+// deterministic form, second launch: dw[k] += sum over the table's rows in row order (k < 9 C), db += column 9 C
+__global__ __launch_bounds__(NT) void k_head_wgrad_reduce(const float* __restrict__ partials, int rows, int ncol,
+                                                          float* __restrict__ dw, float* __restrict__ db) {
+    const int k = blockIdx.x * NT + threadIdx.x;
+    if (k >= ncol) return;
+    float t = 0.0f;
+    for (int r = 0; r < rows; ++r) t += partials[(size_t)r * ncol + k];
+    if (k < ncol - 1) dw[k] += t;
+    else db[0] += t;
 }
 
 // generic-C fallback: one (tap, c) pair per thread over a strip of rows
@@ -617,6 +633,53 @@ __global__ __launch_bounds__(NT) void k_pose_head_bwd(const void* __restrict__ x
         for (int j = 0; j < 8; ++j) atomicAdd(dw + j * C + c, go[j] * sx * inv);
     }
     if (tid < 8) atomicAdd(db + tid, go[tid]);
+}
+
+// Deterministic form of the PoseNet head backward: thread = channel, the images are walked IN ORDER by the one thread that owns
+// dw[.][c] (no atomics); dx as above.  The head sees <= 20 pixels per image: the serial walk costs a few microseconds.
+template <int ES>
+__global__ __launch_bounds__(NT) void k_pose_head_bwd_det(const void* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ d_pose, const float* __restrict__ d_a,
+                                                          const float* __restrict__ d_b, const float* __restrict__ sa,
+                                                          const float* __restrict__ sb, int B, int HW, int C, float pose_scale,
+                                                          float lcc_scale, void* __restrict__ dx, float* __restrict__ dw,
+                                                          float* __restrict__ db) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    const float gs = (sa ? sa[0] : 1.0f) * (sb ? sb[0] : 1.0f);
+    pose_scale *= gs;
+    lcc_scale *= gs;
+    const float inv = 1.0f / (float)HW;
+    float dwacc[8], dbacc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dwacc[j] = 0.0f; dbacc[j] = 0.0f; }
+    for (int b = 0; b < B; ++b) {
+        float go[8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) go[j] = d_pose ? d_pose[b * 6 + j] * pose_scale : 0.0f;
+        go[6] = d_a ? d_a[b] * lcc_scale : 0.0f;
+        go[7] = d_b ? d_b[b] * lcc_scale : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbacc[j] += go[j];
+        if (c >= C) continue;
+        float g = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g += go[j] * w[j * C + c];
+        g *= inv;
+        float sx = 0.0f;
+        for (int p = 0; p < HW; ++p) {
+            const size_t o = ((size_t)b * HW + p) * C + c;
+            const float xv = Elem<ES>::ld(x, o);
+            sx += xv;
+            Elem<ES>::st(dx, o, xv > 0.0f ? g : 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dwacc[j] += go[j] * sx * inv;
+    }
+    if (c < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dw[j * C + c] += dwacc[j];
+    }
+    if (c < 8) db[c] += dbacc[c];
 }
 
 // ---------------------------------------------------------------- Adam ----------------------- //
@@ -832,26 +895,58 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
 
 // The weight / bias gradient alone, from the d(pre) plane colvo_depth_head_bwd left in `scratch` (so that it can run on
 // another stream than the input gradient).
+static int depth_head_wgrad_impl(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw, float* db,
+                                 float* partials, size_t partial_bytes, colvo_stream_t stream);
+
 extern "C" int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw,
                                       float* db, colvo_stream_t stream) {
+    return depth_head_wgrad_impl(dtype, x, dpre, B, H, W, C, dw, db, nullptr, 0, stream);
+}
+
+// pixels per workgroup of the C = 16 kernel: a multiple of 256, at least 8 per thread, and at most ~512 workgroups (two per CU
+// resident)
+static int head_wgrad_ppb(size_t HW, int B) {
+    int ppb = 2048;
+    while ((HW + ppb - 1) / ppb * B > 512 && ppb < 16384) ppb += 256;
+    return ppb;
+}
+
+extern "C" size_t colvo_depth_head_wgrad_scratch_bytes(int B, int H, int W, int C) {
+    if (C != 16 || B < 1 || H < 1 || W < 1) return 0;
+    const size_t HW = (size_t)H * W;
+    const int ppb = head_wgrad_ppb(HW, B);
+    return (size_t)B * ((HW + ppb - 1) / ppb) * (9 * C + 1) * sizeof(float);
+}
+
+extern "C" int colvo_depth_head_wgrad_det(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw,
+                                          float* db, void* scratch, size_t scratch_bytes, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(scratch && C == 16, "colvo_depth_head_wgrad_det: needs scratch and the 16-channel head");
+    return depth_head_wgrad_impl(dtype, x, dpre, B, H, W, C, dw, db, (float*)scratch, scratch_bytes, stream);
+}
+
+static int depth_head_wgrad_impl(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw, float* db,
+                                 float* partials, size_t partial_bytes, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && dpre && dw && db, "colvo_depth_head_wgrad: null pointer argument");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_wgrad: bad dtype");
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024, "colvo_depth_head_wgrad: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W;
     if (C == 16) {
-        // pixels per workgroup: a multiple of 256, at least 8 per thread, and at most ~512 workgroups (two per CU resident)
-        int ppb = 2048;
-        while ((HW + ppb - 1) / ppb * B > 512 && ppb < 16384) ppb += 256;
+        const int ppb = head_wgrad_ppb(HW, B);
+        const int rows_tab = (int)(B * ((HW + ppb - 1) / ppb));
+        COLVO_CHECK_ARG(!partials || (size_t)rows_tab * (9 * 16 + 1) * sizeof(float) <= partial_bytes,
+                        "colvo_depth_head_wgrad_det: scratch too small (colvo_depth_head_wgrad_scratch_bytes)");
         // tap rows per thread: 1 (three workgroups per pixel range) measured 57 -> 45 us inside the step, step -1 %
         static const int rows = [] { const char* e = getenv("COLVO_HEAD_WGRAD_ROWS"); return e ? atoi(e) : 1; }();   // A/B switch
         if (rows == 3) {
             DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 3>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
-                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db, partials));
         } else {
             DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 1>), dim3((unsigned)((HW + ppb - 1) / ppb), B, 3),
-                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db));
+                                                  dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db, partials));
         }
+        if (partials)
+            hipLaunchKernelGGL(k_head_wgrad_reduce, dim3(1), dim3(NT), 0, s, (const float*)partials, rows_tab, 9 * 16 + 1, dw, db);
     } else {
         const int rows = 4;
         DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
@@ -879,6 +974,17 @@ extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, con
     DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_pose, d_a,
                                           d_b, scale_a, scale_b, HW, C, pose_scale, lcc_scale, dx, dw, db));
     COLVO_CHECK_LAUNCH("k_pose_head_bwd");
+    return 0;
+}
+
+extern "C" int colvo_pose_head_bwd_det(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a,
+                                       const float* d_b, const float* scale_a, const float* scale_b, int B, int HW, int C,
+                                       float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(x && w && dx && dw && db && B >= 1 && HW >= 1 && C >= 8, "colvo_pose_head_bwd_det: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd_det: bad dtype");
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd_det<ES>), dim3((C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, x, w,
+                                          d_pose, d_a, d_b, scale_a, scale_b, B, HW, C, pose_scale, lcc_scale, dx, dw, db));
+    COLVO_CHECK_LAUNCH("k_pose_head_bwd_det");
     return 0;
 }
 

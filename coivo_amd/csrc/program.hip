@@ -87,6 +87,8 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
         case COLVO_CMD_CONV_DGRAD_BOTH:
             return colvo_conv_dgrad_both(&c.desc, c.p[0], c.p[1], c.p[2], c.p[3], (void*)c.p[4], (void*)c.p[5], s);
         case COLVO_CMD_CONV_WGRAD:
+            if (c.p[5]) return colvo_conv_wgrad_det(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], (void*)c.p[5],
+                                                    (size_t)(uint32_t)c.i[0], s);
             return colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
         case COLVO_CMD_PACK_NCHW: {
             const float* src[4] = {(const float*)c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3]};
@@ -107,12 +109,17 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
                                               c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[8], (void*)c.p[9], nullptr,
                                               nullptr, s);
         case COLVO_CMD_DEPTH_HEAD_WGRAD:
+            if (c.p[4]) return colvo_depth_head_wgrad_det(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4],
+                                                          (float*)c.p[2], (float*)c.p[3], (void*)c.p[4], (size_t)(uint32_t)c.i[5], s);
             return colvo_depth_head_wgrad(c.i[0], c.p[0], (const float*)c.p[1], c.i[1], c.i[2], c.i[3], c.i[4], (float*)c.p[2],
                                           (float*)c.p[3], s);
         case COLVO_CMD_POSE_HEAD_FWD:
             return colvo_pose_head_fwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], c.i[1], c.i[2], c.i[3], c.f[0],
                                        c.f[1], (float*)c.p[3], s);
         case COLVO_CMD_POSE_HEAD_BWD:
+            if (c.i[4]) return colvo_pose_head_bwd_det(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
+                                                       (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2],
+                                                       c.i[3], c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
             return colvo_pose_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
                                        (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2], c.i[3],
                                        c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);

@@ -344,7 +344,11 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + 16 * mi + 4 * kg + r;
-                    if (co < a.Cout) atomicAdd(a.dw + (size_t)co * 9 * a.Ctot + wc0 + ocol[fi], acc[mi][fi][r]);
+                    if (co < a.Cout) {
+                        const size_t e = (size_t)co * 9 * a.Ctot + wc0 + ocol[fi];
+                        if (a.slabs) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e] = acc[mi][fi][r];   // this split's own slab
+                        else atomicAdd(a.dw + e, acc[mi][fi][r]);
+                    }
                 }
             }
     }
@@ -356,9 +360,49 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
             float t = 0.0f;
 #pragma unroll
             for (int ph = 0; ph < NPH * KS; ++ph) t += sdb[ph * 16 * MT + tid];
-            atomicAdd(a.db + co0 + tid, t);
+            if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else atomicAdd(a.db + co0 + tid, t);
         }
     }
+}
+
+// deterministic form, second launch: dst[i] += slabs[0][i] + slabs[1][i] + ... in split order
+__global__ __launch_bounds__(NT) void k_wgrad_reduce(const float* __restrict__ slabs, int nsplit, size_t n, float* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+        float t = 0.0f;
+        for (int q = 0; q < nsplit; ++q) t += slabs[(size_t)q * n + i];
+        dst[i] += t;
+    }
+}
+
+// plan-only calls report the split count; deterministic calls point the kernel at the caller's scratch.  Returns 1 when the
+// caller has nothing more to do (plan written), 0 to go on, < 0 never; errors are reported through *err.
+inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
+    *err = 0;
+    if (k.plan_out) { *k.plan_out = nsplit; return true; }
+    k.slabs = nullptr; k.db_slabs = nullptr;
+    if (k.scratch) {
+        const long long wsize = (long long)k.Cout * 9 * k.Ctot;
+        const long long need = (long long)nsplit * (wsize + k.Cout) * 4;
+        if (need > k.scratch_bytes) {
+            set_error("colvo_conv_wgrad_det: scratch of %lld bytes, %lld needed (colvo_conv_wgrad_scratch_bytes)", k.scratch_bytes, need);
+            *err = (int)hipErrorInvalidValue;
+            return true;
+        }
+        k.slabs = (float*)const_cast<char*>(k.scratch);
+        k.db_slabs = k.slabs + (size_t)nsplit * wsize;
+    }
+    return false;
+}
+
+inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
+    if (!k.slabs) return 0;
+    const size_t wsize = (size_t)k.Cout * 9 * k.Ctot;
+    unsigned blocks = (unsigned)std::min<size_t>((wsize + NT - 1) / NT, 2048);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(NT), 0, s, (const float*)k.slabs, nsplit, wsize, k.dw);
+    if (k.db) hipLaunchKernelGGL(k_wgrad_reduce, dim3(1), dim3(NT), 0, s, (const float*)k.db_slabs, nsplit, (size_t)k.Cout, k.db);
+    COLVO_CHECK_LAUNCH("k_wgrad_reduce");
+    return 0;
 }
 
 template <typename T, int MT, int NG, bool TAIL, int KS>
@@ -389,10 +433,11 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
     static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
+    { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
     hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3 (teams)");
-    return 0;
+    return wgrad_finish(k, nsplit, s);
 }
 
 template <typename T, int MT, int NG, bool TAIL>
@@ -443,10 +488,11 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
     static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
+    { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
     hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3");
-    return 0;
+    return wgrad_finish(k, nsplit, s);
 }
 
 template <typename T, int MT, int NG>
@@ -492,8 +538,32 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
 
 using namespace colvo;
 
+static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream);
+
 extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
                                 float* db, colvo_stream_t stream) {
+    return wgrad_impl(d, x0, x1, dy, dw, db, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int colvo_conv_wgrad_det(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
+                                    float* db, void* scratch, size_t scratch_bytes, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(scratch, "colvo_conv_wgrad_det: null scratch");
+    return wgrad_impl(d, x0, x1, dy, dw, db, scratch, scratch_bytes, nullptr, stream);
+}
+
+extern "C" size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d) {
+    if (!d || check_desc(d, "colvo_conv_wgrad_scratch_bytes")) return 0;
+    // the launch planner itself, in plan-only mode (no pointer is dereferenced); a batch the call would slice (tensors >= 1 GiB)
+    // is planned per slice, every slice re-using the same scratch
+    int nsplit = 0;
+    static const char dummy = 0;
+    if (wgrad_impl(d, &dummy, d->C1 ? &dummy : nullptr, &dummy, (float*)&dummy, nullptr, nullptr, 0, &nsplit, nullptr)) return 0;
+    return (size_t)nsplit * ((size_t)d->Cout * 9 * (d->C0 + d->C1) + d->Cout) * 4;
+}
+
+static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream) {
     if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
     COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
     // The kernel addresses dY and the sources with 32-bit buffer offsets (< 1 GiB per tensor): larger batches are
@@ -511,9 +581,11 @@ extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const vo
             for (int b0 = 0; b0 < d->B; b0 += bmax) {
                 ColvoConvDesc sub = *d;
                 sub.B = std::min(bmax, d->B - b0);
-                if (int e = colvo_conv_wgrad(&sub, (const char*)x0 + b0 * e0, x1 ? (const char*)x1 + b0 * e1 : nullptr,
-                                             (const char*)dy + b0 * ey, dw, db, stream))
+                int plan = 0;
+                if (int e = wgrad_impl(&sub, (const char*)x0 + b0 * e0, x1 ? (const char*)x1 + b0 * e1 : nullptr,
+                                       (const char*)dy + b0 * ey, dw, db, scratch, scratch_bytes, plan_out ? &plan : nullptr, stream))
                     return e;
+                if (plan_out) *plan_out = std::max(*plan_out, plan);
             }
             return 0;
         }
@@ -522,6 +594,7 @@ extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const vo
     fill_gather(d, x0, d->C1 ? x1 : nullptr, k.g);
     k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
     k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
+    k.scratch = (const char*)scratch; k.scratch_bytes = scratch ? (long long)scratch_bytes : 0; k.plan_out = plan_out;
     const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;

@@ -85,6 +85,10 @@ class _ArenaModule(nn.Module):
         self.defer_join = os.environ.get("COLVO_NO_DEFER_JOIN") is None
         self._join_pending = False
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
+        # deterministic: weight gradients through per-split slabs + fixed-order second launches instead of float atomics
+        # (include/colvo.h colvo_conv_wgrad_det): bitwise repeatable steps at the price of ~one small launch per layer.  Read when a
+        # pass is RECORDED: call clear_programs() after changing it.
+        self.deterministic = os.environ.get("COLVO_DETERMINISTIC") is not None
 
     # ---- arena ------------------------------------------------------------------------------- #
     def _layers(self) -> List[ConvParams]:
@@ -524,7 +528,8 @@ class DepthNet(_ArenaModule):
 
             def wgrad(name, x0, x1, dy):
                 L = getattr(self, name)
-                self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias), x0, x1, dy)
+                scr = ops.conv_wgrad_scratch(P[name], dy.device) if self.deterministic else None
+                self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias, scr), x0, x1, dy)
 
             def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
                 L = getattr(self, name)
@@ -541,8 +546,8 @@ class DepthNet(_ArenaModule):
                 ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
             else:
                 ops.depth_head_bwd_parts(x1, self.head.w_master, depth, *parts, scratch, g)
-            self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias),
-                            x1, scratch)
+            self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
+                                                                    self.deterministic), x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
             for i in range(1, 6):                       # decoder, output side first
                 u = A[f"up{i}"]
@@ -692,12 +697,13 @@ class PoseNet(_ArenaModule):
             x = A[7]
             g = torch.empty_like(x)
             ops.pose_head_bwd(x, self.pred.w_master, grads.get("d_pose"), grads.get("d_a"), grads.get("d_b"),
-                              g, self.pred.g_master, self.pred.g_bias, grads.get("scale_a"), grads.get("scale_b"))
+                              g, self.pred.g_master, self.pred.g_bias, grads.get("scale_a"), grads.get("scale_b"), self.deterministic)
             self._layer_done(self.pred)
             for i in range(7, 0, -1):
                 L = getattr(self, f"conv{i}")
                 src = A["in"] if i == 1 else A[i - 1]
-                self._run_wgrad(L, lambda L=L, i=i, src=src, g=g: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias),
+                scr = ops.conv_wgrad_scratch(P[i], g.device) if self.deterministic else None
+                self._run_wgrad(L, lambda L=L, i=i, src=src, g=g, scr=scr: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias, scr),
                                 src, g)
                 if i > 1 or has_depth:
                     dx = torch.empty_like(src)

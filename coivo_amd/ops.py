@@ -73,12 +73,27 @@ def conv_dgrad_both(d: ConvDesc, dy, w_bwd, relu_mask0, relu_mask1, dx0, dx1) ->
                                          _lib.ptr(dx0), _lib.ptr(dx1), _lib.stream_ptr()), "colvo_conv_dgrad_both")
 
 
-def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db) -> None:
-    _need_cuda(x0, x1, dy, dw, db)
+def conv_wgrad_scratch(d: ConvDesc, device) -> torch.Tensor:
+    """Scratch for the deterministic weight gradient of one conv call (include/colvo.h colvo_conv_wgrad_det)."""
+    n = _lib.load().colvo_conv_wgrad_scratch_bytes(C.byref(d))
+    if n == 0:
+        raise RuntimeError("colvo_conv_wgrad_scratch_bytes failed: " + _lib.load().colvo_last_error().decode("utf-8", "replace"))
+    return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
+
+
+def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db, scratch: Optional[torch.Tensor] = None) -> None:
+    """dw / db += the layer's weight / bias gradient.  With `scratch` (conv_wgrad_scratch) the deterministic form: per-split slabs
+    + a fixed-order second launch instead of float atomics."""
+    _need_cuda(x0, x1, dy, dw, db, scratch)
+    nb = 0 if scratch is None else scratch.numel() * scratch.element_size()
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, dw, db))
+        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, dw, db, scratch), (nb,))
     lib = _lib.load()
+    if scratch is not None:
+        _lib.check(lib.colvo_conv_wgrad_det(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
+                                            _lib.ptr(scratch), nb, _lib.stream_ptr()), "colvo_conv_wgrad_det")
+        return
     _lib.check(lib.colvo_conv_wgrad(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw),
                                     _lib.ptr(db), _lib.stream_ptr()), "colvo_conv_wgrad")
 
@@ -193,14 +208,24 @@ def zero_(t: torch.Tensor) -> None:
     _lib.check(lib.colvo_zero(_lib.ptr(t), t.numel() * t.element_size(), _lib.stream_ptr()), "colvo_zero")
 
 
-def depth_head_wgrad(x, dpre, dw, db) -> None:
+def depth_head_wgrad(x, dpre, dw, db, deterministic: bool = False) -> None:
     """Weight / bias gradient of the depth head from the d(pre) plane depth_head_bwd(dw=None, db=None) left in scratch."""
     _need_cuda(x, dpre, dw, db)
     B, H, W, Cc = x.shape
+    lib = _lib.load()
+    scr, nb = None, 0
+    if deterministic:
+        nb = lib.colvo_depth_head_wgrad_scratch_bytes(B, H, W, Cc)
+        if nb == 0:
+            raise RuntimeError("deterministic depth-head weight gradient: only the 16-channel head is supported")
+        scr = torch.empty((nb + 3) // 4, device=x.device, dtype=torch.float32)
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_DEPTH_HEAD_WGRAD, None, (x, dpre, dw, db), (dt_code(x.dtype), B, H, W, Cc))
-    lib = _lib.load()
+        return rec.add(_lib.CMD_DEPTH_HEAD_WGRAD, None, (x, dpre, dw, db, scr), (dt_code(x.dtype), B, H, W, Cc, nb))
+    if scr is not None:
+        _lib.check(lib.colvo_depth_head_wgrad_det(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(dpre), B, H, W, Cc, _lib.ptr(dw),
+                                                  _lib.ptr(db), _lib.ptr(scr), nb, _lib.stream_ptr()), "colvo_depth_head_wgrad_det")
+        return
     _lib.check(lib.colvo_depth_head_wgrad(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(dpre), B, H, W, Cc, _lib.ptr(dw),
                                           _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_wgrad")
 
@@ -218,19 +243,20 @@ def pose_head_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out: tor
                                        POSE_SCALE, LCC_SCALE, _lib.ptr(out), _lib.stream_ptr()), "colvo_pose_head_fwd")
 
 
-def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a=None, scale_b=None) -> None:
+def pose_head_bwd(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a=None, scale_b=None, deterministic: bool = False) -> None:
     """d_pose [B,6] / d_a [B,1] / d_b [B,1] contiguous or None (= zero); scale_a, scale_b: device scalars multiplied into
-    all three (None = 1)."""
+    all three (None = 1).  deterministic: the atomics-free form (colvo_pose_head_bwd_det)."""
     _need_cuda(x, w, d_pose, d_a, d_b, dx, dw, db, scale_a, scale_b)
     B, H, W, Cc = x.shape
     rec = program.recording()
     if rec is not None:
         return rec.add(_lib.CMD_POSE_HEAD_BWD, None, (x, w, d_pose, d_a, d_b, dx, dw, db, scale_a, scale_b),
-                       (dt_code(x.dtype), B, H * W, Cc), (POSE_SCALE, LCC_SCALE))
+                       (dt_code(x.dtype), B, H * W, Cc, int(deterministic)), (POSE_SCALE, LCC_SCALE))
     lib = _lib.load()
-    _lib.check(lib.colvo_pose_head_bwd(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_pose), _lib.ptr(d_a),
-                                       _lib.ptr(d_b), _lib.ptr(scale_a), _lib.ptr(scale_b), B, H * W, Cc, POSE_SCALE,
-                                       LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.stream_ptr()),
+    fn = lib.colvo_pose_head_bwd_det if deterministic else lib.colvo_pose_head_bwd
+    _lib.check(fn(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(d_pose), _lib.ptr(d_a),
+                  _lib.ptr(d_b), _lib.ptr(scale_a), _lib.ptr(scale_b), B, H * W, Cc, POSE_SCALE,
+                  LCC_SCALE, _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.stream_ptr()),
                "colvo_pose_head_bwd")
 
 

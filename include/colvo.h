@@ -160,6 +160,21 @@ int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_
 int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
                      float* dw, float* db, colvo_stream_t stream);
 
+/* Deterministic weight gradients.  The plain calls end in fp32 atomics (one add per weight and pixel-range split): the sum
+ * depends on the order the workgroups finish in, in the last bits.  The _det forms give every split a slab of its own in
+ * caller-owned scratch (plain stores) and add the slabs in split order with a second small launch: bitwise repeatable run to
+ * run, at the price of that launch.  scratch: >= the matching *_scratch_bytes(), no initialisation needed, private to the call
+ * while it runs.  colvo_pose_head_bwd_det needs none: one thread owns each weight column and walks the images in order. */
+size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d);
+int colvo_conv_wgrad_det(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
+                         void* scratch, size_t scratch_bytes, colvo_stream_t stream);
+size_t colvo_depth_head_wgrad_scratch_bytes(int B, int H, int W, int C);
+int colvo_depth_head_wgrad_det(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw, float* db,
+                               void* scratch, size_t scratch_bytes, colvo_stream_t stream);
+int colvo_pose_head_bwd_det(int dtype, const void* x, const float* w, const float* d_pose, const float* d_a, const float* d_b,
+                            const float* scale_a, const float* scale_b, int B, int HW, int C, float pose_scale, float lcc_scale,
+                            void* dx, float* dw, float* db, colvo_stream_t stream);
+
 /* dy <- dy * (y > 0) in place (first consumer of a ReLU output's gradient when no dgrad produced it). */
 int colvo_relu_bwd_inplace(int dtype, const void* y, void* dy, size_t n, colvo_stream_t stream);
 
@@ -268,14 +283,14 @@ int colvo_read_npy_u8_frames(const char* const* paths, int n, int h, int w, uint
 enum {
     COLVO_CMD_CONV_FWD = 1,      /* p: x0 x1 w_fwd bias y */
     COLVO_CMD_CONV_DGRAD,        /* i: src accumulate; p: dy w_bwd relu_mask dx */
-    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db */
+    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db scratch; i: scratch_bytes (scratch != NULL: colvo_conv_wgrad_det) */
     COLVO_CMD_PACK_NCHW,         /* i: dtype c0 c1 c2 c3 nsrc B H W Cpad; p: src0..src3 dst */
     COLVO_CMD_UNPACK_NHWC_GRAD,  /* i: dtype B H W Cpad c_begin c_count accumulate; p: dsrc dst */
     COLVO_CMD_DEPTH_HEAD_FWD,    /* i: dtype B H W C; f: min max; p: x w bias depth */
     COLVO_CMD_DEPTH_HEAD_BWD,    /* i: dtype B H W C; f: min max; p: x w depth d_depth scratch dx dw db */
-    COLVO_CMD_DEPTH_HEAD_WGRAD,  /* i: dtype B H W C; p: x dpre dw db */
+    COLVO_CMD_DEPTH_HEAD_WGRAD,  /* i: dtype B H W C scratch_bytes; p: x dpre dw db scratch (non-NULL: the _det form) */
     COLVO_CMD_POSE_HEAD_FWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w bias out */
-    COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db scale_a scale_b */
+    COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C det; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db scale_a scale_b */
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
     COLVO_CMD_JOIN,              /* main stream waits for the side stream's work so far */
     COLVO_CMD_DEPTH_HEAD_BWD_PARTS, /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx */

@@ -23,12 +23,14 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     B, H, W, seed = 1, 64, 96, 71
+    det = os.environ.get("DDP_DET") is not None
     dn_o, pn_o = S.make_models(seed)
 
     def fresh():
         dn, pn = hnn.DepthNet(device=dev), hnn.PoseNet(device=dev)
         dn.load_state_dict(dn_o.state_dict())
         pn.load_state_dict(pn_o.state_dict())
+        dn.deterministic = pn.deterministic = det        # DDP_DET=1: weight gradients without float atomics -> exact comparisons
         return dn, pn
 
     full = synth.make_batch(world * B, H, W, seed=seed, device=dev)
@@ -64,11 +66,15 @@ def main():
             scale = b.abs().max().item()
             err = (a - b).abs().max().item()
             assert err < 2e-4 * scale, f"{name}: all-reduced gradient differs from the accumulated reference by {err} (scale {scale})"
+            if det:      # data parallel == one process accumulating the ranks' batches, bit for bit (the spec has no BatchNorm)
+                assert torch.equal(a, b), f"{name}: deterministic mode, yet the all-reduced gradient is not bitwise the accumulated one"
         opt2.step()
         torch.cuda.synchronize()
         # Adam's first step is sign-like (+-lr): float-atomic summation order may flip it on ~zero gradients only
         d = (dn.flat_param - dn2.flat_param).abs()
         assert d.max().item() <= 2.5e-4 and (d > 1e-6).float().mean().item() < 5e-3
+        if det:
+            assert torch.equal(dn.flat_param, dn2.flat_param) and torch.equal(pn.flat_param, pn2.flat_param)
     # second backward from the same parameters, twice: with the split points learned during the first step (few segments) and
     # with the learning pass forced again (one segment per layer) -- same gradients, fewer command-list calls
     from coivo_amd.program import Program
@@ -101,8 +107,10 @@ def main():
     for a, b, name in ((ga_dn, gb_dn, "DepthNet"), (ga_pn, gb_pn, "PoseNet")):
         scale = b.abs().max().item()
         assert (a - b).abs().max().item() < 2e-4 * scale, f"{name}: learned split points changed the all-reduced gradient"
+        if det:
+            assert torch.equal(a, b), f"{name}: deterministic mode, yet the learned split points changed the gradient bits"
     if rank == 0:
-        print("DDP_OK", f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
+        print("DDP_OK" + (" DET" if det else ""), f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -168,6 +168,19 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, form):
     # wgrad accumulates
     ops.conv_wgrad(desc, x0d, x1d, dyd, dw, db)
     _close(dw, 2 * wr.grad, rt * 5, at * 5, "wgrad accumulate")
+    # deterministic form (per-split slabs + a fixed-order second launch instead of float atomics): same values, bitwise
+    # repeatable, accumulates like the plain form
+    scr = ops.conv_wgrad_scratch(desc, d)
+    dws, dbs = [], []
+    for _ in range(2):
+        dwd, dbd = torch.zeros_like(dw), torch.zeros_like(db)
+        ops.conv_wgrad(desc, x0d, x1d, dyd, dwd, dbd, scr)
+        dws.append(dwd); dbs.append(dbd)
+    _close(dws[0], wr.grad, rt * 5, at * 5, "wgrad (deterministic form)")
+    _close(dbs[0], br.grad, rt * 5, at * 5, "bgrad (deterministic form)")
+    assert torch.equal(dws[0], dws[1]) and torch.equal(dbs[0], dbs[1])
+    ops.conv_wgrad(desc, x0d, x1d, dyd, dws[0], dbs[0], scr)
+    _close(dws[0], 2 * wr.grad, rt * 5, at * 5, "wgrad (deterministic form) accumulate")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -221,6 +234,16 @@ def test_depth_head(dtype):
     _close(_nchw(dx), xr.grad * (x > 0), rt, rt, "depth head dx")
     _close(dw, wr.grad, 1e-4, 1e-4, "depth head dw")
     _close(db, br.grad, 1e-4, 1e-4, "depth head db")
+    # split form (dx first, then the weight gradient from the d(pre) plane): atomics and the deterministic table form
+    outs = []
+    for det in (False, True, True):
+        dw2, db2 = torch.zeros(1, 9, Cc, device=d), torch.zeros(1, device=d)
+        ops.depth_head_bwd(xd, w.to(d), depth, dd.to(d), scratch, dx, None, None)
+        ops.depth_head_wgrad(xd, scratch, dw2, db2, det)
+        _close(dw2, wr.grad, 1e-4, 1e-4, f"depth head dw (wgrad call, det={det})")
+        _close(db2, br.grad, 1e-4, 1e-4, f"depth head db (wgrad call, det={det})")
+        outs.append((dw2, db2))
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -252,6 +275,14 @@ def test_pose_head(dtype):
     _close(_nchw(dx), xr.grad * (x > 0), rt, rt, "pose head dx")
     _close(dw, wr.grad, 1e-4, 1e-4, "pose head dw")
     _close(db, br.grad, 1e-4, 1e-4, "pose head db")
+    # deterministic form: no atomics, one thread per weight column walks the images in order
+    dx2 = torch.empty_like(xd)
+    dw2, db2 = torch.zeros(8, 1, Cc, device=d), torch.zeros(8, device=d)
+    ops.pose_head_bwd(xd, w.to(d), dod[:, :6].contiguous(), dod[:, 6:7].contiguous(), dod[:, 7:8].contiguous(), dx2, dw2, db2,
+                      deterministic=True)
+    assert torch.equal(dx2, dx)
+    _close(dw2, wr.grad, 1e-4, 1e-4, "pose head dw (deterministic form)")
+    _close(db2, br.grad, 1e-4, 1e-4, "pose head db (deterministic form)")
 
 
 def test_adam_matches_torch():

@@ -20,8 +20,8 @@ def _port():
     return p
 
 
-def _run(args, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(args, timeout=600, extra_env=None):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port())] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -31,6 +31,15 @@ def test_two_rank_dp_on_one_gpu_matches_averaged_gradients():
     r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "DDP_OK" in r.stdout
+
+
+def test_two_rank_dp_deterministic_is_bitwise_the_accumulated_batch():
+    """Deterministic weight gradients (nn.*.deterministic: per-split slabs + fixed-order second launches instead of float atomics):
+    the 2-rank all-reduced gradient, the parameters after Adam and the learned-split-point replay are BITWISE those of one process
+    accumulating both ranks' batches (the spec is BatchNorm-free)."""
+    r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")], extra_env={"DDP_DET": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DDP_OK DET" in r.stdout
 
 
 def test_bench_multiprocess_path():
