@@ -83,6 +83,8 @@ SIGNATURES = {
     "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
     "colvo_set_aux_side_streams": (_i, [_i]),
     "colvo_set_capture_policy": (_i, [_i, _i]),
+    "colvo_tune_set": (_i, [C.c_char_p, C.c_double]),
+    "colvo_tune_get": (_i, [C.c_char_p, C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -131,6 +133,24 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().colvo_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def tune_set(name: str, value: float) -> None:
+    """Developer / test hook: set an entry of the library's tuning table (coivo_amd/csrc/tuning.h)."""
+    check(load().colvo_tune_set(name.encode(), float(value)), "colvo_tune_set")
+
+
+def tune_get(name: str) -> float:
+    v = C.c_double()
+    check(load().colvo_tune_get(name.encode(), C.byref(v)), "colvo_tune_get")
+    return v.value
+
+
+def dev_env(name: str, default=None):
+    """Developer switches of the Python side are honoured only under COLVO_DEV=1 (production reads no tuning variable)."""
+    if os.environ.get("COLVO_DEV", "0") not in ("", "0"):
+        return os.environ.get(name, default)
+    return default
 
 
 def ptr(t) -> int:

@@ -1502,7 +1502,7 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
         if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
     }
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     ConvK kk = k;
     kk.ntn = (k.N + BN - 1) / BN;
     kk.xcd = xcd_on;
@@ -1576,7 +1576,7 @@ int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     const size_t p_or_out = std::max((size_t)PH * k.pwp * PIXP, (size_t)BM * (BN + 4) * 4);
     const size_t lds = (size_t)BN * WROW + p_or_out;
     const int ntiles = k.tiles_x * k.tiles_y * B;
-    static const int res_wg_per_cu = [] { const char* e = getenv("COLVO_RES_WG_PER_CU"); return e ? atoi(e) : 4; }();   // tuning knob
+    const int res_wg_per_cu = (int)TUNE(res_wg_per_cu);   // tuning knob
     int gx = 256 * res_wg_per_cu;               // workgroups per CU, each walking ntiles / gx tiles
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
@@ -1594,7 +1594,7 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
         const long long src_bytes = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * TT<T>::ES;
         const long long out_bytes = (long long)B * k.Ho * k.Wo * k.N * TT<T>::ES / (k.pool2 ? 4 : 1);
         const long long tpi = (long long)k.tiles_x * k.tiles_y;
-        static const long res_min_tiles = [] { const char* e = getenv("COLVO_RES_MIN_TILES"); return e ? atol(e) : 2048L; }();   // tuning knob
+        const long res_min_tiles = TUNE(res_min_tiles);   // tuning knob
         if (k.nsplit == 0 && k.g.C[1] == 0 && k.g.C[0] == ck && k.g.stride == 1 && src_bytes < 0x40000000LL && out_bytes < 0x40000000LL &&
             tpi >= 2 && k.tiles_x >= 2 && tpi * tpi * B < 0x100000000LL &&        // magic-division ranges
             tpi * B >= res_min_tiles) {
@@ -1611,8 +1611,8 @@ int launch_conv_ng(const ConvK& k, int B, int ng, hipStream_t s) {
             // shorter than the global-load latency it is supposed to hide
             if constexpr (BN == 32) {
                 // measured: pays only when the grid is about one workgroup per CU (it costs occupancy: ~190 VGPRs)
-                static const int depth2_min = [] { const char* e = getenv("COLVO_DEPTH2_MIN_CHUNKS"); return e ? atoi(e) : 8; }();
-                static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 1024L; }();
+                const int depth2_min = (int)TUNE(depth2_min_chunks);
+                const long lone_max = TUNE(lone_max_wgs);
                 const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
                 if (wgs <= lone_max && (k.g.C[0] + k.g.C[1]) / (4 * TT<T>::G) >= depth2_min) {
                     return launch_conv<T, BN, 4, 2>(k, B, s);     // (a three-chunk ring measured no better)
@@ -1658,9 +1658,9 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     {
         // off by default: at B = 16 the 256-pixel grids are 1-1.25 workgroups per CU and measured 10-20 % slower (up3 18.9 ->
         // 21.7 us; gpurun_out/r2_bench_conv_w*.log); the form pays once the grid covers the chip several times (configs[2])
-        static const int wide_on = [] { const char* e = getenv("COLVO_WIDE"); return e ? atoi(e) : 0; }();                 // tuning knob
-        static const long wide_min_wgs = [] { const char* e = getenv("COLVO_WIDE_MIN_WGS"); return e ? atol(e) : 192L; }();   // tuning knob
-        static const int wide_min_chunks = [] { const char* e = getenv("COLVO_WIDE_MIN_CHUNKS"); return e ? atoi(e) : 2; }();
+        const int wide_on = (int)TUNE(wide);                 // tuning knob
+        const long wide_min_wgs = TUNE(wide_min_wgs);   // tuning knob
+        const int wide_min_chunks = (int)TUNE(wide_min_chunks);
         const int nch = (k.g.C[0] + k.g.C[1]) / (ng * G);
         if (wide_on && k.nsplit == 0 && k.g.stride == 1 && k.N >= 32 && nch >= wide_min_chunks) {
             const Tile tw = pick_tile(k.Ho, k.Wo, 1, even, 256);
@@ -1677,8 +1677,8 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
     // Output-channel tile: 64 wide by default; when that grid would leave CUs idle (deep, low-resolution layers at small
     // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
     const long tiles = (long)k.tiles_x * k.tiles_y * B;
-    static const long bn64_min_wgs = [] { const char* e = getenv("COLVO_BN64_MIN_WGS"); return e ? atol(e) : 1024L; }();   // tuning knob
-    static const long bn32_min_wgs = [] { const char* e = getenv("COLVO_BN32_MIN_WGS"); return e ? atol(e) : 0L; }();      // tuning knob (16-wide tiles: measured ~neutral)
+    const long bn64_min_wgs = TUNE(bn64_min_wgs);   // tuning knob
+    const long bn32_min_wgs = TUNE(bn32_min_wgs);      // tuning knob (16-wide tiles: measured ~neutral)
     // (two-output form: a channel tile must not straddle the two sources -- nsplit is a multiple of 32)
     if (k.nsplit == 0 && k.N >= 64 && tiles * ((k.N + 63) / 64) >= bn64_min_wgs) return launch_conv_ng<T, 64>(k, B, ng, s);
     if (k.N >= 32 && tiles * ((k.N + 31) / 32) >= bn32_min_wgs) return launch_conv_ng<T, 32>(k, B, ng, s);
@@ -1689,15 +1689,13 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
 template <typename T>
 int try_launch_conv_q(const ConvK& k0, int B, hipStream_t s) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES, CK = 4 * G;
-    static const int q_on = [] { const char* e = getenv("COLVO_NO_CONV_QUAD"); return e ? 0 : 1; }();
+    const int q_on = (int)TUNE(conv_quad);
     // Measured (bf16; us, one-tile -> quad).  16 frames of 256x320: slower everywhere (enc2b 14.8 -> 23.5, iconv3 19.0 -> 34.2,
     // iconv2 22.0 -> 24.2, enc5b 17.1 -> 42.1).  64 frames of 512x640: the 2-4-chunk layers at 1/2-1/4 resolution win (enc2b 199 ->
     // 153, iconv3 265 -> 217, iconv2 370 -> 275), the 8-16-chunk layers lose to the one-tile kernel's two-chunk ring (enc4b 122 ->
     // 164, iconv5 215 -> 297).  Hence: at least 2048 quad-tile workgroups and at most 4 chunks.
-    const char* mw = getenv("COLVO_QUAD_MIN_WGS");          // tuning knobs, read per call (the tests lower / raise them)
-    const long min_wgs = mw ? atol(mw) : 2048L;
-    const char* mc = getenv("COLVO_QUAD_MAX_CHUNKS");
-    const int max_chunks = mc ? atoi(mc) : 4;
+    const long min_wgs = TUNE(quad_min_wgs);          // (the tests lower / raise these two through colvo_tune_set)
+    const int max_chunks = (int)TUNE(quad_max_chunks);
     const Gather& g = k0.g;
     if (!q_on || g.stride != 1 || k0.pool2 || g.mode[0] != MODE_DIRECT || (g.C[1] > 0 && g.mode[1] != MODE_DIRECT)) return -1;
     if (g.C[0] % CK || g.C[1] % CK || (g.C[0] + g.C[1]) / CK < 2 || (g.C[0] + g.C[1]) / CK > max_chunks) return -1;
@@ -1718,7 +1716,7 @@ int try_launch_conv_q(const ConvK& k0, int B, hipStream_t s) {
     const int bn = (k.N > 16 && tiles * ((k.N + 31) / 32) >= min_wgs) ? 32 : 16;
     k.ntn = (k.N + bn - 1) / bn;
     if (tiles * k.ntn < min_wgs) return -1;
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.xcd = xcd_on;
     constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
     const size_t lds = (size_t)bn * WROW + (size_t)PH * k.pwp * PIXP;
@@ -1742,7 +1740,7 @@ template <typename T, int BN, int DEPTH, int NCH>
 int launch_conv_up2_inst(ConvK k, int B, hipStream_t s) {
     constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
     const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 2) * k.pwp * PIXP;
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.ntn = (k.N + BN - 1) / BN;
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
@@ -1773,7 +1771,7 @@ int launch_dgrad_up2_inst(ConvK k, int B, hipStream_t s) {
         if (e != hipSuccess) { set_error("dgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         configured = 160 * 1024;
     }
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.ntn = (k.N + BN - 1) / BN;
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
@@ -1797,7 +1795,7 @@ template <typename T, int BN, int DEPTH, int NCH>
 int launch_dgrad_s2_inst(ConvK k, int B, hipStream_t s) {
     constexpr int WROW = wrow_bytes(36), PIXP = pitch_bytes(64);
     const size_t lds = (size_t)BN * WROW + (size_t)(k.toh + 1) * k.pwp * PIXP;
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.ntn = (k.N + BN - 1) / BN;
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
@@ -1811,7 +1809,7 @@ template <typename T, int BN>
 int launch_dgrad_s2_bn(const ConvK& k, int B, hipStream_t s) {
     const int nch = k.g.C[0] / (4 * TT<T>::G);
     const long wgs = (long)k.tiles_x * k.tiles_y * B * ((k.N + BN - 1) / BN);
-    static const long lone_max = [] { const char* e = getenv("COLVO_LONE_MAX_WGS"); return e ? atol(e) : 1024L; }();
+    const long lone_max = TUNE(lone_max_wgs);
     if (wgs <= lone_max) {          // about one workgroup per CU: two chunks in flight, K loop unrolled (see launch_conv_ng)
         if (nch == 8) return launch_dgrad_s2_inst<T, BN, 2, 8>(k, B, s);
         if (nch == 16) return launch_dgrad_s2_inst<T, BN, 2, 16>(k, B, s);
@@ -1845,10 +1843,10 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
     {
         // single up-sampled source in whole 32-channel chunks: four output pixels per source position (k_conv_up2; the one-chunk
         // full-resolution layer up1 too: 23.2 -> 18.4 us against the weights-resident one-tile kernel)
-        static const int up2_on = [] { const char* e = getenv("COLVO_NO_CONV_UP2"); return e ? 0 : 1; }();
+        const int up2_on = (int)TUNE(conv_up2);
         const int es = d->dtype == COLVO_F32 ? 4 : 2, ck = d->dtype == COLVO_F32 ? 16 : 32;
         const long long in_bytes = (long long)(d->Hi / 2) * (d->Wi / 2) * d->C0 * es, out_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
-        static const int up2_min_chunks = [] { const char* e = getenv("COLVO_UP2_MIN_CHUNKS"); return e ? atoi(e) : 1; }();   // tuning knob
+        const int up2_min_chunks = (int)TUNE(up2_min_chunks);   // tuning knob
         if (up2_on && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->C0 / ck >= up2_min_chunks &&
             in_bytes < 0x40000000LL && out_bytes < 0x40000000LL) {
             ConvK u = k;
@@ -1862,7 +1860,7 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
                 u.m_tow = mdiv_magic(t.tow); u.m_pw = mdiv_magic(t.tow + 2);
                 hipStream_t s = (hipStream_t)stream;
                 // 16-wide channel tiles while 32-wide ones would leave CUs without a workgroup
-                static const long bn16_max = [] { const char* e = getenv("COLVO_UP2_BN16_MAX_WGS"); return e ? atol(e) : 640L; }();   // tuning knob
+                const long bn16_max = TUNE(up2_bn16_max_wgs);   // tuning knob
                 const long wgs32 = (long)u.tiles_x * u.tiles_y * d->B * ((u.N + 31) / 32);
                 const bool wide = u.N > 16 && wgs32 > bn16_max;
                 if (d->dtype == COLVO_F32)
@@ -1892,7 +1890,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     ConvK k{};
     {
         // stride 2, even input extent, 32-channel chunks of dy: the parity-decomposed kernel (a quarter of the MFMAs)
-        static const int s2_on = [] { const char* e = getenv("COLVO_NO_DGRAD_S2"); return e ? 0 : 1; }();
+        const int s2_on = (int)TUNE(dgrad_s2);
         const int ck = d->dtype == COLVO_F32 ? 16 : 32;
         const long long out_bytes = (long long)d->Hi * d->Wi * Csrc * es, in_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
         if (s2_on && d->stride == 2 && !up && d->Hi == 2 * d->Ho && d->Wi == 2 * d->Wo && d->Cout % ck == 0 &&
@@ -1912,7 +1910,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     }
     {
         // up-sampled source, stride 1, 32-channel chunks of dy: the 2x2 sum-pool folded into the K loop (k_dgrad_up2)
-        static const int up2_on = [] { const char* e = getenv("COLVO_NO_DGRAD_UP2"); return e ? 0 : 1; }();
+        const int up2_on = (int)TUNE(dgrad_up2);
         const int ck = d->dtype == COLVO_F32 ? 16 : 32;
         const long long out_bytes = (long long)(d->Hi / 2) * (d->Wi / 2) * Csrc * es, in_bytes = (long long)d->Ho * d->Wo * d->Cout * es;
         if (up2_on && up && d->stride == 1 && d->Cout % (ck / 2) == 0 && out_bytes < 0x40000000LL && in_bytes < 0x40000000LL) {
@@ -1935,8 +1933,7 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
                 // only where the grid still covers the chip: at batch 16 the 1/8- and 1/16-resolution layers measured 1-2 us
                 // SLOWER in this form (up5 19.4 -> 21.0, up4 18.2 -> 19.4; up3 20.7 -> 19.4, up2 26.8 -> 19.1)
                 // (read at every call, not once: the tests switch it to reach this kernel with small shapes)
-                const char* mw = getenv("COLVO_DGRAD_UP2_MIN_WGS");                                                     // tuning knob
-                const long min_wgs = mw ? atol(mw) : 640L;
+                const long min_wgs = TUNE(dgrad_up2_min_wgs);
                 const long wgs32 = (long)u.tiles_x * u.tiles_y * d->B * ((u.N + 31) / 32);
                 if (wgs32 >= min_wgs) {
                     if (d->dtype == COLVO_F32)
@@ -1976,7 +1973,7 @@ extern "C" int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, con
                                      const void* relu_mask1, void* dx0, void* dx1, colvo_stream_t stream) {
     if (int e = check_desc(d, "colvo_conv_dgrad_both")) return e;
     COLVO_CHECK_ARG(dy && w_bwd && dx0 && dx1 && d->C1 > 0, "colvo_conv_dgrad_both: needs a two-source layer and both outputs");
-    static const int on = [] { const char* e = getenv("COLVO_NO_DGRAD_BOTH"); return e ? 0 : 1; }();
+    const int on = (int)TUNE(dgrad_both);
     const int es = d->dtype == COLVO_F32 ? 4 : 2;
     const long long cmax = std::max(d->C0, d->C1);
     const bool fits = (long long)d->Hi * d->Wi * cmax * es < 0x40000000LL && (long long)d->Ho * d->Wo * d->Cout * es < 0x40000000LL;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace colvo {
 namespace {
@@ -259,8 +260,8 @@ inline double patch_read_conflicts(int toh, int tow, int pwp, int S) {
 // (profiles/r2_conv_pmc.json: 26-48 % of the LDS-active cycles were conflicts).  ext = patch width - tile width at stride 1.
 // Results are cached: the search runs once per shape.
 inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool lds_aware = false, int ext = 3) {
-    static const bool aware_off = getenv("COLVO_NO_LDS_AWARE_TILES") != nullptr;      // A/B switches
-    static const int max_pad = [] { const char* e = getenv("COLVO_LDS_TILE_MAX_PAD"); return e ? atoi(e) : 8; }();
+    const bool aware_off = !TUNE(lds_aware_tiles);
+    const int max_pad = (int)TUNE(lds_tile_max_pad);
     if (aware_off) lds_aware = false;
     struct Key { int Ho, Wo, stride, even, BM, aware, ext; };
     static std::vector<std::pair<Key, Tile>> cache;

@@ -4,6 +4,7 @@
 //   (1x1 conv + spatial mean + pose/LCC scaling), ReLU backward, and Adam over the flat arena (a8).
 // Spec: oracle/colvo_spec.py (DepthNet.head / disp_to_depth, PoseNet.pred, ADAM_KW).
 #include "common.h"
+#include "tuning.h"
 
 namespace colvo {
 namespace {
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(NT) void k_adam(float* __restrict__ p, const float*
 __global__ void k_inc_step(int32_t* step_count) { step_count[0] += 1; }
 
 inline unsigned nblk(size_t n) { return (unsigned)((n + NT - 1) / NT); }
-inline bool head_dgrad_generic() { static const bool v = getenv("COLVO_HEAD_DGRAD_GENERIC") != nullptr; return v; }   // A/B switch
+inline bool head_dgrad_generic() { return TUNE(head_dgrad_generic) != 0; }   // A/B switch
 
 }  // namespace
 }  // namespace colvo
@@ -822,7 +823,7 @@ extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, co
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 && max_depth > min_depth,
                     "colvo_depth_head_fwd: bad shape / range");
     const size_t HW = (size_t)H * W;
-    static const int head_lds = [] { const char* e = getenv("COLVO_HEAD_FWD_NO_LDS"); return e ? 0 : 1; }();   // A/B switch
+    const int head_lds = (int)TUNE(head_fwd_lds);   // A/B switch
     if (C == 16 && dtype == COLVO_BF16 && head_lds && (H + 3) / 4 <= 65535) {
         hipLaunchKernelGGL(k_depth_head_fwd16_lds, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, x, w,
                            bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth);
@@ -937,7 +938,7 @@ static int depth_head_wgrad_impl(int dtype, const void* x, const float* dpre, in
         COLVO_CHECK_ARG(!partials || (size_t)rows_tab * (9 * 16 + 1) * sizeof(float) <= partial_bytes,
                         "colvo_depth_head_wgrad_det: scratch too small (colvo_depth_head_wgrad_scratch_bytes)");
         // tap rows per thread: 1 (three workgroups per pixel range) measured 57 -> 45 us inside the step, step -1 %
-        static const int rows = [] { const char* e = getenv("COLVO_HEAD_WGRAD_ROWS"); return e ? atoi(e) : 1; }();   // A/B switch
+        const int rows = (int)TUNE(head_wgrad_rows);   // A/B switch
         if (rows == 3) {
             DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 3>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
                                                   dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db, partials));

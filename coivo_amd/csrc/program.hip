@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "tuning.h"
 
 using namespace colvo;
 
@@ -51,7 +52,7 @@ std::atomic<int> g_aux_limit{MAX_AUX};      // colvo_set_aux_side_streams(): how
 // them the whole backward pass serialises -- do not raise it.
 std::mutex g_aux_mu;
 int aux_streams() {
-    static const int want = [] { const char* e = getenv("COLVO_SIDE_STREAMS"); int w = e ? atoi(e) - 1 : 1; return w < 0 ? 0 : (w > MAX_AUX ? MAX_AUX : w); }();
+    const int want = std::max(0, std::min(MAX_AUX, (int)TUNE(side_streams) - 1));
     const int n = std::min(want, g_aux_limit.load(std::memory_order_relaxed));
     if (n <= g_naux) return n;
     std::lock_guard<std::mutex> lock(g_aux_mu);

@@ -1,0 +1,107 @@
+// tuning.h -- THE table of dispatch thresholds and A/B switches of libcolvo (gfx950).
+//
+// Every choice between kernel forms is a function of the layer's geometry and of the grid it would launch; the constants of those
+// functions live here, once, with the measurement they came from.  Production processes use the defaults below and read NO
+// environment variable.  Developers change an entry in one of two ways:
+//   * COLVO_DEV=1 in the environment when the library is loaded: every entry may then be overridden by COLVO_<UPPER-CASE NAME>
+//     (read once, at first use) -- how tools/*.sh run their A/B comparisons;
+//   * colvo_tune_set("name", value) at run time (include/colvo.h) -- how the tests reach the large-grid kernel forms with small
+//     shapes; colvo_tune_get reads an entry.
+// Defaults were measured on MI355X inside the training step at BASELINE configs[1] (16 DepthNet images) and re-checked this round
+// at 64 / 128 images of 256x320 (the per-GPU shapes of configs[3] / [4]) and at 64 images of 512x640 (configs[2]):
+// profiles/r3_tuning_check.md.
+#pragma once
+#include <string.h>
+#include <stdlib.h>
+
+namespace colvo {
+namespace tune {
+
+// name, default, what it decides
+#define COLVO_TUNE_TABLE(X)                                                                                                        \
+    /* ---- forward / input-gradient kernels (conv.hip): grids are counted in 256-thread workgroups ---- */                        \
+    X(bn64_min_wgs, 1024, "64-wide output-channel tiles only when that grid still has this many workgroups, else 32-wide")         \
+    X(bn32_min_wgs, 0, "32-wide tiles only above this many workgroups, else 16-wide (0: measured neutral)")                        \
+    X(lone_max_wgs, 1024, "grids up to this size take the two-chunk register ring (~1 workgroup per CU, one wave per SIMD)")       \
+    X(depth2_min_chunks, 8, "... if the layer has at least this many 32-channel chunks")                                           \
+    X(res_wg_per_cu, 4, "weights-resident persistent kernel (single-chunk layers): workgroups per CU")                              \
+    X(res_min_tiles, 2048, "... selected from this many 128-pixel tiles on")                                                        \
+    X(wide, 0, "512-thread / 256-pixel tiles: 10-20 % slower at 16 images, pays at several workgroups per CU; off")                 \
+    X(wide_min_wgs, 192, "... minimum grid when on")                                                                                \
+    X(wide_min_chunks, 2, "... minimum chunk count when on")                                                                        \
+    X(conv_up2, 1, "forward over an up-sampled source: four output pixels per source position (k_conv_up2)")                        \
+    X(up2_min_chunks, 1, "... from this many chunks on")                                                                            \
+    X(up2_bn16_max_wgs, 640, "... with 16-wide channel tiles while the 32-wide grid would have at most this many workgroups")       \
+    X(dgrad_s2, 1, "parity-decomposed input gradient of stride-2 layers (k_dgrad_s2)")                                              \
+    X(dgrad_up2, 1, "input gradient of up-sampled layers with the 2x2 sum-pool in the K loop (k_dgrad_up2)")                        \
+    X(dgrad_up2_min_wgs, 640, "... only where its grid has this many workgroups (1/8, 1/16 resolution lose 1-2 us at 16 images)")  \
+    X(dgrad_both, 1, "both sources' input gradients of a concat layer in one launch")                                               \
+    X(conv_quad, 1, "quad-tile kernel for ordinary stride-1 layers (k_conv_q)")                                                     \
+    X(quad_min_wgs, 8192, "... from this many quad-tile workgroups on (iconv2 at configs[2] size 370 -> 275 us; at 2560-5120 "      \
+                          "workgroups of 256x320 frames it loses 3-6 % of the pass)")                                               \
+    X(quad_max_chunks, 4, "... and at most this many chunks (deeper layers keep the two-chunk ring)")                               \
+    X(xcd_remap, 1, "XCD-contiguous 1-D grids (step +4.3 % without)")                                                               \
+    X(lds_aware_tiles, 1, "tile shapes / padded LDS row pitch chosen against ds_read_b128 bank conflicts")                          \
+    X(lds_tile_max_pad, 8, "... at most this many padding pixels per patch row")                                                    \
+    /* ---- weight gradient (wgrad.hip) ---- */                                                                                     \
+    X(wgrad_mt_max, 2, "output-channel tile = 16 x this (32-wide measured better than 64 on every layer at 16 images)")             \
+    X(wgrad_mt4_min_walk, 24, "... but 64-wide from this many pixel tiles per workgroup (at a 256-workgroup grid) on")              \
+    X(wgrad_ng_max, 4, "16-byte channel granules per chunk")                                                                        \
+    X(wgrad_one_chunk_rule, 1, "16-wide tiles where the input is a single chunk (enc1a/enc1b/enc2a 27/31/26 -> 20/24/24 us)")       \
+    X(wgrad_atomic_mb, 3, "cap on the fp32 atomic traffic of a launch, MB (12 MB 592 us, 6 MB 575, 3 MB 566 over the stack)")       \
+    X(wgrad_wg_lo, 256, "... but at least this many workgroups")                                                                    \
+    X(wgrad_wg_hi, 1024, "... and at most this many")                                                                               \
+    X(wgrad_teams, 4, "pixel-tile teams per workgroup on the full-resolution layers (1 = off)")                                     \
+    X(wgrad_team_max_slabs, 2, "... for layers with at most this many (co tile, chunk) slabs")                                      \
+    X(wgrad_team_wgs, 256, "... grid size of the team form")                                                                        \
+    /* ---- heads, fused loss, streams ---- */                                                                                      \
+    X(head_wgrad_rows, 1, "tap rows per thread of the depth-head weight gradient (1: three workgroups per pixel range)")            \
+    X(head_fwd_lds, 1, "depth-head forward stages its tile in LDS (24.7 -> 18.5 us)")                                               \
+    X(head_dgrad_generic, 0, "depth-head input gradient: generic form instead of the 16-channel granule form")                      \
+    X(march_rows_fwd, 0, "rows per strip segment of the fused-loss forward march (0: chosen to fill the wave slots in whole rounds)") \
+    X(march_rows_bwd, 0, "... of the one-pass loss + gradient march")                                                               \
+    X(side_streams, 2, "weight-gradient streams colvo_run_commands alternates between (the caller's + library-owned ones)")
+
+struct Table {
+#define X(name, dflt, doc) double name = dflt;
+    COLVO_TUNE_TABLE(X)
+#undef X
+};
+
+inline bool dev_mode() {
+    static const bool v = [] { const char* e = getenv("COLVO_DEV"); return e && atoi(e) != 0; }();
+    return v;
+}
+
+inline Table& table() {
+    static Table t = [] {
+        Table x;
+        if (dev_mode()) {
+            char env[96];
+#define X(name, dflt, doc)                                                        \
+    {                                                                             \
+        snprintf(env, sizeof env, "COLVO_%s", #name);                             \
+        for (char* c = env; *c; ++c) if (*c >= 'a' && *c <= 'z') *c -= 32;       \
+        if (const char* e = getenv(env)) x.name = atof(e);                        \
+    }
+            COLVO_TUNE_TABLE(X)
+#undef X
+        }
+        return x;
+    }();
+    return t;
+}
+
+inline double* find(const char* name) {
+    Table& t = table();
+#define X(n, dflt, doc) if (!strcmp(name, #n)) return &t.n;
+    COLVO_TUNE_TABLE(X)
+#undef X
+    return nullptr;
+}
+
+#define TUNE(name) ((long)::colvo::tune::table().name)
+#define TUNE_F(name) (::colvo::tune::table().name)
+
+}  // namespace tune
+}  // namespace colvo

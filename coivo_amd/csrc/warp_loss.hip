@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "tuning.h"
 
 namespace colvo {
 namespace {
@@ -1235,7 +1236,7 @@ extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const flo
     hipStream_t s = (hipStream_t)stream;
     // marching-wave forward: one wave per (image, 32-row segment, 62-column strip)
     int seg_rows = pick_march_rows(B, H, W);
-    if (const char* e = getenv("COLVO_MARCH_ROWS_FWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
+    if (TUNE(march_rows_fwd) > 0) seg_rows = std::max(4, std::min(MROWS_MAX, (int)TUNE(march_rows_fwd)));   // tuning knob
     const int strips_x = (W + MCOLS - 1) / MCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fwd: too many strips");
@@ -1261,7 +1262,7 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     hipStream_t s = (hipStream_t)stream;
     // marching-wave backward: one wave per (image, row segment, 60-column strip)
     int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
-    if (const char* e = getenv("COLVO_MARCH_ROWS_BWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
+    if (TUNE(march_rows_bwd) > 0) seg_rows = std::max(4, std::min(MROWS_MAX, (int)TUNE(march_rows_bwd)));   // tuning knob
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");
@@ -1286,7 +1287,7 @@ extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const f
     COLVO_CHECK_ARG((size_t)H * W < (1u << 30), "colvo_warp_loss_fused: image too large");
     hipStream_t s = (hipStream_t)stream;
     int seg_rows = pick_march_rows(B, H, W, BCOLS, 4, 8);
-    if (const char* e = getenv("COLVO_MARCH_ROWS_BWD")) seg_rows = std::max(4, std::min(MROWS_MAX, atoi(e)));   // tuning knob
+    if (TUNE(march_rows_bwd) > 0) seg_rows = std::max(4, std::min(MROWS_MAX, (int)TUNE(march_rows_bwd)));   // tuning knob
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fused: too many strips");

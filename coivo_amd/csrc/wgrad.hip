@@ -426,12 +426,12 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
     const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
     // one workgroup per CU (KS * 4 waves fill its SIMDs): as many pixel-range splits as keep the grid within 256
     const int per_split = chunks * cot;
-    static const int wg_target = [] { const char* e = getenv("COLVO_WGRAD_TEAM_WGS"); return e ? atoi(e) : 256; }();   // tuning knob
+    const int wg_target = (int)TUNE(wgrad_team_wgs);   // tuning knob
     int nsplit = std::max(1, wg_target / per_split);
     if (nsplit > k.ntiles) nsplit = k.ntiles;
     k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
@@ -452,8 +452,8 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
         // Measured at batch 16, us: up1 47.8 -> 37.5, iconv1 38.5 -> 28.9; with 32-wide co tiles it loses (enc1b 30.7 -> 40.2,
         // up2 / iconv2 32.8 -> 37.5) and everywhere else the walk is short and the per-workgroup costs decide: -1...+8
         // (gpurun_out/r2_bench_conv_slabs*.log).  4 teams = 1024 threads, 128 registers per lane.
-        static const int teams = [] { const char* e = getenv("COLVO_WGRAD_TEAMS"); return e ? atoi(e) : 4; }();          // tuning knob; 1 = off
-        static const int max_slabs = [] { const char* e = getenv("COLVO_WGRAD_TEAM_MAX_SLABS"); return e ? atoi(e) : 2; }();   // tuning knob
+        const int teams = (int)TUNE(wgrad_teams);          // tuning knob; 1 = off
+        const int max_slabs = (int)TUNE(wgrad_team_max_slabs);   // tuning knob
         const int slabs = ((k.g.C[0] + k.g.C[1]) / CK) * ((k.Cout + 16 * MT - 1) / (16 * MT));
         const size_t stage = ((size_t)BM * DYP + (size_t)PH * PW * PIXP + 15) & ~(size_t)15;
         if constexpr (!TAIL && MT == 1)
@@ -475,9 +475,9 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     // but keep at least ~256 workgroups in flight and at most ~1024.
     const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
     const int per_split = chunks * cot;
-    static const double atomic_budget = [] { const char* e = getenv("COLVO_WGRAD_ATOMIC_MB"); return (e ? atof(e) : 3.0) * 1e6; }();
-    static const int wg_lo = [] { const char* e = getenv("COLVO_WGRAD_WG_LO"); return e ? atoi(e) : 256; }();
-    static const int wg_hi = [] { const char* e = getenv("COLVO_WGRAD_WG_HI"); return e ? atoi(e) : 1024; }();
+    const double atomic_budget = TUNE_F(wgrad_atomic_mb) * 1e6;
+    const int wg_lo = (int)TUNE(wgrad_wg_lo);
+    const int wg_hi = (int)TUNE(wgrad_wg_hi);
     int nsplit = (int)(atomic_budget / wbytes);
     const int lo = (wg_lo + per_split - 1) / per_split, hi = (wg_hi + per_split - 1) / per_split;
     if (nsplit > hi) nsplit = hi;
@@ -486,7 +486,7 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     if (nsplit < 1) nsplit = 1;
     k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
-    static const int xcd_on = [] { const char* e = getenv("COLVO_NO_XCD_REMAP"); return e ? 0 : 1; }();
+    const int xcd_on = (int)TUNE(xcd_remap);
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
@@ -515,7 +515,7 @@ int launch_wgrad_ng(const WgradK& k, int ng, hipStream_t s) {
 template <typename T>
 int launch_wgrad_t(const WgradK& k, hipStream_t s) {
     constexpr int G = TT<T>::G;
-    static const int ng_max = [] { const char* e = getenv("COLVO_WGRAD_NG_MAX"); return e ? atoi(e) : 4; }();   // tuning knob
+    const int ng_max = (int)TUNE(wgrad_ng_max);   // tuning knob
     int ng = ng_max;
     for (int i = 0; i < 2; ++i)
         if (k.g.C[i] > 0) while (ng > 1 && (k.g.C[i] % (ng * G)) != 0) ng >>= 1;
@@ -523,12 +523,17 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
         COLVO_CHECK_ARG(k.g.C[i] % (ng * G) == 0, "wgrad: channel count %d is not a multiple of %d", k.g.C[i], G);
     // co tile: 32 wide (MT = 2) measured better than 64 on every layer -- twice the (co, chunk) combinations, so half the
     // pixel-range splits and half the fp32 atomic traffic for the same number of workgroups (wgrad 638 -> 589 us)
-    static const int mt_max = [] { const char* e = getenv("COLVO_WGRAD_MT_MAX"); return e ? atoi(e) : 2; }();   // tuning knob
+    const int mt_max = (int)TUNE(wgrad_mt_max);   // tuning knob
     // ... and 16 wide where the input is a single channel chunk (the high-resolution encoder layers: the (co tile, chunk) grid
     // is then 1-2 slabs; measured enc1a 27.0 -> 19.5, enc1b 30.9 -> 24.4, enc2a 26.3 -> 23.5 us; two-chunk layers lose)
-    static const int one_chunk_rule = [] { const char* e = getenv("COLVO_WGRAD_NO_ONE_CHUNK_RULE"); return e ? 0 : 1; }();   // A/B switch
+    const int one_chunk_rule = (int)TUNE(wgrad_one_chunk_rule);   // A/B switch
     const bool one_chunk = one_chunk_rule && (k.g.C[0] + k.g.C[1]) == ng * G;
-    if (k.Cout >= 64 && mt_max >= 4) return launch_wgrad_ng<T, 4>(k, ng, s);
+    // ... except where the pixel-tile walk is long: with >= mt4_min tiles per workgroup at a 256-workgroup grid the 64-wide tile's
+    // LDS reuse (0.45 instead of 0.7 fragment reads per MFMA) outweighs its doubled atomic traffic -- measured over the stack:
+    // 16 images 533 -> 596 us (32-wide stays), 64 images 1651 -> 1423, 128 images 3162 -> 2662, 64 images of 512x640 5854 -> 4775
+    // (profiles/r3_tuning_check.md)
+    const long walk = (long)k.ntiles * ((k.g.C[0] + k.g.C[1]) / (ng * G)) * ((k.Cout + 63) / 64) / 256;
+    if (k.Cout >= 64 && (mt_max >= 4 || walk >= TUNE(wgrad_mt4_min_walk))) return launch_wgrad_ng<T, 4>(k, ng, s);
     if (k.Cout >= 32 && mt_max >= 2 && !one_chunk) return launch_wgrad_ng<T, 2>(k, ng, s);
     return launch_wgrad_ng<T, 1>(k, ng, s);
 }

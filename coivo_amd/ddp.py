@@ -61,10 +61,10 @@ class GradBuckets:
             # active hardware queues as this GPU schedules well.  With the library's second side stream on top the step measured
             # 5.2 ms instead of 1.7 (bench.py --rccl-single): the claim keeps the weight gradients on ONE
             # side stream while this object is attached (streams.py; detach() gives the queue back).
-            from . import streams
+            from . import _lib, streams
             if dist.get_backend(process_group) == "nccl":
                 streams.check_environment(self.world)
-            if os.environ.get("COLVO_DDP_KEEP_AUX") is None:        # A/B switch
+            if _lib.dev_env("COLVO_DDP_KEEP_AUX") is None:        # developer A/B switch (COLVO_DEV=1)
                 self._queue_claim = streams.claim_external_queue("rccl")
         self.transport_dtype = transport_dtype
         self.states: List[_ArenaState] = []

@@ -17,7 +17,7 @@ SSIM_WEIGHT = 0.85
 # Training calls (any of depth / pose / lcc_a / lcc_b requires grad) compute the loss AND its unnormalised gradients in
 # one pass (colvo_warp_loss_fused); backward then only applies dL/dloss / max(3 n_valid, 1).  COLVO_LOSS_UNFUSED=1 keeps
 # the two-pass form (forward kernel, then a backward kernel that re-evaluates the warp).
-FUSE_TRAINING_PASS = os.environ.get("COLVO_LOSS_UNFUSED") is None
+FUSE_TRAINING_PASS = _lib.dev_env("COLVO_LOSS_UNFUSED") is None        # developer switch (COLVO_DEV=1)
 
 # Optional kernel timing for bench.py: when enabled, every fused-op call is bracketed by HIP events recorded on
 # the stream the kernels are launched on (PyTorch's current stream), immediately around the C-ABI call.

@@ -28,12 +28,12 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .program import Program
 
 # weight-gradient stream: high priority (-1) -- it is the longer of the two chains of the backward pass (measured ~0.4 %
 # of the step against normal priority, 0)
-_SIDE_PRIORITY = int(os.environ.get("COLVO_SIDE_PRIORITY", "-1"))
+_SIDE_PRIORITY = int(_lib.dev_env("COLVO_SIDE_PRIORITY", "-1"))
 
 ENC_CH = (32, 64, 128, 256, 512)
 DEC_CH = (16, 32, 64, 128, 256)
@@ -75,14 +75,14 @@ class _ArenaModule(nn.Module):
         self._side = None
         self._plans = {}
         self._insts: Dict[tuple, List["_PassInst"]] = {}     # recorded programs + their activation buffers, per shape
-        self.use_programs = os.environ.get("COLVO_NO_PROGRAM") is None
+        self.use_programs = _lib.dev_env("COLVO_NO_PROGRAM") is None           # developer switches: COLVO_DEV=1 only
         self._rec: Optional[Program] = None
-        self.overlap_wgrad = os.environ.get("COLVO_NO_OVERLAP") is None
+        self.overlap_wgrad = _lib.dev_env("COLVO_NO_OVERLAP") is None
         # defer_join: the main stream does not wait for this network's weight gradients at the end of ITS backward node but
         # at the end of the whole backward pass (an autograd-engine callback), so the nodes that follow are enqueued in
         # between.  PoseNet's backward sits on the critical path in front of DepthNet's: only its input-gradient chain has
         # to finish before DepthNet's backward may start; its weight gradients then run beside DepthNet's kernels.
-        self.defer_join = os.environ.get("COLVO_NO_DEFER_JOIN") is None
+        self.defer_join = _lib.dev_env("COLVO_NO_DEFER_JOIN") is None
         self._join_pending = False
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
         # deterministic: weight gradients through per-split slabs + fixed-order second launches instead of float atomics
@@ -631,7 +631,7 @@ class PoseNet(_ArenaModule):
         self.pred = ConvParams(cin, 8, 1)
         # 7 tiny layers: driven from Python the fork/join bookkeeping costs more than it hides; recorded it is free.
         # With a deferred join (FusedAdam) only the input-gradient chain stays in front of DepthNet's backward.
-        self.overlap_wgrad = self.overlap_wgrad and self.use_programs and os.environ.get("COLVO_NO_POSE_OVERLAP") is None
+        self.overlap_wgrad = self.overlap_wgrad and self.use_programs and _lib.dev_env("COLVO_NO_POSE_OVERLAP") is None
         self._build_arena(torch.device(device))
 
     def forward(self, tgt, ref, tgt_depth: Optional[torch.Tensor] = None, ref_depth: Optional[torch.Tensor] = None):

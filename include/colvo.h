@@ -324,6 +324,12 @@ int colvo_set_aux_side_streams(int n);
  * parent's stream and opens a stream per further child. */
 int colvo_set_capture_policy(int policy, int group);
 
+/* Dispatch thresholds (coivo_amd/csrc/tuning.h: ONE table, defaults measured on MI355X; production reads no environment
+ * variable).  Developer / test hooks: set or read an entry by name ("quad_min_wgs", "wgrad_atomic_mb", ...); with COLVO_DEV=1 in
+ * the environment at load time every entry can also be overridden by COLVO_<UPPER-CASE NAME>. */
+int colvo_tune_set(const char* name, double value);
+int colvo_tune_get(const char* name, double* value);
+
 #ifdef __cplusplus
 }
 #endif

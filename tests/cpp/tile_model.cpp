@@ -8,6 +8,9 @@
 #include <utility>
 #include <vector>
 
+#include "../../coivo_amd/csrc/tuning.h"      // the thresholds the model reads (plain C++)
+using namespace colvo;
+
 #include TILE_MODEL_SNIPPET      // the Tile struct, patch_read_conflicts() and pick_tile(), cut out of conv_common.h by the test
 
 int main(int argc, char** argv) {

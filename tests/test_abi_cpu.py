@@ -87,3 +87,33 @@ def test_product_package_does_not_import_the_oracle():
     for f in ("nn.py", "functional.py", "optim.py", "ops.py", "ddp.py", "synth.py", "_lib.py", "build.py"):
         txt = open(os.path.join(pkg, f)).read()
         assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M)
+
+
+def test_tuning_table_hooks_and_no_stray_getenv(lib):
+    """One table of dispatch thresholds (csrc/tuning.h): entries can be read / set by name, unknown names fail loudly, and no
+    kernel source reads an environment variable of its own (the developer-build ablation switches excepted)."""
+    from coivo_amd import _lib
+    assert _lib.tune_get("bn64_min_wgs") == 1024 and _lib.tune_get("wgrad_atomic_mb") == 3
+    _lib.tune_set("quad_min_wgs", 7)
+    assert _lib.tune_get("quad_min_wgs") == 7
+    _lib.tune_set("quad_min_wgs", 2048)
+    assert lib.colvo_tune_set(b"no_such_entry", 1.0) != 0 and b"no tuning entry" in lib.colvo_last_error()
+    csrc = os.path.join(ROOT, "coivo_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f == "tuning.h":
+            continue
+        for line in open(os.path.join(csrc, f)):
+            if "getenv(" in line:
+                assert "COLVO_ABL" in line or "COLVO_TRACE" in line, f"{f}: {line.strip()}"
+    # the Python side honours its developer switches only under COLVO_DEV=1
+    os.environ["COLVO_TEST_SWITCH"] = "x"
+    dev = os.environ.pop("COLVO_DEV", None)
+    try:
+        assert _lib.dev_env("COLVO_TEST_SWITCH") is None
+        os.environ["COLVO_DEV"] = "1"
+        assert _lib.dev_env("COLVO_TEST_SWITCH") == "x"
+    finally:
+        os.environ.pop("COLVO_TEST_SWITCH")
+        os.environ.pop("COLVO_DEV", None)
+        if dev is not None:
+            os.environ["COLVO_DEV"] = dev

@@ -91,14 +91,21 @@ def _close(got, ref, rtol, atol_scale, what):
 
 
 @pytest.fixture(autouse=True)
-def _both_kernel_forms(request, monkeypatch):
+def _both_kernel_forms(request):
     """The fat-workgroup kernels (k_conv_q: quad tiles for stride-1 layers; k_dgrad_up2: sum-pool in the K loop) are selected
-    only for large grids (>= 2048 / 640 workgroups); the parametrised cases are small, so half of the runs lower the thresholds to
-    reach them (the other half exercises the one-tile kernels on the same shapes)."""
+    only for large grids (>= 2048 / 640 workgroups); the parametrised cases are small, so half of the runs lower the thresholds
+    in the library's tuning table (colvo_tune_set, csrc/tuning.h) to reach them -- the other half exercises the one-tile kernels
+    on the same shapes."""
+    from coivo_amd import _lib
+    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks")
+    saved = {n: _lib.tune_get(n) for n in names}
     if "form1" in request.node.name:
-        monkeypatch.setenv("COLVO_DGRAD_UP2_MIN_WGS", "0")
-        monkeypatch.setenv("COLVO_QUAD_MIN_WGS", "0")
-        monkeypatch.setenv("COLVO_QUAD_MAX_CHUNKS", "64")
+        _lib.tune_set("dgrad_up2_min_wgs", 0)
+        _lib.tune_set("quad_min_wgs", 0)
+        _lib.tune_set("quad_max_chunks", 64)
+    yield
+    for n, v in saved.items():
+        _lib.tune_set(n, v)
 
 
 @pytest.mark.parametrize("form", ["form0", "form1"])
