@@ -25,7 +25,7 @@ f = newest(f"{SRC}/bench_trace/*/*_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 with open(f"profiles/{R}_bench_kernel_stats.csv", "w", newline="") as o:
     w = csv.writer(o)
-    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline (25 steps + cfg2 roofline probe)"])
+    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline: 25 fast-path steps (5 warm-up + 20 timed), 23 steps of the spec call sequence (bench.py's spec_sequence_ms side measurement: 3 + 20) and the configs[2] roofline probe of the fused loss (25 launches)"])
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"].replace("colvo::(anonymous namespace)::", "")[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
