@@ -218,18 +218,50 @@ def roofline_cfg2(dev):
     hand, hand_p = Fh.GradHandover(), Fh.GradHandover()
     depth._colvo_handover = hand
     pose._colvo_handover = a._colvo_handover = bb._colvo_handover = hand_p
-    Fh.enable_timing(True)
-    for it in range(25):
+    def one():
         loss = Fh.photometric_loss(tgt, ref, depth, pose, K, a, bb)
         g_raw, gp, ga, gb = torch.autograd.grad(loss, [depth, pose, a, bb])
         hand.take((g_raw,))
         hand_p.take((gp, ga, gb))
+
+    Fh.enable_timing(True)
+    for it in range(25):
+        one()
     torch.cuda.synchronize()
     ev = Fh.timing_events()
     tf = sorted(e0.elapsed_time(e1) for e0, e1 in ev["fwd"][5:])
     tb = sorted(e0.elapsed_time(e1) for e0, e1 in ev["bwd"][5:])
     Fh.enable_timing(False)
-    f_ms, b_ms = tf[len(tf) // 2], tb[len(tb) // 2]
+    f_single_ms, b_ms = tf[len(tf) // 2], tb[len(tb) // 2]
+    # The op's duration proper: NB C-ABI calls back to back between ONE pair of events on the launch stream (the host enqueues a
+    # call in microseconds, the GPU needs ~0.19 ms: the queue never runs dry), divided by NB.  A bracket around every single call adds the two
+    # event records and the launch gap behind an idle queue to each sample (~12 us here: fwd_us_single_bracket) -- rocprofv3's
+    # average for the march kernel + finalize (profiles/r3_bench_kernel_stats.csv, r3_traffic.json) agrees with THIS figure.
+    NB = 20
+    from coivo_amd import _lib
+    lib = _lib.load()
+    f32 = dict(device=dev, dtype=torch.float32)
+    ws = torch.empty(lib.colvo_warp_loss_workspace_floats(B, H, W), **f32)
+    state, d_raw = torch.empty(4, **f32), torch.empty(B, 1, H, W, **f32)
+    gpart, gunit = torch.empty(B * 14, **f32), torch.empty(B * 8, **f32)
+    dd, pp, aa, b2 = depth.detach(), pose.detach(), a.detach(), bb.detach()
+    sp = torch.cuda.current_stream().cuda_stream
+
+    def call():         # exactly the C-ABI call functional._WarpLoss.forward makes (the one the single brackets sit around)
+        _lib.check(lib.colvo_warp_loss_fused(_lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(dd), _lib.ptr(pp), _lib.ptr(K), _lib.ptr(aa),
+                                             _lib.ptr(b2), B, H, W, Fh.SSIM_WEIGHT, _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw),
+                                             _lib.ptr(gpart), _lib.ptr(gunit), sp), "colvo_warp_loss_fused")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e0.record()
+        for it in range(NB):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        reps.append(e0.elapsed_time(e1) / NB)
+    f_ms = sorted(reps)[1]
     px = B * H * W
     # the backward call launches NOTHING (gradient handover): the op's duration is the forward call's; the bracket around the
     # empty backward measures the two event records themselves (~4.5 us, reported as bwd_us) and is not a kernel duration
@@ -238,15 +270,16 @@ def roofline_cfg2(dev):
             "workload": f"B={B} {W}x{H} fp32, 1 warp direction", "bwd_launches": 0,
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic("B=32 640x512 (configs[2])"),
-            "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3, "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px,
-            "real_bytes": LOSS_REAL_BYTES_PER_PIXEL * px,
+            "fwd_us": f_ms * 1e3, "fwd_us_single_bracket": f_single_ms * 1e3, "bwd_us": b_ms * 1e3,
+            "algorithmic_bytes": LOSS_BYTES_PER_PIXEL * px, "real_bytes": LOSS_REAL_BYTES_PER_PIXEL * px,
             "achieved_real_bytes": LOSS_REAL_BYTES_PER_PIXEL * px / (f_ms * 1e-3) / 1e9,
             "frac_real_bytes": LOSS_REAL_BYTES_PER_PIXEL * px / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "timing": "hip events on the launch stream directly around each C-ABI call (forward = one-pass loss + unnormalised "
-                      "gradients + finalize; backward launches nothing -- all four gradients are handed to their consumers, the "
-                      "depth / pose head backward kernels, unnormalised with two device scalars, as in the training step: "
-                      "bwd_us is the cost of the two event records around no launch and is NOT part of `achieved`, which is "
-                      "algorithmic bytes / fwd_us; fwd_us itself still contains one such event pair), median of 20 launches"}
+            "timing": "fwd_us: 20 calls of the op back to back between ONE pair of hip events on the launch stream, / 20, median of 3 "
+                      "repetitions (forward call = one-pass loss + unnormalised gradients + finalize; the backward call launches "
+                      "nothing -- all four gradients are handed to their consumers, the depth / pose head backward kernels, "
+                      "unnormalised with two device scalars, as in the training step).  fwd_us_single_bracket: the round-1/2 "
+                      "protocol, an event pair around every single call (adds the two event records and the launch gap behind an "
+                      "idle queue); bwd_us: such a pair around the empty backward call = the cost of the bracket itself"}
 
 
 def workload_name(args, B, H, W):
@@ -293,17 +326,40 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(*plan["device"])
 
+    import contextlib
     import torch.distributed as dist
-    if args.rccl_single and world == 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", plan["master_addr"])
-        kw = dict(plan["init_kwargs"])
-        if "device_id" in kw:
-            kw["device_id"] = dev
-        dist.init_process_group(plan["backend"], **kw)
+
+    @contextlib.contextmanager
+    def stdout_to_stderr():
+        """RCCL prints a version banner on STDOUT when its first communicator is created; stdout carries exactly one JSON line
+        (the driver parses it), so the file descriptor points at stderr while the communicator comes up."""
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            yield
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
+    with stdout_to_stderr():
+        if args.rccl_single and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", plan["master_addr"])
+            kw = dict(plan["init_kwargs"])
+            if "device_id" in kw:
+                kw["device_id"] = dev
+            dist.init_process_group(plan["backend"], **kw)
+        if dist.is_initialized():
+            # the first collective creates the communicator (and prints the banner): do it here, on a throw-away tensor
+            t0_ = torch.zeros(1, device=dev if plan["backend"] != "gloo" or args.rccl_single else "cpu")
+            dist.all_reduce(t0_)
+            if t0_.is_cuda:
+                torch.cuda.synchronize()
 
     from coivo_amd import build as _colvo_build      # fresh checkout / edited kernels: (re)build in-tree, rank 0 first
     if local_rank == 0:
@@ -462,7 +518,7 @@ def main():
     if ddp is not None and not use_graph:
         # scaling = fps(N GPUs, b pairs each) / fps(1 GPU, b pairs).  The denominator, measured here on
         # this rank's GPU: the same step at the same per-GPU batch with the gradient exchange detached.
-        ddp.detach()
+        ddp.pause()          # hooks off, but the communicator's hardware queue stays claimed (coivo_amd/streams.py)
         scale_was, opt.grad_scale = opt.grad_scale, 1.0
         ms1 = timed_run(fast_step, min(args.steps, 20))
         side["single_gpu_same_batch"] = {"pairs_per_gpu": B, "ms_per_step": ms1, "value": B / (ms1 * 1e-3),

@@ -136,6 +136,19 @@ class GradBuckets:
         for st in self.states:
             st.next, st.low, st.calls = 1, st.module.flat_grad.numel(), 0
 
+    def pause(self) -> None:
+        """Take the hooks off the networks (steps then run without any gradient exchange) but keep the communicator's hardware
+        queue claimed: the communicator still exists.  resume() puts them back."""
+        self._paused_hooks = [st.module.grad_ready_hook for st in self.states]
+        for st in self.states:
+            st.module.grad_ready_hook = None
+        self.attached = False
+
+    def resume(self) -> None:
+        for st, h in zip(self.states, getattr(self, "_paused_hooks", [])):
+            st.module.grad_ready_hook = h
+        self.attached = True
+
     def detach(self) -> None:
         """Unhook from the networks and give the communicator's hardware queue back to the stream policy."""
         for st in self.states:
