@@ -23,7 +23,11 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--rccl-single" in sys.argv:
     # runtime's default of 4 queues the side stream landed on the main stream's queue once the communicator existed and the
     # backward pass serialised (1.96 ms per step against 1.68 with 8 queues, one rank through the RCCL path).  Read at HIP
     # initialisation, so it has to be in the environment before torch is imported.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    try:
+        if int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) < 8:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    except ValueError:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 import torch
 
