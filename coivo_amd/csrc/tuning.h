@@ -44,6 +44,7 @@ namespace tune {
     X(lds_aware_tiles, 1, "tile shapes / padded LDS row pitch chosen against ds_read_b128 bank conflicts")                          \
     X(lds_tile_max_pad, 8, "... at most this many padding pixels per patch row")                                                    \
     /* ---- weight gradient (wgrad.hip) ---- */                                                                                     \
+    X(wgrad_up2, 1, "weight gradient of up-sampled layers in the four-class form (16 instead of 36 products, k_wgrad_up2)")          \
     X(wgrad_mt_max, 2, "output-channel tile = 16 x this (32-wide measured better than 64 on every layer at 16 images)")             \
     X(wgrad_mt4_min_walk, 24, "... but 64-wide from this many pixel tiles per workgroup (at a 256-workgroup grid) on")              \
     X(wgrad_ng_max, 4, "16-byte channel granules per chunk")                                                                        \

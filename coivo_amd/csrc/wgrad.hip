@@ -495,6 +495,295 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     return wgrad_finish(k, nsplit, s);
 }
 
+// --------------------------------------------------------------------------------------------- //
+// weight gradient of a conv over a nearest-2x UP-SAMPLED source: four output classes, 16 products   //
+// --------------------------------------------------------------------------------------------- //
+// y[2a+py][2b+px] = sum_{ky,kx} w[ky][kx] x[a + r(py,ky)][b + r(px,kx)] with r(0,.) = (-1, 0, 0), r(1,.) = (0, 0, +1): the 3x3 taps of
+// an output pixel of parity class (py, px) fall on only 2x2 source pixels.  So
+//     dw[ky][kx] = sum_{py,px} dW'[py][px][rho(py,ky)][rho(px,kx)],   rho(0,.) = (0, 1, 1),  rho(1,.) = (0, 0, 1),
+//     dW'[py][px][r][c] = sum_{a,b} dy[2a+py][2b+px] (x) x[a+py+r-1][b+px+c-1]
+// -- 4 classes x 4 source taps = 16 products over the SOURCE positions instead of 9 taps over four times as many output pixels:
+// 2.25 x fewer MFMAs.  The general kernel stages, per 512 output pixels, four dY tiles and four gathered 10x18-pixel patches of the
+// virtual up-sampled image; here a workgroup takes a tile of <= 128 source positions, stages their four dY class planes and ONE
+// (toh+2) x (tow+2) patch of real source pixels (-44 % staged bytes), and wave w owns class w: per 32-position k-step it reads MT dY
+// fragments and 4 taps x CK/16 patch fragments for 4 * CK/16 * MT MFMAs (0.4-0.6 LDS fragment reads per MFMA instead of 0.7).
+// At the end the four classes meet in LDS -- each dW' entry is added to the 1, 2 or 4 taps it stands for, one wave at a time -- and
+// the workgroup adds its [9][16 MT][CK] block to dw exactly like k_wgrad3x3 (fp32 atomics, or this split's slab in the deterministic
+// form).  Grid, pixel-range splits and XCD order as in k_wgrad3x3 (tiles run over source positions).
+template <typename T, int MT>
+__global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
+    constexpr int G = TT<T>::G, ES = TT<T>::ES;
+    constexpr int NG = 4, CK = NG * G;               // 32 bf16 / 16 f32 channels per chunk
+    constexpr int NCF = CK / 16;                     // column fragments per source tap
+    constexpr int NACC = 4 * NCF;                    // accumulators per dY fragment: 4 source taps x NCF
+    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int DYP = dy_pitch<T, MT>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = output parity class
+    const int cpy = cls >> 1, cpx = cls & 1;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
+    const int per_split = gridDim.x / a.nsplit;
+    const int bsplit = lid / per_split, brem = lid - bsplit * per_split;
+    const int bchunk = brem / a.cot, bco = brem - bchunk * a.cot;
+    const int co0 = bco * 16 * MT;
+    const int c0 = bchunk * CK;                      // single source: channel offset = weight column offset
+    const int PH = a.toh + 2, PW = a.tow + 2;        // patch of SOURCE pixels: tile + 1 each side
+    const int npix = a.toh * a.tow;
+    char* sDY = smem;                                // [4 classes][BM][16 MT]
+    char* sX = smem + 4 * BM * DYP;                  // [PH * PW][CK]
+
+    f32x4 acc[MT][NACC];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) acc[mi][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc = 0.0f;
+
+    const int t_begin = bsplit * a.tiles_per_split;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    constexpr int DGR = 16 * MT / G;                 // dY granules per (class, position)
+    constexpr int DIT = 4 * BM * DGR / NT;
+    constexpr int PPF = 3;                           // patch <= 10 x 18 positions x 4 granules
+    const int ptotal = PH * PW * NG;
+    u32x4 dyv[DIT], pv[PPF];
+    struct TileC { int b, ty, tx; };
+    auto tile_next = [&](TileC& c) {
+        if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.b; } }
+    };
+    TileC cur;
+    {
+        const int t = __builtin_amdgcn_readfirstlane(t_begin);
+        cur.b = t / tiles_per_img;
+        const int tr_ = t - cur.b * tiles_per_img;
+        cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
+    }
+    const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
+    const long long dy_bytes = (long long)a.B * a.Ho * a.Wo * a.Cout * ES;
+    const long long x_bytes = (long long)a.B * Hs * Ws * Cs * ES;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(dy_bytes < 0x7fffffffLL ? dy_bytes : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.g.src[0], 0, (int)(x_bytes < 0x7fffffffLL ? x_bytes : 0x7fffffffLL), 0x00020000);
+
+    int dy_off[DIT], dy_yx[DIT], dy_lds[DIT];
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+        const int i = it * NT + tid;
+        const int c4 = i / (BM * DGR), rem = i - c4 * (BM * DGR);
+        const int pos = rem / DGR, gch = rem - pos * DGR;
+        const int oy = mdiv(pos, a.m_tow), ox = pos - oy * a.tow;
+        const bool ok = (pos < npix) && (co0 + gch * G < a.Cout);
+        dy_off[it] = ok ? (((2 * oy + (c4 >> 1)) * a.Wo + 2 * ox + (c4 & 1)) * a.Cout + co0 + gch * G) * ES : OOB_OFF;
+        dy_yx[it] = (oy << 16) | ox;
+        dy_lds[it] = (c4 * BM + pos) * DYP + gch * 16;
+    }
+    int p_yx[PPF], p_cg[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int pix = i / NG;
+        p_cg[it] = i - pix * NG;
+        const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
+        p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
+    }
+    auto load_tile = [&](const TileC& c) {
+        const int oy0 = c.ty * a.toh, ox0 = c.tx * a.tow;
+        {
+            const int base = ((c.b * a.Ho + 2 * oy0) * a.Wo + 2 * ox0) * a.Cout * ES;      // wave-uniform: the scalar offset
+            const int remy = Hs - oy0, remx = Ws - ox0;
+            if (remy >= a.toh && remx >= a.tow) {
+#pragma unroll
+                for (int it = 0; it < DIT; ++it) dyv[it] = bld16(rdy, dy_off[it], base);
+            } else {
+#pragma unroll
+                for (int it = 0; it < DIT; ++it) {
+                    const bool ok = ((dy_yx[it] >> 16) < remy) && ((dy_yx[it] & 0xffff) < remx);
+                    dyv[it] = bld16(rdy, ok ? dy_off[it] : OOB_OFF, base);
+                }
+            }
+        }
+        const int base = c.b * Hs * Ws * Cs * ES;
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int vy = oy0 - 1 + (p_yx[it] >> 16), vx = ox0 - 1 + (p_yx[it] & 0xffff);
+            const bool inb = ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
+            pv[it] = bld16(rx, inb ? ((vy * Ws + vx) * Cs + c0 + p_cg[it] * G) * ES : OOB_OFF, base);
+        }
+    };
+    constexpr int NPH = NT / (16 * MT);
+    const int db_co = tid % (16 * MT), db_ph = tid / (16 * MT);
+
+    if (t_begin < t_end) load_tile(cur);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) st16(sDY + dy_lds[it], dyv[it]);
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int i = it * NT + tid;
+            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
+        }
+        __syncthreads();
+        tile_next(cur);
+        if (t + 1 < t_end) load_tile(cur);             // in flight during the MFMAs below
+
+        if (bchunk == 0 && a.db) {                     // bias gradient: all four class planes (rows beyond the tile hold zeros)
+            float s0 = 0.0f;
+#pragma unroll 4
+            for (int p = db_ph; p < 4 * BM; p += NPH) {
+                if constexpr (ES == 2) s0 += bf2f(*reinterpret_cast<const uint16_t*>(sDY + p * DYP + db_co * 2));
+                else s0 += *reinterpret_cast<const float*>(sDY + p * DYP + db_co * 4);
+            }
+            dbacc += s0;
+        }
+
+        const char* sDYc = sDY + cls * BM * DYP;
+        if constexpr (ES == 2) {
+            const int q = l15 >> 2, pp = lane & 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                int xo[2], yo[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;       // K position -> tile position (see k_wgrad3x3)
+                    yo[h] = p * DYP;
+                    if (p >= npix) p = 0;                                              // its dY rows are zero
+                    const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+                    xo[h] = ((oy + cpy) * PW + ox + cpx) * PIXP;                       // source tap (0, 0) of this class
+                }
+                s16x8 af[MT];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sDYc + yo[0] + (16 * mi + 4 * pp) * 2));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)(sDYc + yo[1] + (16 * mi + 4 * pp) * 2));
+                    af[mi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                    for (int f = 0; f < NCF; ++f) {
+                        const int bo = ((tp >> 1) * PW + (tp & 1)) * PIXP + (16 * f + 4 * pp) * 2;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + bo));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + bo));
+                        const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            acc[mi][tp * NCF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf), acc[mi][tp * NCF + f], 0, 0, 0);
+                    }
+            }
+        } else {
+            int p = kg;
+            int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
+            for (int ks = 0; ks < BM / 4; ++ks) {
+                const bool live = p < npix;
+                const int xo = live ? ((oy + cpy) * PW + ox + cpx) * PIXP : 0;
+                float av[MT];
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) av[mi] = *reinterpret_cast<const float*>(sDYc + p * DYP + (16 * mi + l15) * 4);
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+                    for (int f = 0; f < NCF; ++f) {
+                        const float bvv = *reinterpret_cast<const float*>(sX + xo + ((tp >> 1) * PW + (tp & 1)) * PIXP + (16 * f + l15) * 4);
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+                            acc[mi][tp * NCF + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bvv, acc[mi][tp * NCF + f], 0, 0, 0);
+                    }
+                p += 4; ox += 4;
+                while (ox >= a.tow) { ox -= a.tow; ++oy; }
+            }
+        }
+    }
+
+    mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * NACC]>(acc));
+    // ---- the four classes meet: red[tap][co][c] += dW'[class][r][c'] for every tap the entry stands for, one wave at a time ----
+    __syncthreads();                                   // staging buffers are free
+    float* red = reinterpret_cast<float*>(smem);       // [9][16 MT][CK]
+    constexpr int RED = 9 * 16 * MT * CK;
+    for (int i = tid; i < RED; i += NT) red[i] = 0.0f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (cls == w) {
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const int r = tp >> 1, c = tp & 1;
+                // taps whose source offset is (r, c) for this class: rows {0} | {1, 2} for py = 0, {0, 1} | {2} for py = 1
+                const int ky_lo = cpy == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), ky_hi = cpy == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+                const int kx_lo = cpx == 0 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kx_hi = cpx == 0 ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
+                for (int ky = ky_lo; ky <= ky_hi; ++ky)
+                    for (int kx = kx_lo; kx <= kx_hi; ++kx) {
+                        float* rt = red + (size_t)(ky * 3 + kx) * 16 * MT * CK;
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                            for (int f = 0; f < NCF; ++f)
+#pragma unroll
+                                for (int rr = 0; rr < 4; ++rr)
+                                    rt[(16 * mi + 4 * kg + rr) * CK + 16 * f + l15] += acc[mi][tp * NCF + f][rr];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < RED; i += NT) {
+        const int tap = i / (16 * MT * CK), rem = i - tap * (16 * MT * CK);
+        const int col = rem / CK, c = rem - col * CK;
+        const int co = co0 + col;
+        if (co < a.Cout) {
+            const size_t e = (size_t)co * 9 * a.Ctot + (size_t)tap * a.Ctot + c0 + c;
+            if (a.slabs) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e] = red[i];
+            else atomicAdd(a.dw + e, red[i]);
+        }
+    }
+    if (bchunk == 0 && a.db) {
+        __syncthreads();
+        float* sdb = reinterpret_cast<float*>(smem);
+        sdb[tid] = dbacc;
+        __syncthreads();
+        if (tid < 16 * MT && co0 + tid < a.Cout) {
+            float t = 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
+            if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else atomicAdd(a.db + co0 + tid, t);
+        }
+    }
+}
+
+template <typename T, int MT>
+int launch_wgrad_up2(WgradK k, hipStream_t s) {
+    constexpr int G = TT<T>::G, CK = 4 * G, PIXP = pitch_bytes(64), DYP = dy_pitch<T, MT>();
+    const size_t lds = std::max((size_t)4 * BM * DYP + (size_t)(k.toh + 2) * (k.tow + 2) * PIXP, (size_t)9 * 16 * MT * CK * 4) + 64;
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad (up-sampled source): tile needs %zu bytes of LDS", lds);
+    static size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured && !k.plan_out) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_up2<T, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("wgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = 160 * 1024;
+    }
+    const int chunks = k.g.C[0] / CK;
+    const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
+    const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
+    const int per_split = chunks * cot;
+    int nsplit = (int)(TUNE_F(wgrad_atomic_mb) * 1e6 / wbytes);
+    const int lo = ((int)TUNE(wgrad_wg_lo) + per_split - 1) / per_split, hi = ((int)TUNE(wgrad_wg_hi) + per_split - 1) / per_split;
+    if (nsplit > hi) nsplit = hi;
+    if (nsplit < lo) nsplit = lo;
+    if (nsplit > k.ntiles) nsplit = k.ntiles;
+    if (nsplit < 1) nsplit = 1;
+    k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
+    nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
+    k.nsplit = nsplit; k.cot = cot; k.xcd = (int)TUNE(xcd_remap);
+    { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
+    hipLaunchKernelGGL((k_wgrad_up2<T, MT>), dim3((unsigned)(nsplit * cot * chunks)), dim3(NT), lds, s, k);
+    COLVO_CHECK_LAUNCH("k_wgrad_up2");
+    return wgrad_finish(k, nsplit, s);
+}
+
 template <typename T, int MT, int NG>
 int launch_wgrad(const WgradK& k, hipStream_t s) {
     const int S = k.g.stride;
@@ -600,6 +889,24 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
     k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
     k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
     k.scratch = (const char*)scratch; k.scratch_bytes = scratch ? (long long)scratch_bytes : 0; k.plan_out = plan_out;
+    {
+        // single up-sampled source in whole 32-channel (bf16) / 16-channel (f32) chunks: the four-class form over source positions
+        const int ck = d->dtype == COLVO_F32 ? 16 : 32;
+        if (TUNE(wgrad_up2) && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->Cout >= 16) {
+            const int Hs = d->Hi / 2, Ws = d->Wi / 2;
+            const Tile t = pick_tile(Hs, Ws, 1, false);
+            if ((t.toh + 2) * (t.tow + 2) * 4 <= 3 * NT) {
+                k.toh = t.toh; k.tow = t.tow;
+                k.tiles_x = (Ws + t.tow - 1) / t.tow; k.tiles_y = (Hs + t.toh - 1) / t.toh;
+                k.ntiles = d->B * k.tiles_x * k.tiles_y;
+                k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 2);
+                hipStream_t s = (hipStream_t)stream;
+                const bool wide = d->Cout >= 32;
+                if (d->dtype == COLVO_F32) return wide ? launch_wgrad_up2<float, 2>(k, s) : launch_wgrad_up2<float, 1>(k, s);
+                return wide ? launch_wgrad_up2<bf16_t, 2>(k, s) : launch_wgrad_up2<bf16_t, 1>(k, s);
+            }
+        }
+    }
     const Tile t = pick_tile(d->Ho, d->Wo, d->stride, false);
     k.toh = t.toh; k.tow = t.tow;
     k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
