@@ -33,7 +33,7 @@ for grp in ("sq1", "sq2", "tcp", "tcc"):
 
 out = []
 for (name, grid, lds), c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("duration_ns", [0]))):
-    if not (name.startswith("k_conv3x3") or name.startswith("k_wgrad3x3")):
+    if not name.startswith(("k_conv", "k_wgrad", "k_dgrad")):       # every conv-stack kernel form
         continue
     m = {k: sum(v) / len(v) for k, v in c.items()}
     if not m.get("duration_ns"):
