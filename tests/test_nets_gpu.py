@@ -228,3 +228,32 @@ def test_fused_adam_step_counter_survives_state_dict():
         o.step()
     assert torch.equal(nets[0].flat_param, nets[1].flat_param)
     assert int(restored.state_dict()["state"][0]["step"].item()) == 3
+
+
+def test_zero_grad_is_ordered_with_both_backward_streams():
+    """The gradient arena's memset must be ordered before the weight gradients of the next backward pass on EVERY stream that
+    writes them, and a reader that joins (optimizer, join_side) must see the zeros.  Poison the arena before every zero_grad();
+    deterministic mode makes 'same gradients' an exact comparison.  (Written for an experiment that moved the memset to the side
+    stream -- measured 1 % slower, DESIGN.md section 3.2 -- and kept as the guard of that ordering.)"""
+    from coivo_amd import nn as hnn
+    _, _, dn, pn = _models(9)
+    dn.deterministic = pn.deterministic = True
+    d = to_dev(synth.make_batch(2, 64, 96, seed=9))
+
+    def grads():
+        loss = hnn.dcdp_forward(dn, pn, d["tgt"], d["ref"], d["K"])[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return dn.flat_grad.clone(), pn.flat_grad.clone()
+
+    dn.zero_grad(); pn.zero_grad()
+    ref = grads()                                   # first backward creates the side streams
+    for _ in range(3):
+        dn.flat_grad.fill_(1e3); pn.flat_grad.fill_(-1e3)
+        dn.zero_grad(); pn.zero_grad()
+        got = grads()
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    dn.flat_grad.fill_(7.0)
+    dn.zero_grad()
+    dn.join_side()                                  # what FusedAdam.step() does before it reads the arena
+    assert float(dn.flat_grad.abs().max()) == 0.0
