@@ -417,7 +417,7 @@ def main():
     def fast_step():
         opt.zero_grad()
         if args.full_loss:
-            loss = hnn.dcdp_forward(dn, pn, tgt, ref, K, full_loss=True)[0]
+            loss = hnn.dcdp_forward(dn, pn, None, None, K, full_loss=True, frames=frames)[0]
         else:
             d_t, d_r, d_l = dn.forward_pair_split(frames)     # d_l: depth_t again, the loss's own gradient path (nn.py)
             pose, a, b = pn(tgt, ref, d_t, d_r)

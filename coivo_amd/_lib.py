@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -52,6 +52,10 @@ SIGNATURES = {
     "colvo_smooth_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "colvo_avgpool2_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "colvo_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "colvo_full_objective_workspace_floats": (_sz, [_i, _i, _i, _i]),
+    "colvo_full_objective_fwd": (_i, [_vp] * 8 + [_i] * 4 + [_f] * 3 + [_vp] * 3),
+    "colvo_full_objective_bwd": (_i, [_vp] * 3 + [_i] * 4 + [_f, _f] + [_vp] * 6),
+    "colvo_full_objective_terms": (_i, [_vp, _i, _i, _i, _i, C.POINTER(_vp)]),
     "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "colvo_conv_dgrad_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -69,7 +73,7 @@ SIGNATURES = {
     "colvo_depth_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_depth_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "colvo_depth_head_wgrad": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "colvo_depth_head_bwd_parts": (_i, [_i] + [_vp] * 8 + [_i, _i, _i, _i, _f, _f] + [_vp] * 5),
+    "colvo_depth_head_bwd_parts": (_i, [_i] + [_vp] * 9 + [_i, _i, _i, _i, _f, _f] + [_vp] * 5),
     "colvo_pose_head_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),

@@ -321,9 +321,11 @@ __global__ __launch_bounds__(NT) void k_depth_head_dpre(const float* __restrict_
     if (i < n) dpre[i] = head_dpre(depth[i], d_depth[i], lo, hi);
 }
 
-// the same with the incoming gradient in parts: first half of the images g0 + sa*sb*graw, second half g1 (any may be null)
+// the same with the incoming gradient in parts: first half of the images g0 + sa*sb*graw, second half g1 + sa*sb*graw1
+// (any may be null)
 __global__ __launch_bounds__(NT) void k_depth_head_dpre_parts(const float* __restrict__ depth, const float* __restrict__ g0,
                                                               const float* __restrict__ g1, const float* __restrict__ graw,
+                                                              const float* __restrict__ graw1,
                                                               const float* __restrict__ sa, const float* __restrict__ sb,
                                                               size_t n_half, float lo, float hi, float* __restrict__ dpre) {
     const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(NT) void k_depth_head_dpre_parts(const float* __res
         if (graw) g = fmaf((sa ? sa[0] : 1.0f) * (sb ? sb[0] : 1.0f), graw[i], g);
     } else {
         g = g1 ? g1[i - n_half] : 0.0f;
+        if (graw1) g = fmaf((sa ? sa[0] : 1.0f) * (sb ? sb[0] : 1.0f), graw1[i - n_half], g);
     }
     dpre[i] = head_dpre(depth[i], g, lo, hi);
 }
@@ -866,9 +869,10 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
 }
 
 extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float* w, const float* depth, const float* g_first,
-                                          const float* g_second, const float* g_raw, const float* scale_a,
-                                          const float* scale_b, int B, int H, int W, int C, float min_depth, float max_depth,
-                                          float* scratch, void* dx, float* dw, float* db, colvo_stream_t stream) {
+                                          const float* g_second, const float* g_raw, const float* g_raw_second,
+                                          const float* scale_a, const float* scale_b, int B, int H, int W, int C,
+                                          float min_depth, float max_depth, float* scratch, void* dx, float* dw, float* db,
+                                          colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && w && depth && scratch && dx && ((dw == nullptr) == (db == nullptr)),
                     "colvo_depth_head_bwd_parts: null pointer argument");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_bwd_parts: bad dtype");
@@ -878,8 +882,8 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W, n = (size_t)B * HW;
     const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
-    hipLaunchKernelGGL(k_depth_head_dpre_parts, dim3(nblk(n)), dim3(NT), 0, s, depth, g_first, g_second, g_raw, scale_a,
-                       scale_b, n / 2, lo, hi, scratch);
+    hipLaunchKernelGGL(k_depth_head_dpre_parts, dim3(nblk(n)), dim3(NT), 0, s, depth, g_first, g_second, g_raw, g_raw_second,
+                       scale_a, scale_b, n / 2, lo, hi, scratch);
     COLVO_CHECK_LAUNCH("k_depth_head_dpre_parts");
     if (dw) {
         if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;

@@ -106,7 +106,8 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
                                         (float*)c.p[7], s);
         case COLVO_CMD_DEPTH_HEAD_BWD_PARTS:
             return colvo_depth_head_bwd_parts(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
-                                              (const float*)c.p[4], (const float*)c.p[5], (const float*)c.p[6], (const float*)c.p[7],
+                                              (const float*)c.p[4], (const float*)c.p[5], (const float*)c.p[10],
+                                              (const float*)c.p[6], (const float*)c.p[7],
                                               c.i[1], c.i[2], c.i[3], c.i[4], c.f[0], c.f[1], (float*)c.p[8], (void*)c.p[9], nullptr,
                                               nullptr, s);
         case COLVO_CMD_DEPTH_HEAD_WGRAD:

@@ -46,8 +46,9 @@ constexpr int GEO_N = 20;
 
 // Thread 0 evaluates the per-image rotation exactly in the oracle's operation order
 // (pose_vec2mat: R = Rz Ry Rx, no FMA contraction), everybody picks it up as wave-uniform scalars.
+// `level`: intrinsics of the 2x2-average-pooled image, `level` times over (spec: scale_intrinsics, same operation order)
 __device__ __forceinline__ void geo_compute(const float* pose, const float* K, const float* la,
-                                            const float* lb, int b, float* s) {
+                                            const float* lb, int b, float* s, int level = 0) {
 #pragma clang fp contract(off)
     const float* p = pose + 6 * b;
     const float* k = K + 9 * b;
@@ -65,8 +66,13 @@ __device__ __forceinline__ void geo_compute(const float* pose, const float* K, c
     s[7] = cy * sx;
     s[8] = cy * cx;
     s[9] = p[0]; s[10] = p[1]; s[11] = p[2];
-    s[12] = k[0]; s[13] = k[4]; s[14] = k[2]; s[15] = k[5];
-    s[16] = 1.0f / k[0]; s[17] = 1.0f / k[4];
+    float kfx = k[0], kfy = k[4], kcx = k[2], kcy = k[5];
+    for (int l = 0; l < level; ++l) {
+        kfx = kfx * 0.5f; kfy = kfy * 0.5f;
+        kcx = (kcx - 0.5f) * 0.5f; kcy = (kcy - 0.5f) * 0.5f;
+    }
+    s[12] = kfx; s[13] = kfy; s[14] = kcx; s[15] = kcy;
+    s[16] = 1.0f / kfx; s[17] = 1.0f / kfy;
     s[18] = la ? la[b] : 1.0f;
     s[19] = lb ? lb[b] : 0.0f;
 }
@@ -113,6 +119,7 @@ __device__ __forceinline__ float window_mult(int q, int p, int n) {
 // plane offset (no 64-bit VALU address arithmetic), and are bounds-checked by the hardware.
 struct Img {
     __amdgpu_buffer_rsrc_t ref, tgt, dep;
+    __amdgpu_buffer_rsrc_t dr;      // the reference frame's own depth (geometric-consistency variant only)
     int plane4;     // bytes per plane
 };
 __device__ __forceinline__ Img img_make(const float* tgt, const float* ref, const float* depth, int b, int H, int W) {
@@ -122,6 +129,7 @@ __device__ __forceinline__ Img img_make(const float* tgt, const float* ref, cons
     im.ref = __builtin_amdgcn_make_buffer_rsrc((void*)(ref + (size_t)b * 3 * plane), 0, 3 * im.plane4, 0x00020000);
     im.tgt = __builtin_amdgcn_make_buffer_rsrc((void*)(tgt + (size_t)b * 3 * plane), 0, 3 * im.plane4, 0x00020000);
     im.dep = __builtin_amdgcn_make_buffer_rsrc((void*)(depth + (size_t)b * plane), 0, im.plane4, 0x00020000);
+    im.dr = im.dep;
     return im;
 }
 __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -470,16 +478,34 @@ struct BwdState {
     float HK[3][9];
     float part[NPART];
     float lacc, lcnt;                       // fused pass only: loss sum and valid count of the pixels this wave owns
+    float gacc;                             // geometric-consistency variant only: sum of the term over the owned pixels
 };
 
 // FUSED: the same pass also accumulates the loss itself (alpha, 1 - alpha in al / l1w), for the one-kernel
 // loss + unnormalised-gradient forward of the training path (colvo_warp_loss_fused).
 // EDGE: the strip touches the left / right image border (or hangs over it), so the horizontal gather of the window
 // coefficients needs the reflection multiplicities wxw[]; interior strips (9 of 11 at W = 640) take plain 3-sums.
-template <int K, bool FUSED, bool EDGE>
+// GEO (with FUSED): the geometric-consistency term |D_proj - D_samp| / (D_proj + D_samp) of the same projection rides along
+// (spec: geometric_consistency_loss; /root/reference/README.md:1, :7): the reference frame's own depth is a fourth sampled
+// plane on the taps the warp uses anyway; the term's value is summed beside the photometric one, its gradient w.r.t. the
+// projected depth and the sample position runs through the same chain rule (weight `grho` relative to the photometric
+// gradient, both still unnormalised: the two terms share their valid-pixel count), and its gradient w.r.t. the sampled
+// taps is scattered into `dr_acc` as 64-bit FIXED-POINT atomics (2^-32 units): integer addition is associative, so the
+// scatter is bit-reproducible whatever order the waves arrive in.
+constexpr float GEO_FIX = 4294967296.0f;     // 2^32
+// q * 2^32 as a two's-complement 64-bit integer (|q| < 2^31; truncated below 2^-32): floor and fraction are exact in fp32
+__device__ __forceinline__ unsigned long long to_fix32(float q) {
+    const float h = floorf(q);
+    const unsigned lo = (unsigned)((q - h) * GEO_FIX);
+    return ((unsigned long long)(unsigned)(int)h << 32) | lo;
+}
+
+template <int K, bool FUSED, bool EDGE, bool GEO = false>
 __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& im, int j, int nrows, int y_first,
                                          int gxcol, int px, bool own_col, float Xh, const float (&wxw)[3], int H,
-                                         int W, float kss, float kl1, float* __restrict__ d_depth_img, float al, float l1w) {
+                                         int W, float kss, float kl1, float* __restrict__ d_depth_img, float al, float l1w,
+                                         float grho = 0.0f, unsigned long long* __restrict__ dr_acc = nullptr,
+                                         float* __restrict__ geo_img = nullptr) {
     constexpr int K1 = (K + 1) % 3, K2 = (K + 2) % 3;
     if (j >= nrows) return;                              // wave-uniform
     // (1) consume the taps of row j: warp, its spatial derivatives, LCC
@@ -505,6 +531,8 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
     const float mp = st.m[K1], Pxv = st.Px[K1], Pyv = st.Py[K1], Pzv = st.Pz[K1];
     // (2) issue the loads of the next rows (they fly under the arithmetic below).  Rows past the end of the strip are
     //     clamped by reflect_idx, so the loads are always legal and no step-index branch is needed.
+    float vd[4];                                         // GEO: the reference depth on the taps of row j+1, consumed in (6)
+    int to00 = 0, to01 = 0, to10 = 0;
     {
         const int py = reflect_idx(y_first + j + 1, H);
         const Proj p = project_px(g, st.dv[K1], px, py, H, W);
@@ -516,6 +544,11 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
             const int so = c * im.plane4;
             st.v[K1][c][0] = bload(im.ref, t.o00, so); st.v[K1][c][1] = bload(im.ref, t.o01, so);
             st.v[K1][c][2] = bload(im.ref, t.o10, so); st.v[K1][c][3] = bload(im.ref, t.o11, so);
+        }
+        if constexpr (GEO) {
+            vd[0] = bload(im.dr, t.o00, 0); vd[1] = bload(im.dr, t.o01, 0);
+            vd[2] = bload(im.dr, t.o10, 0); vd[3] = bload(im.dr, t.o11, 0);
+            to00 = t.o00; to01 = t.o01 - t.o00; to10 = t.o10 - t.o00;
         }
     }
     {
@@ -620,15 +653,71 @@ __device__ __forceinline__ void bwd_step(BwdState& st, const Geo& g, const Img& 
         st.part[9] += dPz * cX; st.part[10] += dPz * cY; st.part[11] += dPz * cZ;
         if (own) d_depth_img[(size_t)gyp * W + gxcol] = dd;
     }
+    // (6) GEO: the geometric-consistency term of pixel row j+1 -- the row projected in (2); its reference-depth taps have
+    //     been in flight under (3)-(5) and the next step waits for the image taps issued before them anyway.  Pixel-local, so
+    //     value, chain rule and scatter happen here at once and nothing is carried between steps: the term's depth gradient
+    //     goes to a plane of its own (geo_img; the caller adds the two planes under their common normaliser).
+    if constexpr (GEO) {
+        const int r = j + 1, gyr = y_first + r;
+        const bool own = own_col && (r >= 2) && (r <= nrows - 3) && (gyr < H);
+        const float m = st.m[K1], mo = own ? m : 0.0f;
+        const float wx = st.wx[K1], wy = st.wy[K1], ux = 1.0f - wx, uy = 1.0f - wy;
+        const float bs = fmaf(fmaf(vd[3], wx, vd[2] * ux), wy, fmaf(vd[1], wx, vd[0] * ux) * uy);     // D_samp
+        const float a = st.Pz[K1];                                                                    // D_proj (1 where invalid)
+        const float inv = nr_rcp((m > 0.0f) ? a + bs : 1.0f);
+        const float df = a - bs;
+        st.gacc = fmaf(mo * fabsf(df), inv, st.gacc);
+        const float sg = (df > 0.0f) ? 1.0f : ((df < 0.0f) ? -1.0f : 0.0f);
+        const float k2 = mo * grho * sg * 2.0f * inv * inv;
+        const float gb = -k2 * a, ga = k2 * bs;          // d / d D_samp, d / d D_proj
+        const float gxd = gb * fmaf(wy, vd[3] - vd[2], uy * (vd[1] - vd[0]));
+        const float gyd = gb * fmaf(wx, vd[3] - vd[1], ux * (vd[2] - vd[0]));
+        const float iz = nr_rcp(a);
+        const float dPx = gxd * g.fx * iz;
+        const float dPy = gyd * g.fy * iz;
+        const float dPz = ga - (dPx * st.Px[K1] + dPy * st.Py[K1]) * iz;
+        const float Yh = ((float)gyr - g.cy) * g.ify;
+        const float rx_ = g.r00 * Xh + g.r01 * Yh + g.r02;
+        const float ry_ = g.r10 * Xh + g.r11 * Yh + g.r12;
+        const float rz_ = g.r20 * Xh + g.r21 * Yh + g.r22;
+        const float dcur = st.dv[K1];
+        const float cX = Xh * dcur, cY = Yh * dcur, cZ = dcur;
+        st.part[0] += dPx; st.part[1] += dPy; st.part[2] += dPz;
+        st.part[3] += dPx * cX; st.part[4] += dPx * cY; st.part[5] += dPx * cZ;
+        st.part[6] += dPy * cX; st.part[7] += dPy * cY; st.part[8] += dPy * cZ;
+        st.part[9] += dPz * cX; st.part[10] += dPz * cY; st.part[11] += dPz * cZ;
+        if (own) {
+            geo_img[(size_t)gyr * W + gxcol] = dPx * rx_ + dPy * ry_ + dPz * rz_;
+            if (m > 0.0f) {
+                char* q = reinterpret_cast<char*>(dr_acc) + 2 * (size_t)to00;
+                atomicAdd(reinterpret_cast<unsigned long long*>(q), to_fix32(gb * ux * uy));
+                atomicAdd(reinterpret_cast<unsigned long long*>(q + 2 * to01), to_fix32(gb * wx * uy));
+                atomicAdd(reinterpret_cast<unsigned long long*>(q + 2 * to10), to_fix32(gb * ux * wy));
+                atomicAdd(reinterpret_cast<unsigned long long*>(q + 2 * to10 + 2 * to01), to_fix32(gb * wx * wy));
+            }
+        }
+    }
 }
 
-template <bool FUSED>
+// level: pyramid level of the images this launch works on (the intrinsics are scaled in the kernel); GEO: see bwd_step
+// (depth_r: the reference frame's depth, dr_acc: [B,H,W] 64-bit fixed-point accumulators zeroed by the caller, geo_partials:
+// one float per strip segment, grho: weight of the term's gradient relative to the photometric one)
+struct GeoArgs {
+    const float* depth_r;
+    unsigned long long* dr_acc;
+    float* geo_partials;
+    float* d_depth_geo;          // [B,H,W]: the term's (unnormalised, grho-weighted) gradient w.r.t. the target depth
+    float grho;
+};
+
+template <bool FUSED, bool GEO = false>
 __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
     const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
     const float* __restrict__ lcc_b, int B, int H, int W, int strips_x, int nseg, int seg_rows, float alpha,
     const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
-    float* __restrict__ partials) {
+    float* __restrict__ partials, int level, GeoArgs ga) {
+    static_assert(FUSED || !GEO, "the geometric-consistency term rides on the one-pass form only");
     __shared__ float s_geo[4][GEO_N + 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: keeps the buffer descriptors uniform
@@ -638,10 +727,18 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     const int item = live ? item_raw : nitems - 1;
     const int b = item / (nseg * strips_x), rem = item - b * (nseg * strips_x);
     const int seg = rem / strips_x, strip = rem - seg * strips_x;
-    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave]);
+    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave], level);
     __syncthreads();
     const Geo g = geo_load(s_geo[wave]);
-    const Img im = img_make(tgt, ref, depth, b, H, W);
+    Img im = img_make(tgt, ref, depth, b, H, W);
+    unsigned long long* dr_acc = nullptr;
+    float* geo_img = nullptr;
+    if constexpr (GEO) {
+        im.dr = __builtin_amdgcn_make_buffer_rsrc((void*)(ga.depth_r + (size_t)b * H * W), 0, im.plane4, 0x00020000);
+        dr_acc = ga.dr_acc + (size_t)b * H * W;
+        geo_img = ga.d_depth_geo + (size_t)b * H * W;
+    }
+    const float grho = GEO ? ga.grho : 0.0f;
     // fused pass: unnormalised gradients (scaled by dL/dloss / max(3 n_valid, 1) once that is known)
     const float gscale = FUSED ? 1.0f : grad_loss[0] * loss_state[1];   // dL/dloss / max(3 n_valid, 1)
     const float kss = gscale * alpha * (-0.5f);
@@ -663,7 +760,7 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     }
 
     BwdState st;
-    st.lacc = 0.0f; st.lcnt = 0.0f;
+    st.lacc = 0.0f; st.lcnt = 0.0f; st.gacc = 0.0f;
 #pragma unroll
     for (int k = 0; k < NPART; ++k) st.part[k] = 0.0f;
 #pragma unroll
@@ -708,16 +805,16 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     if (edge) {
 #pragma unroll 1
         for (int j = 0; j < nrows; j += 3) {
-            bwd_step<0, FUSED, true>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-            bwd_step<1, FUSED, true>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-            bwd_step<2, FUSED, true>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<0, FUSED, true, GEO>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
+            bwd_step<1, FUSED, true, GEO>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
+            bwd_step<2, FUSED, true, GEO>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
         }
     } else {
 #pragma unroll 1
         for (int j = 0; j < nrows; j += 3) {
-            bwd_step<0, FUSED, false>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-            bwd_step<1, FUSED, false>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
-            bwd_step<2, FUSED, false>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha);
+            bwd_step<0, FUSED, false, GEO>(st, g, im, j, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
+            bwd_step<1, FUSED, false, GEO>(st, g, im, j + 1, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
+            bwd_step<2, FUSED, false, GEO>(st, g, im, j + 2, nrows, y_first, gxcol, px, own_col, Xh, wxw, H, W, kss, kl1, ddimg, alpha, 1.0f - alpha, grho, dr_acc, geo_img);
         }
     }
     constexpr int NP = FUSED ? NPART_F : NPART;
@@ -729,6 +826,10 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     if constexpr (FUSED) {
         const float la = wave_sum(live ? st.lacc : 0.0f), lc = wave_sum(live ? st.lcnt : 0.0f);
         if (lane == 0 && live) { partials[(size_t)item * NP + 14] = la; partials[(size_t)item * NP + 15] = lc; }
+    }
+    if constexpr (GEO) {
+        const float gs = wave_sum(live ? st.gacc : 0.0f);
+        if (lane == 0 && live) ga.geo_partials[item] = gs;
     }
 }
 
@@ -1213,6 +1314,253 @@ __global__ __launch_bounds__(NT) void k_avgpool2_bwd(const float* __restrict__ d
     *reinterpret_cast<float2*>(xp + 2 * Wo) = make_float2(g, g);
 }
 
+// --------------------------------------------------------------------------------------------- //
+// The widened objective as ONE native call (spec: dcdp_full_loss):       //
+//   multi-scale photometric (+ the geometric-consistency term inside the level-0 pass)           //
+//   + edge-aware smoothness, value and gradients, 6 launches forward and 1 backward              //
+// --------------------------------------------------------------------------------------------- //
+constexpr int FULL_MAX_LEVELS = 4;
+constexpr int FULL_STATE_N = 32;     // [0] total, [1] geometric term, [2] smoothness term, [4+4s ..] level s: loss, c_s, n_valid
+
+// one level of the 2x2-average pyramid for all 7 planes of every pair (target 3, reference 3, target depth 1) in one launch
+__global__ __launch_bounds__(NT) void k_pyramid_level(const float* __restrict__ st, const float* __restrict__ sr,
+                                                      const float* __restrict__ sd, int B, int Ho, int Wo,
+                                                      float* __restrict__ dt, float* __restrict__ dr, float* __restrict__ dd) {
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (o >= (size_t)Ho * Wo) return;
+    int p = blockIdx.y;
+    const float* x; float* y;
+    if (p < 3 * B) { x = st; y = dt; } else if (p < 6 * B) { x = sr; y = dr; p -= 3 * B; } else { x = sd; y = dd; p -= 6 * B; }
+    const int v = (int)(o / Wo), u = (int)(o - (size_t)v * Wo);
+    const float* xp = x + (size_t)p * 4 * Ho * Wo + (size_t)(2 * v) * (2 * Wo) + 2 * u;
+    const float2 r0 = *reinterpret_cast<const float2*>(xp), r1 = *reinterpret_cast<const float2*>(xp + 2 * Wo);
+    y[(size_t)p * Ho * Wo + o] = 0.25f * ((r0.x + r0.y) + (r1.x + r1.y));
+}
+
+// smoothness term, value and gradient in one pass (the term's normalisers are pair counts, known before the data): per-block
+// partial {Sx, Sy} as k_smooth_fwd, d term / d depth in gather form as k_smooth_bwd (without dL/dterm); the same thread
+// clears its pixel's fixed-point accumulator of the geometric-consistency scatter (zero_acc may be null)
+__global__ __launch_bounds__(NT) void k_smooth_both(const float* __restrict__ depth, const float* __restrict__ img, int H, int W,
+                                                    float inv_nx, float inv_ny, float* __restrict__ partials,
+                                                    float* __restrict__ d_raw, unsigned long long* __restrict__ zero_acc) {
+    __shared__ float red[4][2];
+    const int b = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    float sx = 0.0f, sy = 0.0f;
+    if (o < plane) {
+        const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
+        const float* dp = depth + (size_t)b * plane;
+        const float* ip = img + (size_t)b * 3 * plane;
+        const float d0 = 1.0f / dp[o];
+        float gd = 0.0f;
+        if (u + 1 < W) {
+            const float dd = 1.0f / dp[o + 1] - d0, w = edge_w(ip, plane, o, o + 1);
+            sx = fabsf(dd) * w;
+            gd -= sgnf(dd) * w * inv_nx;
+        }
+        if (u >= 1) gd += sgnf(d0 - 1.0f / dp[o - 1]) * edge_w(ip, plane, o - 1, o) * inv_nx;
+        if (v + 1 < H) {
+            const float dd = 1.0f / dp[o + W] - d0, w = edge_w(ip, plane, o, o + W);
+            sy = fabsf(dd) * w;
+            gd -= sgnf(dd) * w * inv_ny;
+        }
+        if (v >= 1) gd += sgnf(d0 - 1.0f / dp[o - W]) * edge_w(ip, plane, o - W, o) * inv_ny;
+        d_raw[(size_t)b * plane + o] = gd * (-d0 * d0);
+        if (zero_acc) zero_acc[(size_t)b * plane + o] = 0ull;
+    }
+    sx = wave_sum(sx); sy = wave_sum(sy);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
+        partials[2 * blk] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        partials[2 * blk + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    }
+}
+
+struct FullLevels {
+    int S, B;
+    int items_per_image[FULL_MAX_LEVELS];
+    const float* partials[FULL_MAX_LEVELS];      // the level's march partials (NPART_F per strip segment)
+    const float* raw[FULL_MAX_LEVELS];           // the level's unnormalised depth gradient [B, H >> s, W >> s]
+};
+
+// Blocks 0 .. S*B-1: the 14 gradient sums of one image at one level (still unnormalised) -> gpart[s][b][14].
+// Last block: every term's value and normaliser -> state, the weighted total -> state[0] and loss_out: each thread gathers
+// its share of all (at most 11) sums, the waves reduce them by DPP, thread 0 adds the four wave totals.  Fixed orders.
+__global__ __launch_bounds__(NT) void k_full_finalize(FullLevels lv, const float* __restrict__ geo_partials,
+                                                      const float* __restrict__ sm_partials, int sm_nblk, float inv_nx,
+                                                      float inv_ny, float w_geo, float w_sm, float* __restrict__ gpart,
+                                                      float* __restrict__ state, float* __restrict__ loss_out) {
+    __shared__ float sh[NT];
+    const int tid = threadIdx.x, B = lv.B;
+    if ((int)blockIdx.x == B * lv.S) {
+        constexpr int NV = 2 * FULL_MAX_LEVELS + 3;
+        float v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < FULL_MAX_LEVELS; ++s) {
+            if (s < lv.S) {
+                const int n = B * lv.items_per_image[s];
+                const float* pp = lv.partials[s];
+                for (int i = tid; i < n; i += NT) { v[2 * s] += pp[(size_t)i * NPART_F + 14]; v[2 * s + 1] += pp[(size_t)i * NPART_F + 15]; }
+            }
+        }
+        if (geo_partials) {
+            const int n = B * lv.items_per_image[0];
+            for (int i = tid; i < n; i += NT) v[2 * FULL_MAX_LEVELS] += geo_partials[i];
+        }
+        if (sm_partials)
+            for (int i = tid; i < sm_nblk; i += NT) {
+                v[2 * FULL_MAX_LEVELS + 1] += sm_partials[2 * i];
+                v[2 * FULL_MAX_LEVELS + 2] += sm_partials[2 * i + 1];
+            }
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float t = wave_sum(v[q]);
+            if ((tid & 63) == 0) sh[(tid >> 6) * NV + q] = t;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float tot[NV];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) tot[q] = (sh[q] + sh[NV + q]) + (sh[2 * NV + q] + sh[3 * NV + q]);
+            float total = 0.0f;
+            const float w = 1.0f / (float)lv.S;
+            for (int s = 0; s < lv.S; ++s) {
+                const float denom = fmaxf(3.0f * tot[2 * s + 1], 1.0f), l = tot[2 * s] / denom;
+                total += w * l;
+                state[4 + 4 * s] = l; state[4 + 4 * s + 1] = w / denom; state[4 + 4 * s + 2] = tot[2 * s + 1]; state[4 + 4 * s + 3] = 0.0f;
+            }
+            float geo = 0.0f, sm = 0.0f;
+            if (geo_partials) { geo = tot[2 * FULL_MAX_LEVELS] / fmaxf(tot[1], 1.0f); total += w_geo * geo; }
+            if (sm_partials) { sm = tot[2 * FULL_MAX_LEVELS + 1] * inv_nx + tot[2 * FULL_MAX_LEVELS + 2] * inv_ny; total += w_sm * sm; }
+            state[0] = total; state[1] = geo; state[2] = sm; state[3] = 0.0f;
+            loss_out[0] = total;
+        }
+        return;
+    }
+    const int s = blockIdx.x / B, b = blockIdx.x - s * B;
+    constexpr int ROWS = NT / NPART;  // 18 partial rows per pass
+    const int k = tid % NPART, r = tid / NPART;
+    const int bpi = lv.items_per_image[s];
+    const float* pp = lv.partials[s];
+    float acc = 0.0f;
+    if (r < ROWS) {
+        for (int i = r; i < bpi; i += ROWS) acc += pp[((size_t)b * bpi + i) * NPART_F + k];
+        sh[k * ROWS + r] = acc;
+    }
+    __syncthreads();
+    if (tid < NPART) {
+        float t = 0.0f;
+        for (int i = 0; i < ROWS; ++i) t += sh[tid * ROWS + i];
+        gpart[((size_t)s * B + b) * NPART + tid] = t;
+    }
+}
+
+// backward of the whole objective: every gradient in one launch.
+//   d_dt = g (sum_s c_s / 4^s raw_s[y >> s, x >> s] + c_0 geo_raw + w_sm sd_raw)   (the pooling chain is the index shift)
+//   d_dr = g c_0 acc / 2^32                                             (fixed-point scatter of the geometric term)
+//   blocks 0..B-1, thread 0: pose / LCC gradients of one image from gpart (dR -> Euler angles)
+__global__ __launch_bounds__(NT) void k_full_combine(FullLevels lv, const float* __restrict__ state,
+                                                     const float* __restrict__ grad_loss, const float* __restrict__ sd_raw,
+                                                     const float* __restrict__ geo_raw, const unsigned long long* __restrict__ acc, const float* __restrict__ gpart,
+                                                     const float* __restrict__ pose, int H, int W, float w_sm,
+                                                     float* __restrict__ d_dt, float* __restrict__ d_dr,
+                                                     float* __restrict__ d_pose, float* __restrict__ d_a, float* __restrict__ d_b) {
+    const float g = grad_loss[0];
+    const int B = lv.B;
+    float c[FULL_MAX_LEVELS];
+#pragma unroll
+    for (int s = 0; s < FULL_MAX_LEVELS; ++s) c[s] = (s < lv.S) ? g * state[4 + 4 * s + 1] : 0.0f;
+    const size_t plane = (size_t)H * W, n = (size_t)B * plane;
+    const size_t stride = (size_t)gridDim.x * NT;
+    const float gsm = g * w_sm;
+    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const int b = (int)(i / plane);
+        const size_t o = i - (size_t)b * plane;
+        const int y = (int)(o / W), x = (int)(o - (size_t)y * W);
+        float v = c[0] * (geo_raw ? lv.raw[0][i] + geo_raw[i] : lv.raw[0][i]);
+        float f = 0.25f;
+#pragma unroll
+        for (int s = 1; s < FULL_MAX_LEVELS; ++s) {
+            if (s < lv.S) {
+                const int ws = W >> s, hs = H >> s;
+                v = fmaf(c[s] * f, lv.raw[s][((size_t)b * hs + (y >> s)) * ws + (x >> s)], v);
+                f *= 0.25f;
+            }
+        }
+        if (sd_raw) v = fmaf(gsm, sd_raw[i], v);
+        d_dt[i] = v;
+        if (d_dr) d_dr[i] = c[0] * ((float)(long long)acc[i] * (1.0f / GEO_FIX));
+    }
+    if ((int)blockIdx.x >= B) return;
+    __shared__ float tot[NPART + 2];
+    const int b = blockIdx.x;
+    if (threadIdx.x < NPART) {
+        float t = 0.0f;
+#pragma unroll
+        for (int s = 0; s < FULL_MAX_LEVELS; ++s)
+            if (s < lv.S) t = fmaf(c[s], gpart[((size_t)s * B + b) * NPART + threadIdx.x], t);
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float drx, dry, drz;
+        dR_to_euler(tot + 3, pose + 6 * b, drx, dry, drz);
+        d_pose[6 * b + 0] = tot[0]; d_pose[6 * b + 1] = tot[1]; d_pose[6 * b + 2] = tot[2];
+        d_pose[6 * b + 3] = drx; d_pose[6 * b + 4] = dry; d_pose[6 * b + 5] = drz;
+        d_a[b] = tot[12];
+        d_b[b] = tot[13];
+    }
+}
+
+// where everything lives in the caller's workspace (fp32 units; the 64-bit accumulators come first)
+struct FullPlan {
+    int S;
+    int h[FULL_MAX_LEVELS], w[FULL_MAX_LEVELS], seg_rows[FULL_MAX_LEVELS], strips[FULL_MAX_LEVELS], nseg[FULL_MAX_LEVELS];
+    size_t tgt[FULL_MAX_LEVELS], ref[FULL_MAX_LEVELS], dep[FULL_MAX_LEVELS], raw[FULL_MAX_LEVELS], part[FULL_MAX_LEVELS];
+    size_t acc, geo_part, geo_raw, sd, sm_part, gpart, state, total;
+    int sm_nblk;
+};
+
+inline FullPlan full_plan(int B, int H, int W, int S) {
+    FullPlan p{};
+    p.S = S;
+    size_t o = 0;
+    auto take = [&](size_t n) { const size_t at = o; o += (n + 3) & ~(size_t)3; return at; };      // 16-byte granules
+    p.acc = take(2 * (size_t)B * H * W);
+    for (int s = 0; s < S; ++s) {
+        const int h = H >> s, w = W >> s;
+        p.h[s] = h; p.w[s] = w;
+        int rows = pick_march_rows(B, h, w, BCOLS, 4, 8);
+        if (TUNE(march_rows_bwd) > 0) rows = std::max(4, std::min(MROWS_MAX, (int)TUNE(march_rows_bwd)));
+        p.seg_rows[s] = rows;
+        p.strips[s] = (w + BCOLS - 1) / BCOLS;
+        p.nseg[s] = (h + rows - 1) / rows;
+        const size_t px = (size_t)B * h * w;
+        if (s > 0) { p.tgt[s] = take(3 * px); p.ref[s] = take(3 * px); p.dep[s] = take(px); }
+        p.raw[s] = take(px);
+        p.part[s] = take((size_t)B * p.nseg[s] * p.strips[s] * NPART_F);
+    }
+    p.geo_part = take((size_t)B * p.nseg[0] * p.strips[0]);
+    p.geo_raw = take((size_t)B * H * W);
+    p.sd = take((size_t)B * H * W);
+    p.sm_nblk = B * (int)(((size_t)H * W + NT - 1) / NT);
+    p.sm_part = take(2 * (size_t)p.sm_nblk);
+    p.gpart = take((size_t)S * B * NPART);
+    p.state = take(FULL_STATE_N);
+    p.total = o;
+    return p;
+}
+
+inline bool full_shape_ok(int B, int H, int W, int S) {
+    return B >= 1 && B <= 9000 && S >= 1 && S <= FULL_MAX_LEVELS && (H >> (S - 1)) >= 2 && (W >> (S - 1)) >= 2
+           && H % (1 << (S - 1)) == 0 && W % (1 << (S - 1)) == 0 && (size_t)H * W < (1u << 28);
+}
+
 
 }  // namespace
 }  // namespace colvo
@@ -1267,7 +1615,7 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");
     hipLaunchKernelGGL((k_warp_loss_bwd_march<false>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
-                       lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, loss_state, grad_loss, d_depth, workspace);
+                       lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, loss_state, grad_loss, d_depth, workspace, 0, GeoArgs{});
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march");
     hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, nseg * strips_x, pose,
                        d_pose, d_a, d_b);
@@ -1293,7 +1641,7 @@ extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const f
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fused: too many strips");
     hipLaunchKernelGGL((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose,
                        K, lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, (const float*)nullptr,
-                       (const float*)nullptr, d_depth_raw, workspace);
+                       (const float*)nullptr, d_depth_raw, workspace, 0, GeoArgs{});
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<fused>");
     hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(NT), 0, s, workspace, nseg * strips_x, B, pose,
                        grad_partials, grad_unit, loss_state);
@@ -1419,5 +1767,112 @@ extern "C" int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, flo
     hipLaunchKernelGGL(k_avgpool2_bwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
                        dy, Ho, Wo, dx);
     COLVO_CHECK_LAUNCH("k_avgpool2_bwd");
+    return 0;
+}
+
+// ---- the widened objective in one call ---------------------------------------------------------------------------- //
+extern "C" size_t colvo_full_objective_workspace_floats(int B, int H, int W, int num_scales) {
+    if (!full_shape_ok(B, H, W, num_scales)) return 0;
+    return full_plan(B, H, W, num_scales).total;
+}
+
+extern "C" int colvo_full_objective_fwd(const float* tgt, const float* ref, const float* depth_t, const float* depth_r,
+                                        const float* pose, const float* K, const float* lcc_a, const float* lcc_b, int B, int H,
+                                        int W, int num_scales, float ssim_weight, float geo_weight, float smooth_weight,
+                                        float* workspace, float* loss, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(tgt && ref && depth_t && pose && K && lcc_a && lcc_b && workspace && loss,
+                    "colvo_full_objective_fwd: null pointer argument");
+    COLVO_CHECK_ARG(geo_weight == 0.0f || depth_r, "colvo_full_objective_fwd: the geometric term needs the reference depth");
+    COLVO_CHECK_ARG(full_shape_ok(B, H, W, num_scales),
+                    "colvo_full_objective_fwd: bad shape B=%d H=%d W=%d scales=%d (H, W divisible by 2^(scales-1), scales <= %d)",
+                    B, H, W, num_scales, FULL_MAX_LEVELS);
+    COLVO_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "colvo_full_objective_fwd: workspace must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const FullPlan p = full_plan(B, H, W, num_scales);
+    const bool geo = geo_weight != 0.0f, smooth = smooth_weight != 0.0f;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace + p.acc);
+    const size_t plane = (size_t)H * W;
+    // (1) smoothness: value partials + raw gradient; clears the scatter accumulators on the way
+    const float inv_nx = 1.0f / ((float)B * H * (W - 1)), inv_ny = 1.0f / ((float)B * (H - 1) * W);      // (H, W >= 2)
+    if (smooth) {
+        hipLaunchKernelGGL(k_smooth_both, dim3((unsigned)((plane + NT - 1) / NT), B), dim3(NT), 0, s, depth_t, tgt, H, W,
+                           inv_nx, inv_ny, workspace + p.sm_part, workspace + p.sd, geo ? acc : nullptr);
+        COLVO_CHECK_LAUNCH("k_smooth_both");
+    } else if (geo) {
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * plane * 8, s);
+        if (e != hipSuccess) { set_error("colvo_full_objective_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    // (2) pyramid
+    const float *lt = tgt, *lr = ref, *ld = depth_t;
+    FullLevels lv{};
+    lv.S = num_scales; lv.B = B;
+    for (int l = 0; l < num_scales; ++l) {
+        if (l > 0) {
+            float *nt = workspace + p.tgt[l], *nr = workspace + p.ref[l], *nd = workspace + p.dep[l];
+            const size_t px = (size_t)p.h[l] * p.w[l];
+            hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((px + NT - 1) / NT), 7 * B), dim3(NT), 0, s, lt, lr, ld, B, p.h[l],
+                               p.w[l], nt, nr, nd);
+            COLVO_CHECK_LAUNCH("k_pyramid_level");
+            lt = nt; lr = nr; ld = nd;
+        }
+        // (3) one-pass photometric loss + gradients of the level; level 0 carries the geometric term
+        const long long nitems = (long long)B * p.nseg[l] * p.strips[l];
+        COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_full_objective_fwd: too many strips");
+        lv.items_per_image[l] = p.nseg[l] * p.strips[l];
+        lv.partials[l] = workspace + p.part[l];
+        lv.raw[l] = workspace + p.raw[l];
+        if (l == 0 && geo) {
+            // both terms are masked means over the SAME valid pixels (photometric: 3 channels each, weight 1/S): relative to the
+            // photometric gradient the term's weighs  geo_weight / n  over  (1/S) / (3 n)
+            GeoArgs ga{depth_r, acc, workspace + p.geo_part, workspace + p.geo_raw, 3.0f * (float)num_scales * geo_weight};
+            hipLaunchKernelGGL((k_warp_loss_bwd_march<true, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, lt, lr, ld,
+                               pose, K, lcc_a, lcc_b, B, p.h[l], p.w[l], p.strips[l], p.nseg[l], p.seg_rows[l], ssim_weight,
+                               (const float*)nullptr, (const float*)nullptr, workspace + p.raw[l], workspace + p.part[l], l, ga);
+        } else {
+            hipLaunchKernelGGL((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, lt, lr, ld, pose,
+                               K, lcc_a, lcc_b, B, p.h[l], p.w[l], p.strips[l], p.nseg[l], p.seg_rows[l], ssim_weight,
+                               (const float*)nullptr, (const float*)nullptr, workspace + p.raw[l], workspace + p.part[l], l,
+                               GeoArgs{});
+        }
+        COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<full objective>");
+    }
+    // (4) every term's value, the total, the per-image gradient sums
+    hipLaunchKernelGGL(k_full_finalize, dim3(B * num_scales + 1), dim3(NT), 0, s, lv, geo ? workspace + p.geo_part : (const float*)nullptr,
+                       smooth ? workspace + p.sm_part : (const float*)nullptr, p.sm_nblk, inv_nx, inv_ny, geo_weight, smooth_weight,
+                       workspace + p.gpart, workspace + p.state, loss);
+    COLVO_CHECK_LAUNCH("k_full_finalize");
+    return 0;
+}
+
+extern "C" int colvo_full_objective_terms(const float* workspace, int B, int H, int W, int num_scales, const float** state) {
+    COLVO_CHECK_ARG(workspace && state && full_shape_ok(B, H, W, num_scales), "colvo_full_objective_terms: bad argument");
+    *state = workspace + full_plan(B, H, W, num_scales).state;
+    return 0;
+}
+
+extern "C" int colvo_full_objective_bwd(const float* workspace, const float* grad_loss, const float* pose, int B, int H, int W,
+                                        int num_scales, float geo_weight, float smooth_weight, float* d_depth_t,
+                                        float* d_depth_r, float* d_pose, float* d_a, float* d_b, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(workspace && grad_loss && pose && d_depth_t && d_pose && d_a && d_b,
+                    "colvo_full_objective_bwd: null pointer argument");
+    COLVO_CHECK_ARG(geo_weight == 0.0f || d_depth_r, "colvo_full_objective_bwd: the geometric term needs d_depth_r");
+    COLVO_CHECK_ARG(full_shape_ok(B, H, W, num_scales), "colvo_full_objective_bwd: bad shape");
+    const FullPlan p = full_plan(B, H, W, num_scales);
+    FullLevels lv{};
+    lv.S = num_scales; lv.B = B;
+    for (int l = 0; l < num_scales; ++l) {
+        lv.items_per_image[l] = p.nseg[l] * p.strips[l];
+        lv.partials[l] = workspace + p.part[l];
+        lv.raw[l] = workspace + p.raw[l];
+    }
+    const bool geo = geo_weight != 0.0f, smooth = smooth_weight != 0.0f;
+    const size_t n = (size_t)B * H * W;
+    unsigned blocks = (unsigned)std::min<size_t>((n + NT * 4 - 1) / (NT * 4), 4096);
+    if (blocks < (unsigned)B) blocks = (unsigned)B;
+    hipLaunchKernelGGL(k_full_combine, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, lv, workspace + p.state, grad_loss,
+                       smooth ? workspace + p.sd : (const float*)nullptr, geo ? workspace + p.geo_raw : (const float*)nullptr,
+                       geo ? reinterpret_cast<const unsigned long long*>(workspace + p.acc) : (const unsigned long long*)nullptr,
+                       workspace + p.gpart, pose, H, W, smooth_weight, d_depth_t, geo ? d_depth_r : (float*)nullptr, d_pose, d_a, d_b);
+    COLVO_CHECK_LAUNCH("k_full_combine");
     return 0;
 }

@@ -339,19 +339,12 @@ def dcdp_full_loss_composite(tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, *, geo_w
     return loss
 
 
-_const_cache = {}
-
-
-def _const(device, key, values):
-    t = _const_cache.get((device, key))
-    if t is None:
-        t = _const_cache[(device, key)] = torch.tensor(values, device=device, dtype=torch.float32)
-    return t
-
-
 class _FullObjective(torch.autograd.Function):
-    """The widened objective as ONE autograd node: every term's kernels are called directly, the term weights ride on the
-    device scalars the backward kernels take anyway, and the pyramid's gradient chain is two pooling-backward launches."""
+    """The widened objective as ONE autograd node over TWO native calls (include/colvo.h colvo_full_objective_fwd / _bwd):
+    forward = smoothness + pyramid + the one-pass photometric kernel per level (the level-0 launch carries the geometric-
+    consistency term on the projection and taps it has anyway) + one finalize; backward = one launch that turns the saved raw
+    planes and per-image sums into every gradient.  No torch kernel runs in either direction; the gradient w.r.t. the
+    reference depth is a fixed-point scatter (bit-reproducible)."""
 
     @staticmethod
     def forward(ctx, tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, geo_weight, smooth_weight, num_scales, ssim_weight):
@@ -359,112 +352,68 @@ class _FullObjective(torch.autograd.Function):
         B, C, H, W = tgt.shape
         if C != 3:
             raise ValueError("dcdp_full_loss: images must have 3 channels")
-        if (H % (1 << (num_scales - 1))) or (W % (1 << (num_scales - 1))):
+        if num_scales < 1 or (H % (1 << (num_scales - 1))) or (W % (1 << (num_scales - 1))):
             raise ValueError("dcdp_full_loss: H and W must be divisible by 2^(num_scales - 1)")
+        if geo_weight and d_r is None:
+            raise ValueError("dcdp_full_loss: the geometric-consistency term (geo_weight != 0) needs the reference depth")
         tgt, ref = _chk(tgt, "tgt", (B, 3, H, W)), _chk(ref, "ref", (B, 3, H, W))
-        d_t, d_r = _chk(d_t, "tgt_depth", (B, 1, H, W)), _chk(d_r, "ref_depth", (B, 1, H, W))
+        d_t = _chk(d_t, "tgt_depth", (B, 1, H, W))
+        d_r = _chk(d_r, "ref_depth", (B, 1, H, W)) if d_r is not None else None
         pose, K = _chk(pose, "pose", (B, 6)), _chk(K, "K", (B, 3, 3))
         lcc_a, lcc_b = _chk(lcc_a, "lcc_a", (B, 1)), _chk(lcc_b, "lcc_b", (B, 1))
-        dev = tgt.device
-        sp = _lib.stream_ptr()
-        f32 = dict(device=dev, dtype=torch.float32)
-        # pyramid of frames, depth and intrinsics
-        ts, rs, ds, Ks = [tgt], [ref], [d_t], [K]
-        kS = _const(dev, "kS", [[0.5, 1.0, 0.5], [1.0, 0.5, 0.5], [1.0, 1.0, 1.0]])
-        kT = _const(dev, "kT", [[0.0, 0.0, -0.25], [0.0, 0.0, -0.25], [0.0, 0.0, 0.0]])
-        for s_ in range(1, num_scales):
-            h, w = H >> s_, W >> s_
-            nt, nr, nd = torch.empty(B, 3, h, w, **f32), torch.empty(B, 3, h, w, **f32), torch.empty(B, 1, h, w, **f32)
-            _lib.check(lib.colvo_avgpool2_fwd(_lib.ptr(ts[-1]), B * 3, 2 * h, 2 * w, _lib.ptr(nt), sp), "colvo_avgpool2_fwd")
-            _lib.check(lib.colvo_avgpool2_fwd(_lib.ptr(rs[-1]), B * 3, 2 * h, 2 * w, _lib.ptr(nr), sp), "colvo_avgpool2_fwd")
-            _lib.check(lib.colvo_avgpool2_fwd(_lib.ptr(ds[-1]), B, 2 * h, 2 * w, _lib.ptr(nd), sp), "colvo_avgpool2_fwd")
-            ts.append(nt); rs.append(nr); ds.append(nd)
-            Ks.append(torch.addcmul(kT, Ks[-1], kS))          # fx/2, fy/2, (cx - 1/2)/2, (cy - 1/2)/2 (spec: scale_intrinsics)
-        states, raws, parts = [], [], []
-        for s_ in range(num_scales):
-            h, w = H >> s_, W >> s_
-            ws = torch.empty(lib.colvo_warp_loss_workspace_floats(B, h, w), **f32)
-            st, raw, gp = torch.empty(4, **f32), torch.empty(B, 1, h, w, **f32), torch.empty(B * 14, **f32)
-            _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fused(
-                _lib.ptr(ts[s_]), _lib.ptr(rs[s_]), _lib.ptr(ds[s_]), _lib.ptr(pose), _lib.ptr(Ks[s_]), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
-                B, h, w, float(ssim_weight), _lib.ptr(ws), _lib.ptr(st), _lib.ptr(raw), _lib.ptr(gp), 0, sp)), "colvo_warp_loss_fused")
-            states.append(st); raws.append(raw); parts.append(gp)
-        terms = [st[0] for st in states]
-        weights = [1.0 / num_scales] * num_scales
-        geo_state = None
-        if geo_weight:
-            ws = torch.empty(lib.colvo_geo_loss_workspace_floats(B, H, W), **f32)
-            geo_state = torch.empty(4, **f32)
-            _lib.check(lib.colvo_geo_loss_fwd(_lib.ptr(d_t), _lib.ptr(d_r), _lib.ptr(pose), _lib.ptr(K), B, H, W, _lib.ptr(ws),
-                                              _lib.ptr(geo_state), sp), "colvo_geo_loss_fwd")
-            terms.append(geo_state[0]); weights.append(float(geo_weight))
-        if smooth_weight:
-            ws = torch.empty(2 * B * ((H * W + 255) // 256), **f32)
-            sm = torch.empty(1, **f32)
-            _lib.check(lib.colvo_smooth_loss_fwd(_lib.ptr(d_t), _lib.ptr(tgt), B, H, W, _lib.ptr(ws), _lib.ptr(sm), sp),
-                       "colvo_smooth_loss_fwd")
-            terms.append(sm[0]); weights.append(float(smooth_weight))
-        wts = _const(dev, ("w",) + tuple(weights), weights)
-        total = torch.dot(torch.stack(terms), wts)
-        ctx.cfg = (B, H, W, num_scales, bool(geo_weight), bool(smooth_weight))
-        ctx.wts = wts
-        ctx.pyr = (ts, rs, ds, Ks, states, raws, parts, geo_state)
-        ctx.save_for_backward(tgt, d_t, d_r, pose, K)
-        return total
+        n = lib.colvo_full_objective_workspace_floats(B, H, W, num_scales)
+        if n == 0:
+            raise ValueError(f"dcdp_full_loss: unsupported shape B={B} H={H} W={W} num_scales={num_scales} (at most 4 scales)")
+        f32 = dict(device=tgt.device, dtype=torch.float32)
+        ws, loss = torch.empty(n, **f32), torch.empty((), **f32)
+        _lib.check(_timed("fwd", lambda: lib.colvo_full_objective_fwd(
+            _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(d_t), _lib.ptr(d_r), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a),
+            _lib.ptr(lcc_b), B, H, W, num_scales, float(ssim_weight), float(geo_weight), float(smooth_weight), _lib.ptr(ws),
+            _lib.ptr(loss), _lib.stream_ptr())), "colvo_full_objective_fwd")
+        ctx.cfg = (B, H, W, num_scales, float(geo_weight), float(smooth_weight))
+        ctx.ws = ws
+        ctx.save_for_backward(pose)
+        return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         lib = _lib.load()
-        tgt, d_t, d_r, pose, K = ctx.saved_tensors
-        B, H, W, num_scales, has_geo, has_smooth = ctx.cfg
-        ts, rs, ds, Ks, states, raws, parts, geo_state = ctx.pyr
-        dev = tgt.device
-        sp = _lib.stream_ptr()
-        f32 = dict(device=dev, dtype=torch.float32)
-        gs = grad_loss.to(torch.float32).reshape(1) * ctx.wts          # dL/d(term_i) for every term: one launch
-        d_pose = d_a = d_b = None
-        d_depth = [None] * num_scales
-        for s_ in range(num_scales):
-            h, w = H >> s_, W >> s_
-            dd, dp = torch.empty(B, 1, h, w, **f32), torch.empty(B, 6, **f32)
-            da, db = torch.empty(B, 1, **f32), torch.empty(B, 1, **f32)
-            _lib.check(_timed("bwd", lambda: lib.colvo_warp_loss_fused_bwd(
-                _lib.ptr(states[s_]), _lib.ptr(gs[s_:s_ + 1]), _lib.ptr(raws[s_]), _lib.ptr(parts[s_]), _lib.ptr(pose), B, h, w,
-                _lib.ptr(dd), _lib.ptr(dp), _lib.ptr(da), _lib.ptr(db), sp)), "colvo_warp_loss_fused_bwd")
-            d_depth[s_] = dd
-            d_pose = dp if d_pose is None else d_pose.add_(dp)
-            d_a = da if d_a is None else d_a.add_(da)
-            d_b = db if d_b is None else d_b.add_(db)
-        for s_ in range(num_scales - 1, 0, -1):                        # pooled levels hand their gradient up the pyramid
-            h, w = H >> (s_ - 1), W >> (s_ - 1)
-            up = torch.empty(B, 1, h, w, **f32)
-            _lib.check(lib.colvo_avgpool2_bwd(_lib.ptr(d_depth[s_]), B, h, w, _lib.ptr(up), sp), "colvo_avgpool2_bwd")
-            d_depth[s_ - 1].add_(up)
-        g_dt, g_dr = d_depth[0], None
-        k = num_scales
-        if has_geo:
-            ws = torch.empty(lib.colvo_geo_loss_workspace_floats(B, H, W), **f32)
-            gt, g_dr, gp = torch.empty_like(d_t), torch.empty_like(d_r), torch.empty(B, 6, **f32)
-            _lib.check(lib.colvo_geo_loss_bwd(_lib.ptr(d_t), _lib.ptr(d_r), _lib.ptr(pose), _lib.ptr(K), B, H, W,
-                                              _lib.ptr(geo_state), _lib.ptr(gs[k:k + 1]), _lib.ptr(ws), _lib.ptr(gt), _lib.ptr(g_dr),
-                                              _lib.ptr(gp), sp), "colvo_geo_loss_bwd")
-            g_dt.add_(gt)
-            d_pose.add_(gp)
-            k += 1
-        if has_smooth:
-            sd = torch.empty_like(d_t)
-            _lib.check(lib.colvo_smooth_loss_bwd(_lib.ptr(d_t), _lib.ptr(tgt), B, H, W, _lib.ptr(gs[k:k + 1]), _lib.ptr(sd), sp),
-                       "colvo_smooth_loss_bwd")
-            g_dt.add_(sd)
-        ctx.pyr = None
-        return None, None, g_dt, g_dr, d_pose, None, d_a, d_b, None, None, None, None
+        (pose,) = ctx.saved_tensors
+        B, H, W, num_scales, geo_weight, smooth_weight = ctx.cfg
+        ws, ctx.ws = ctx.ws, None
+        if ws is None:
+            raise RuntimeError("dcdp_full_loss: backward through the same node twice (its workspace is released after the first)")
+        f32 = dict(device=pose.device, dtype=torch.float32)
+        g = grad_loss.to(torch.float32).contiguous()
+        g_dt = torch.empty(B, 1, H, W, **f32)
+        g_dr = torch.empty(B, 1, H, W, **f32) if geo_weight else None
+        dp, da, db = torch.empty(B, 6, **f32), torch.empty(B, 1, **f32), torch.empty(B, 1, **f32)
+        _lib.check(_timed("bwd", lambda: lib.colvo_full_objective_bwd(
+            _lib.ptr(ws), _lib.ptr(g), _lib.ptr(pose), B, H, W, num_scales, geo_weight, smooth_weight, _lib.ptr(g_dt),
+            _lib.ptr(g_dr), _lib.ptr(dp), _lib.ptr(da), _lib.ptr(db), _lib.stream_ptr())), "colvo_full_objective_bwd")
+        return None, None, g_dt, g_dr, dp, None, da, db, None, None, None, None
+
+
+def full_objective_terms(loss: torch.Tensor):
+    """Not part of the spec: the individual terms of the dcdp_full_loss value `loss` came from, for logging -- a view of 32
+    device floats: [0] total, [1] geometric term, [2] smoothness term, [4 + 4 s] photometric loss of pyramid level s."""
+    fn = loss.grad_fn
+    if fn is None or not hasattr(fn, "ws") or fn.ws is None:
+        raise ValueError("full_objective_terms: needs the (not yet back-propagated) output of dcdp_full_loss")
+    B, H, W, S, _, _ = fn.cfg
+    import ctypes
+    state = ctypes.c_void_p()
+    _lib.check(_lib.load().colvo_full_objective_terms(_lib.ptr(fn.ws), B, H, W, S, ctypes.byref(state)), "colvo_full_objective_terms")
+    off = (state.value - fn.ws.data_ptr()) // 4
+    return fn.ws[off:off + 32]
 
 
 def dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, *, geo_weight: float = GEO_WEIGHT,
                    smooth_weight: float = SMOOTH_WEIGHT, num_scales: int = NUM_SCALES,
                    ssim_weight: float = SSIM_WEIGHT) -> torch.Tensor:
     """Multi-scale photometric + geo_weight * geometric consistency + smooth_weight * smoothness (spec: dcdp_full_loss),
-    as one autograd node (dcdp_full_loss_composite is the term-by-term form the tests compare it with)."""
+    as one autograd node over two native calls (dcdp_full_loss_composite is the term-by-term form the tests compare it
+    with).  d_r may be None when geo_weight == 0."""
     return _FullObjective.apply(tgt, ref, d_t, d_r, pose, K, lcc_a, lcc_b, float(geo_weight), float(smooth_weight),
                                 int(num_scales), float(ssim_weight))
 

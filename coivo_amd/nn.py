@@ -452,6 +452,15 @@ class DepthNet(_ArenaModule):
         d_l._colvo_handover = hand
         return d_t, d_r, d_l
 
+    def forward_pair_full(self, frames: torch.Tensor):
+        """forward_pair with BOTH depths a second time -> (depth_t, depth_r, depth_t', depth_r'): the primed pair goes to an
+        objective that consumes both frames' depth (functional.dcdp_full_loss) and to nothing else, the plain pair to
+        PoseNet.  The backward node then receives the four gradients separately and the head's backward kernel adds them
+        while it reads them: no autograd accumulation, zero-fill or concatenation kernels."""
+        if frames.dim() != 4 or frames.shape[0] % 2:
+            raise ValueError("forward_pair_full: expected [2B,3,H,W]")
+        return _DepthNetPairFn.apply(self, frames, self._trigger(), None, True)
+
     # ---- whole-network forward / backward ---------------------------------------------------- #
     def _plan(self, B, H, W):
         dt = self.compute_dtype
@@ -506,8 +515,8 @@ class DepthNet(_ArenaModule):
         return depth, (A, P, inst)
 
     def _backward_impl(self, saved, depth: torch.Tensor, d_depth: Optional[torch.Tensor], parts=None) -> None:
-        """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b): the gradient of the first / second
-        half of the images and an unnormalised addend for the first half (ops.depth_head_bwd_parts), each may be None."""
+        """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b[, g_raw_second]): the gradient of the
+        first / second half of the images and a (scaled) addend for each half (ops.depth_head_bwd_parts), each may be None."""
         A, P, inst = saved
         self.attach_grads()
         B, _, H, W = depth.shape
@@ -518,7 +527,7 @@ class DepthNet(_ArenaModule):
             which = "bwd"
         else:
             parts = tuple(_dealias([None if t is None else t.contiguous() for t in parts]))
-            names = ("g_first", "g_second", "g_raw", "scale_a", "scale_b")
+            names = ("g_first", "g_second", "g_raw", "scale_a", "scale_b", "g_raw_second")
             ext = {"depth": depth}
             ext.update({n: t for n, t in zip(names, parts) if t is not None})
             which = "bwd:" + ",".join(n for n, t in zip(names, parts) if t is not None)
@@ -545,7 +554,8 @@ class DepthNet(_ArenaModule):
             if parts is None:
                 ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
             else:
-                ops.depth_head_bwd_parts(x1, self.head.w_master, depth, *parts, scratch, g)
+                ops.depth_head_bwd_parts(x1, self.head.w_master, depth, *parts[:5], scratch, g,
+                                         parts[5] if len(parts) > 5 else None)
             self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
                                                                     self.deterministic), x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
@@ -599,24 +609,26 @@ class _DepthNetPairFn(torch.autograd.Function):
     backward kernel as they are (no zero-fill, cat or add kernels in between)."""
 
     @staticmethod
-    def forward(ctx, net: DepthNet, frames, trigger, handover):
+    def forward(ctx, net: DepthNet, frames, trigger, handover, both=False):
         depth, saved = net._forward_impl(frames)
         ctx.net, ctx.saved, ctx.handover = net, saved, handover
         ctx.lease = _Lease(saved[2])
         ctx.save_for_backward(depth)
         B = frames.shape[0] // 2
+        if both:                                   # forward_pair_full: BOTH depths once more, for an objective that takes both
+            return depth[:B], depth[B:], depth[:B], depth[B:]
         return depth[:B], depth[B:], depth[:B]
 
     @staticmethod
-    def backward(ctx, g_t, g_r, g_l):
+    def backward(ctx, g_t, g_r, g_l, g_lr=None):
         (depth,) = ctx.saved_tensors
         sa = sb = None
         if ctx.handover is not None:
             sa, sb = ctx.handover.take((g_l,))     # unnormalised loss gradient + its two device scale factors
-        ctx.net._backward_impl(ctx.saved, depth, None, parts=(g_t, g_r, g_l, sa, sb))
+        ctx.net._backward_impl(ctx.saved, depth, None, parts=(g_t, g_r, g_l, sa, sb, g_lr))
         ctx.saved = None
         ctx.lease.release()
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class PoseNet(_ArenaModule):
@@ -741,18 +753,27 @@ class _PoseNetFn(torch.autograd.Function):
         return None, None, None, d_t, d_r, None, None
 
 
-def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85, full_loss: bool = False):
+def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_weight: float = 0.85, full_loss: bool = False,
+                 frames: Optional[torch.Tensor] = None):
     """One coupled DCDP forward (spec: dcdp_forward): depth of both frames -> pose + LCC -> loss
-    (full_loss: the widened objective dcdp_full_loss -- multi-scale photometric + geometric consistency + smoothness)."""
+    (full_loss: the widened objective dcdp_full_loss -- multi-scale photometric + geometric consistency + smoothness).
+    frames (not in the spec): the pair batch already stacked as [target frames | reference frames] = [2B,3,H,W], as the loader
+    delivers it; tgt / ref are then ignored (may be None) and the concatenation kernel is saved."""
     from .functional import dcdp_full_loss, photometric_loss
+    if frames is not None:
+        if frames.dim() != 4 or frames.shape[0] % 2:
+            raise ValueError("dcdp_forward: frames must be [2B,3,H,W]")
+        tgt, ref = frames[:frames.shape[0] // 2], frames[frames.shape[0] // 2:]
+    else:
+        frames = torch.cat([tgt, ref], dim=0)
     if full_loss:
-        # several consumers of the depth and pose tensors: ordinary autograd accumulation (no gradient hand-over)
-        d_t, d_r = depth_net.forward_pair(torch.cat([tgt, ref], dim=0))
+        # the objective is one native call that returns finished gradients (no hand-over of scale factors); the depth of both
+        # frames reaches it through outputs of their own, so no gradient is accumulated by autograd
+        d_t, d_r, d_lt, d_lr = depth_net.forward_pair_full(frames)
         pose, a, b = pose_net(tgt, ref, d_t, d_r)
-        pose, a, b = pose * 1.0, a * 1.0, b * 1.0        # plain tensors: the loss takes its general path
-        loss = dcdp_full_loss(tgt, ref, d_t, d_r, pose, K, a, b, ssim_weight=ssim_weight)
+        loss = dcdp_full_loss(tgt, ref, d_lt, d_lr, pose, K, a, b, ssim_weight=ssim_weight)
         return loss, d_t, d_r, pose, a, b
-    d_t, d_r, d_l = depth_net.forward_pair_split(torch.cat([tgt, ref], dim=0))
+    d_t, d_r, d_l = depth_net.forward_pair_split(frames)
     pose, a, b = pose_net(tgt, ref, d_t, d_r)
     loss = photometric_loss(tgt, ref, d_l, pose, K, a, b, ssim_weight=ssim_weight)     # d_l aliases d_t (its own grad path)
     return loss, d_t, d_r, pose, a, b

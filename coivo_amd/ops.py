@@ -183,18 +183,21 @@ def depth_head_bwd(x, w, depth, d_depth, scratch, dx, dw, db) -> None:
                                         _lib.ptr(db), _lib.stream_ptr()), "colvo_depth_head_bwd")
 
 
-def depth_head_bwd_parts(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx) -> None:
-    """depth_head_bwd with the incoming gradient in parts (DCDP step, depth of 2*Bh images): first half
-    g_first + scale_a[0]*scale_b[0]*g_raw, second half g_second; any part may be None.  Weight gradient: depth_head_wgrad."""
-    _need_cuda(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx)
+def depth_head_bwd_parts(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx, g_raw_second=None) -> None:
+    """depth_head_bwd with the incoming gradient in parts (DCDP step, depth of 2*Bh images): with s = scale_a[0]*scale_b[0],
+    first half g_first + s*g_raw, second half g_second + s*g_raw_second; any part may be None.  Weight gradient:
+    depth_head_wgrad."""
+    _need_cuda(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx, g_raw_second)
     B, H, W, Cc = x.shape
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_DEPTH_HEAD_BWD_PARTS, None, (x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx),
+        return rec.add(_lib.CMD_DEPTH_HEAD_BWD_PARTS, None,
+                       (x, w, depth, g_first, g_second, g_raw, scale_a, scale_b, scratch, dx, g_raw_second),
                        (dt_code(x.dtype), B, H, W, Cc), (MIN_DEPTH, MAX_DEPTH))
     lib = _lib.load()
     _lib.check(lib.colvo_depth_head_bwd_parts(dt_code(x.dtype), _lib.ptr(x), _lib.ptr(w), _lib.ptr(depth), _lib.ptr(g_first),
-                                              _lib.ptr(g_second), _lib.ptr(g_raw), _lib.ptr(scale_a), _lib.ptr(scale_b),
+                                              _lib.ptr(g_second), _lib.ptr(g_raw), _lib.ptr(g_raw_second), _lib.ptr(scale_a),
+                                              _lib.ptr(scale_b),
                                               B, H, W, Cc, MIN_DEPTH, MAX_DEPTH, _lib.ptr(scratch), _lib.ptr(dx), 0, 0,
                                               _lib.stream_ptr()), "colvo_depth_head_bwd_parts")
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 5
+#define COLVO_ABI_VERSION 6
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -109,6 +109,33 @@ int colvo_smooth_loss_bwd(const float* depth, const float* img, int B, int H, in
 /* x [planes,H,W] -> y [planes,H/2,W/2] (mean of each 2x2 block), and its gradient dy -> dx (H, W: the INPUT extent). */
 int colvo_avgpool2_fwd(const float* x, int planes, int H, int W, float* y, colvo_stream_t stream);
 int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, float* dx, colvo_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------- *
+ * SURVEY.md §8f-1 + §8f-2 in ONE call: the widened objective (spec: dcdp_full_loss)            *
+ *   mean_s photometric_loss(pyramid level s) + geo_weight * geometric_consistency_loss        *
+ *   + smooth_weight * smoothness_loss, value AND every gradient.                               *
+ *   README.md:1 "Considering Geometric and Photometric Consistency", :7.                       *
+ * ------------------------------------------------------------------------------------------- */
+/* Forward: 4 + num_scales launches, no host synchronisation -- smoothness (value + raw gradient), the 2x2-average pyramid
+ * of both frames and the target depth (one launch per level, intrinsics scaled inside the kernels), the one-pass
+ * photometric kernel per level (loss + unnormalised gradients), whose level-0 launch ALSO evaluates the geometric-
+ * consistency term on the projection and bilinear taps it has anyway (the reference frame's depth depth_r is a fourth
+ * sampled plane), and one finalize.  The gradient w.r.t. depth_r is scattered as 64-bit fixed-point atomics (2^-32 units):
+ * bit-reproducible.  tgt, ref [B,3,H,W]; depth_t, depth_r [B,1,H,W] (depth_r may be NULL when geo_weight == 0);
+ * H, W divisible by 2^(num_scales-1), 1 <= num_scales <= 4.  workspace: colvo_full_objective_workspace_floats() floats,
+ * 16-byte aligned, kept untouched until the backward call; loss: one device float.
+ * Backward: ONE launch; grad_loss: device scalar dL/dloss; d_depth_t, d_depth_r [B,1,H,W] (d_depth_r may be NULL when
+ * geo_weight == 0), d_pose [B,6], d_a, d_b [B].  colvo_full_objective_terms: *state -> 32 device floats inside the workspace:
+ * [0] total, [1] geometric term, [2] smoothness term, [4+4s ..] level s: {photometric loss, (1/S)/max(3 n_valid,1), n_valid}. */
+size_t colvo_full_objective_workspace_floats(int B, int H, int W, int num_scales);
+int colvo_full_objective_fwd(const float* tgt, const float* ref, const float* depth_t, const float* depth_r,
+                             const float* pose, const float* K, const float* lcc_a, const float* lcc_b, int B, int H, int W,
+                             int num_scales, float ssim_weight, float geo_weight, float smooth_weight, float* workspace,
+                             float* loss, colvo_stream_t stream);
+int colvo_full_objective_bwd(const float* workspace, const float* grad_loss, const float* pose, int B, int H, int W,
+                             int num_scales, float geo_weight, float smooth_weight, float* d_depth_t, float* d_depth_r,
+                             float* d_pose, float* d_a, float* d_b, colvo_stream_t stream);
+int colvo_full_objective_terms(const float* workspace, int B, int H, int W, int num_scales, const float** state);
 
 /* Un-fused debugging entry (spec: inverse_warp()).  ref [B,C,H,W] -> warped [B,C,H,W], valid [B,1,H,W]. */
 int colvo_inverse_warp(const float* ref, const float* depth, const float* pose, const float* K,
@@ -210,13 +237,14 @@ int colvo_depth_head_bwd(int dtype, const void* x, const float* w, const float* 
 int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, int H, int W, int C,
                            float* dw, float* db, colvo_stream_t stream);
 /* colvo_depth_head_bwd with the incoming gradient given in parts (the DCDP step: DepthNet ran on B = 2*Bh images, target
- * frames first): d_depth[b] = g_first[b] + scale_a[0]*scale_b[0]*g_raw[b] for b < Bh, g_second[b-Bh] for b >= Bh.
- * g_first, g_second, g_raw: [Bh,1,H,W] each, any of them may be NULL (= zero); scale_a, scale_b: device scalars, NULL = 1
- * (the fused loss hands over d_depth_raw with grad_loss and loss_state + 1).  No concatenated / summed copy is made. */
+ * frames first): with s = scale_a[0]*scale_b[0], d_depth[b] = g_first[b] + s*g_raw[b] for b < Bh,
+ * g_second[b-Bh] + s*g_raw_second[b-Bh] for b >= Bh.  g_first, g_second, g_raw, g_raw_second: [Bh,1,H,W] each, any of them
+ * may be NULL (= zero); scale_a, scale_b: device scalars, NULL = 1 (the fused loss hands over d_depth_raw with grad_loss and
+ * loss_state + 1; the widened objective hands over finished gradients for both halves).  No concatenated / summed copy is made. */
 int colvo_depth_head_bwd_parts(int dtype, const void* x, const float* w, const float* depth, const float* g_first,
-                               const float* g_second, const float* g_raw, const float* scale_a, const float* scale_b,
-                               int B, int H, int W, int C, float min_depth, float max_depth, float* scratch,
-                               void* dx, float* dw, float* db, colvo_stream_t stream);
+                               const float* g_second, const float* g_raw, const float* g_raw_second, const float* scale_a,
+                               const float* scale_b, int B, int H, int W, int C, float min_depth, float max_depth,
+                               float* scratch, void* dx, float* dw, float* db, colvo_stream_t stream);
 
 /* PoseNet head: 1x1 conv (C -> 8) + spatial mean + (POSE_SCALE, LCC_SCALE) affine.
  * out (8*B floats) is PLANAR: [ pose B x 6 | lcc_a B | lcc_b B ] so the three results are contiguous views;
@@ -293,7 +321,7 @@ enum {
     COLVO_CMD_POSE_HEAD_BWD,     /* i: dtype B HW C det; f: pose_scale lcc_scale; p: x w d_pose d_a d_b dx dw db scale_a scale_b */
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
     COLVO_CMD_JOIN,              /* main stream waits for the side stream's work so far */
-    COLVO_CMD_DEPTH_HEAD_BWD_PARTS, /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx */
+    COLVO_CMD_DEPTH_HEAD_BWD_PARTS, /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx g_raw_second */
     COLVO_CMD_CONV_DGRAD_BOTH     /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
 };
 

@@ -147,3 +147,76 @@ def test_full_loss_one_node_equals_composite(B, H, W, geo, smooth, scales):
         scale = max(c.abs().max().item(), 1e-20)
         # geometric-consistency tap gradients are float atomics: order-dependent in the last bits
         assert (a - c).abs().max().item() <= 2e-5 * scale + 1e-9, (name, (a - c).abs().max().item(), scale)
+
+
+def _objective_run(fn, d, d_r, **args):
+    leaves = [d[k].clone().requires_grad_(True) for k in ("gt_depth", "gt_pose", "gt_a", "gt_b")]
+    dr = None if d_r is None else d_r.clone().requires_grad_(True)
+    loss = fn(d["tgt"], d["ref"], leaves[0], dr, leaves[1], d["K"], leaves[2], leaves[3], **args)
+    grads = torch.autograd.grad(loss * 2.0, leaves + ([dr] if dr is not None else []), allow_unused=True)
+    return loss, grads
+
+
+@pytest.mark.parametrize("B,H,W,geo,smooth,scales", [(1, 4, 4, 0.5, 0.1, 1), (2, 33, 47, 0.5, 0.1, 1), (2, 36, 52, 0.7, 0.0, 3),
+                                                     (1, 64, 124, 0.5, 0.2, 2), (3, 40, 72, 0.25, 0.1, 4)])
+def test_full_loss_native_against_live_oracle(B, H, W, geo, smooth, scales):
+    """The native objective (geometric term inside the level-0 one-pass kernel) on ragged shapes -- odd widths at one scale,
+    strips that end inside a wave, four levels -- against the oracle's dcdp_full_loss, value and every gradient."""
+    from coivo_amd import functional as Fh
+    from oracle import colvo_spec as S
+    b = synth.make_batch(B, H, W, seed=300 + H)
+    d = to_dev(b)
+    d_r = d["gt_depth"] * 1.07 + 0.05
+    args = dict(geo_weight=geo, smooth_weight=smooth, num_scales=scales)
+    lh, gh = _objective_run(Fh.dcdp_full_loss, d, d_r, **args)
+    bo = {k: v.clone() for k, v in b.items()}
+    lo, go = _objective_run(S.dcdp_full_loss, bo, bo["gt_depth"] * 1.07 + 0.05, **args)
+    assert abs(lh.item() - lo.item()) < 1e-5
+    for a, c, name in zip(gh, go, ("d_t", "pose", "a", "b", "d_r")):
+        assert_close_frac(a, c, rtol=2e-3, atol_scale=3e-4 if name.startswith("d_") else 3e-3,
+                          max_bad_frac=2e-3 if name.startswith("d_") else 0, what=name)
+
+
+def test_full_loss_is_bit_reproducible_and_optional_reference_depth():
+    """The scatter of the geometric term's tap gradients is fixed-point (integer atomics): two runs agree bit for bit, in
+    every gradient.  Without the geometric term the reference depth may be omitted and receives no gradient."""
+    from coivo_amd import functional as Fh
+    B, H, W = 4, 128, 192
+    d = to_dev(synth.make_batch(B, H, W, seed=77))
+    d_r = d["gt_depth"] * 0.93 + 0.02
+    runs = [_objective_run(Fh.dcdp_full_loss, d, d_r) for _ in range(3)]
+    for l, g in runs[1:]:
+        assert torch.equal(l, runs[0][0])
+        for a, c in zip(g, runs[0][1]):
+            assert torch.equal(a, c)
+    assert float(runs[0][1][4].abs().max()) > 0.0
+    l0, g0 = _objective_run(Fh.dcdp_full_loss, d, None, geo_weight=0.0)
+    l1, g1 = _objective_run(Fh.dcdp_full_loss, d, d_r, geo_weight=0.0)
+    assert torch.equal(l0, l1) and g1[4] is None
+    with pytest.raises(ValueError):
+        Fh.dcdp_full_loss(d["tgt"], d["ref"], d["gt_depth"], None, d["gt_pose"], d["K"], d["gt_a"], d["gt_b"])
+
+
+def test_full_loss_terms_view_and_errors():
+    from coivo_amd import functional as Fh
+    from oracle import colvo_spec as S
+    B, H, W = 2, 48, 64
+    b = synth.make_batch(B, H, W, seed=5)
+    d = to_dev(b)
+    d_t = d["gt_depth"].clone().requires_grad_(True)
+    d_r = d["gt_depth"] * 1.1
+    loss = Fh.dcdp_full_loss(d["tgt"], d["ref"], d_t, d_r, d["gt_pose"], d["K"], d["gt_a"], d["gt_b"])
+    terms = Fh.full_objective_terms(loss).cpu()
+    geo = S.geometric_consistency_loss(b["gt_depth"], b["gt_depth"] * 1.1, b["gt_pose"], b["K"]).item()
+    sm = S.smoothness_loss(b["gt_depth"], b["tgt"]).item()
+    ph = S.photometric_loss(b["tgt"], b["ref"], b["gt_depth"], b["gt_pose"], b["K"], b["gt_a"], b["gt_b"]).item()
+    assert abs(terms[0].item() - loss.item()) == 0.0
+    assert abs(terms[1].item() - geo) < 1e-5 and abs(terms[2].item() - sm) < 1e-5 and abs(terms[4].item() - ph) < 1e-5
+    loss.backward()
+    with pytest.raises(ValueError):
+        Fh.full_objective_terms(loss)                       # the workspace is gone after the backward
+    with pytest.raises(ValueError):
+        Fh.dcdp_full_loss(d["tgt"][..., :62], d["ref"][..., :62], d_t[..., :62], d_r[..., :62], d["gt_pose"], d["K"], d["gt_a"],
+                          d["gt_b"])                        # 62 is not divisible by 4
+    with pytest.raises(ValueError):
+        Fh.dcdp_full_loss(d["tgt"], d["ref"], d_t, d_r, d["gt_pose"], d["K"], d["gt_a"], d["gt_b"], num_scales=5)
