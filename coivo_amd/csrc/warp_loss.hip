@@ -710,26 +710,15 @@ struct GeoArgs {
     float grho;
 };
 
-template <bool FUSED, bool GEO = false>
-__global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
-    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
-    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
-    const float* __restrict__ lcc_b, int B, int H, int W, int strips_x, int nseg, int seg_rows, float alpha,
-    const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
-    float* __restrict__ partials, int level, GeoArgs ga) {
+// one wave's strip segment: everything after the per-image geometry has been put into LDS (sgeo) by the caller
+template <bool FUSED, bool GEO>
+__device__ __forceinline__ void march_body(const float* __restrict__ tgt, const float* __restrict__ ref,
+                                           const float* __restrict__ depth, int H, int W, int seg_rows, float alpha,
+                                           const float* __restrict__ loss_state, const float* __restrict__ grad_loss,
+                                           float* __restrict__ d_depth, float* __restrict__ partials, const GeoArgs& ga,
+                                           int item, bool live, int b, int seg, int strip, int lane, const float* sgeo) {
     static_assert(FUSED || !GEO, "the geometric-consistency term rides on the one-pass form only");
-    __shared__ float s_geo[4][GEO_N + 4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: keeps the buffer descriptors uniform
-    const int nitems = B * nseg * strips_x;
-    const int item_raw = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // (image, segment, strip), strip fastest
-    const bool live = item_raw < nitems;
-    const int item = live ? item_raw : nitems - 1;
-    const int b = item / (nseg * strips_x), rem = item - b * (nseg * strips_x);
-    const int seg = rem / strips_x, strip = rem - seg * strips_x;
-    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave], level);
-    __syncthreads();
-    const Geo g = geo_load(s_geo[wave]);
+    const Geo g = geo_load(sgeo);
     Img im = img_make(tgt, ref, depth, b, H, W);
     unsigned long long* dr_acc = nullptr;
     float* geo_img = nullptr;
@@ -833,6 +822,74 @@ __global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
     }
 }
 
+template <bool FUSED, bool GEO = false>
+__global__ __launch_bounds__(NT, 2) void k_warp_loss_bwd_march(
+    const float* __restrict__ tgt, const float* __restrict__ ref, const float* __restrict__ depth,
+    const float* __restrict__ pose, const float* __restrict__ K, const float* __restrict__ lcc_a,
+    const float* __restrict__ lcc_b, int B, int H, int W, int strips_x, int nseg, int seg_rows, float alpha,
+    const float* __restrict__ loss_state, const float* __restrict__ grad_loss, float* __restrict__ d_depth,
+    float* __restrict__ partials, int level, GeoArgs ga) {
+    __shared__ float s_geo[4][GEO_N + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: keeps the buffer descriptors uniform
+    const int nitems = B * nseg * strips_x;
+    const int item_raw = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // (image, segment, strip), strip fastest
+    const bool live = item_raw < nitems;
+    const int item = live ? item_raw : nitems - 1;
+    const int b = item / (nseg * strips_x), rem = item - b * (nseg * strips_x);
+    const int seg = rem / strips_x, strip = rem - seg * strips_x;
+    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave], level);
+    __syncthreads();
+    march_body<FUSED, GEO>(tgt, ref, depth, H, W, seg_rows, alpha, loss_state, grad_loss, d_depth, partials, ga, item, live, b, seg,
+                           strip, lane, s_geo[wave]);
+}
+
+// The one-pass kernel over SEVERAL pyramid levels in one launch (the widened objective): the strip segments of level 0 come
+// first, the small levels fill the tail of the launch instead of paying a launch + drain each.  Every level's workgroup count
+// is padded to a multiple of 8 so that each XCD (workgroups are dealt round-robin) gets a contiguous eighth of every level.
+constexpr int MARCH_MAX_LEVELS = 4;
+struct MarchLevel {
+    const float *tgt, *ref, *depth;
+    float *d_depth, *partials;
+    int H, W, strips_x, nseg, seg_rows;
+    int wg8;                     // workgroups of this level per XCD
+};
+struct MarchLevels {
+    int S;
+    MarchLevel lv[MARCH_MAX_LEVELS];
+};
+
+template <bool GEO>
+__global__ __launch_bounds__(NT, 2) void k_warp_loss_march_levels(MarchLevels ml, const float* __restrict__ pose,
+                                                                  const float* __restrict__ K, const float* __restrict__ lcc_a,
+                                                                  const float* __restrict__ lcc_b, int B, float alpha, GeoArgs ga) {
+    __shared__ float s_geo[4][GEO_N + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = blockIdx.x & 7;
+    int k = blockIdx.x >> 3, l = 0;
+    // the level this workgroup belongs to and its fields, by scalar selects (no dynamically indexed copy of the argument)
+    MarchLevel L = ml.lv[0];
+#pragma unroll
+    for (int i = 1; i < MARCH_MAX_LEVELS; ++i) {
+        if (i < ml.S && l == i - 1 && k >= L.wg8) { k -= L.wg8; l = i; L = ml.lv[i]; }
+    }
+    const int nitems = B * L.nseg * L.strips_x;
+    const int item_raw = (xcd * L.wg8 + k) * 4 + wave;          // (image, segment, strip), strip fastest
+    const bool live = item_raw < nitems;
+    const int item = live ? item_raw : nitems - 1;
+    const int b = item / (L.nseg * L.strips_x), rem = item - b * (L.nseg * L.strips_x);
+    const int seg = rem / L.strips_x, strip = rem - seg * L.strips_x;
+    if (lane == 0) geo_compute(pose, K, lcc_a, lcc_b, b, s_geo[wave], l);
+    __syncthreads();
+    if (GEO && l == 0)
+        march_body<true, GEO>(L.tgt, L.ref, L.depth, L.H, L.W, L.seg_rows, alpha, nullptr, nullptr, L.d_depth, L.partials, ga, item,
+                              live, b, seg, strip, lane, s_geo[wave]);
+    else
+        march_body<true, false>(L.tgt, L.ref, L.depth, L.H, L.W, L.seg_rows, alpha, nullptr, nullptr, L.d_depth, L.partials, ga,
+                                item, live, b, seg, strip, lane, s_geo[wave]);
+}
+
 // fused forward, second kernel: blocks 0..B-1 fold the 14 gradient sums of one image (still unnormalised) into
 // gpart[b][14]; block B folds the loss sum and the valid count of ALL strips into loss_state.  Fixed orders: deterministic.
 // dR (row-major 3x3 gradient w.r.t. the rotation matrix) -> gradient w.r.t. the Euler angles (R = Rz Ry Rx)
@@ -848,45 +905,74 @@ __device__ __forceinline__ void dR_to_euler(const float* dR, const float* p, flo
         + dR[3] * (cz * cy) + dR[4] * (cz * sy * sx - sz * cx) + dR[5] * (cz * sy * cx + sz * sx);
 }
 
+// The finalize kernels run 1024 threads per workgroup: they are chains of dependent strided loads (one partial per strip
+// segment), so their duration is the number of sequential trips to L2 -- 7 -> 2 for the loss sums of BASELINE configs[1], 30 -> 8
+// at configs[2] -- not bandwidth.
+constexpr int FT = 1024;
+constexpr int FROWS = FT / NPART;           // 73 partial rows per pass
+
+// sums of NV per-thread values over the FT threads: DPP inside the wave, then thread 0 adds the 16 wave totals in order
+template <int NV>
+__device__ __forceinline__ void block_sums(float (&v)[NV], float* sh) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float t = wave_sum(v[q]);
+        if ((tid & 63) == 0) sh[(tid >> 6) * NV + q] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            float t = 0.0f;
+            for (int w = 0; w < FT / 64; ++w) t += sh[w * NV + q];
+            v[q] = t;
+        }
+    }
+}
+
+// the 14 gradient sums of image b over its strip segments (partials of NPART_F floats each), fixed order; the result is
+// valid in threads 0..13 (and left in sh[0..13] after a barrier when `publish`)
+__device__ __forceinline__ float image_sums(const float* __restrict__ pp, int b, int bpi, float* sh) {
+    const int tid = threadIdx.x, k = tid % NPART, r = tid / NPART;
+    float acc = 0.0f;
+    if (r < FROWS) {
+        for (int i = r; i < bpi; i += FROWS) acc += pp[((size_t)b * bpi + i) * NPART_F + k];
+        sh[k * FROWS + r] = acc;
+    }
+    __syncthreads();
+    float t = 0.0f;
+    if (tid < NPART)
+        for (int i = 0; i < FROWS; ++i) t += sh[tid * FROWS + i];
+    return t;
+}
+
 // gunit (may be null): the pose / LCC gradients of every image, still UNNORMALISED, already converted to Euler angles, in
 // PoseNet's planar output layout [d_pose B x 6 | d_a B | d_b B] -- for consumers that apply dL/dloss / max(3 n, 1) themselves
-__global__ __launch_bounds__(NT) void k_warp_loss_fused_finalize(const float* __restrict__ partials, int blocks_per_image,
+__global__ __launch_bounds__(FT) void k_warp_loss_fused_finalize(const float* __restrict__ partials, int blocks_per_image,
                                                                  int B, const float* __restrict__ pose,
                                                                  float* __restrict__ gpart, float* __restrict__ gunit,
                                                                  float* __restrict__ loss_state) {
-    __shared__ float s0[NT], s1[NT];
+    __shared__ float sh[FT];
+    __shared__ float s1[NPART + 2];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x == B) {
         const int n = B * blocks_per_image;
-        float a = 0.0f, c = 0.0f;
-        for (int i = tid; i < n; i += NT) { a += partials[(size_t)i * NPART_F + 14]; c += partials[(size_t)i * NPART_F + 15]; }
-        s0[tid] = a; s1[tid] = c;
-        __syncthreads();
-        for (int o = NT / 2; o > 0; o >>= 1) {
-            if (tid < o) { s0[tid] += s0[tid + o]; s1[tid] += s1[tid + o]; }
-            __syncthreads();
-        }
+        float v[2] = {0.0f, 0.0f};
+        for (int i = tid; i < n; i += FT) { v[0] += partials[(size_t)i * NPART_F + 14]; v[1] += partials[(size_t)i * NPART_F + 15]; }
+        block_sums<2>(v, sh);
         if (tid == 0) {
-            const float denom = fmaxf(3.0f * s1[0], 1.0f);
-            loss_state[0] = s0[0] / denom;
+            const float denom = fmaxf(3.0f * v[1], 1.0f);
+            loss_state[0] = v[0] / denom;
             loss_state[1] = 1.0f / denom;
-            loss_state[2] = s1[0];
+            loss_state[2] = v[1];
             loss_state[3] = 0.0f;
         }
         return;
     }
     const int b = blockIdx.x;
-    constexpr int ROWS = NT / NPART;  // 18 partial rows per pass
-    const int k = tid % NPART, r = tid / NPART;
-    float acc = 0.0f;
-    if (r < ROWS)
-        for (int i = r; i < blocks_per_image; i += ROWS) acc += partials[((size_t)b * blocks_per_image + i) * NPART_F + k];
-    float* s = s0;                     // [NPART][ROWS] packed
-    if (r < ROWS) s[k * ROWS + r] = acc;
-    __syncthreads();
+    const float t = image_sums(partials, b, blocks_per_image, sh);
     if (tid < NPART) {
-        float t = 0.0f;
-        for (int i = 0; i < ROWS; ++i) t += s[tid * ROWS + i];
         gpart[b * NPART + tid] = t;
         s1[tid] = t;
     }
@@ -1337,45 +1423,93 @@ __global__ __launch_bounds__(NT) void k_pyramid_level(const float* __restrict__ 
     y[(size_t)p * Ho * Wo + o] = 0.25f * ((r0.x + r0.y) + (r1.x + r1.y));
 }
 
-// smoothness term, value and gradient in one pass (the term's normalisers are pair counts, known before the data): per-block
-// partial {Sx, Sy} as k_smooth_fwd, d term / d depth in gather form as k_smooth_bwd (without dL/dterm); the same thread
-// clears its pixel's fixed-point accumulator of the geometric-consistency scatter (zero_acc may be null)
-__global__ __launch_bounds__(NT) void k_smooth_both(const float* __restrict__ depth, const float* __restrict__ img, int H, int W,
-                                                    float inv_nx, float inv_ny, float* __restrict__ partials,
-                                                    float* __restrict__ d_raw, unsigned long long* __restrict__ zero_acc) {
+// 2x2-average pyramid cell of one plane: NL levels below the source in one go (NL = 2: a 4x4 block -> four level-1 pixels and
+// one level-2 pixel, the same arithmetic as pooling twice).  Hs, Ws: extent of the SOURCE plane (divisible by 2^NL).
+template <int NL>
+__device__ __forceinline__ void pyramid_cell(const float* __restrict__ src, int Hs, int Ws, int cy, int cx,
+                                             float* __restrict__ d1, float* __restrict__ d2) {
+    if constexpr (NL == 1) {
+        const float* xp = src + (size_t)(2 * cy) * Ws + 2 * cx;
+        const float2 r0 = *reinterpret_cast<const float2*>(xp), r1 = *reinterpret_cast<const float2*>(xp + Ws);
+        d1[(size_t)cy * (Ws >> 1) + cx] = 0.25f * ((r0.x + r0.y) + (r1.x + r1.y));
+    } else {
+        const float* xp = src + (size_t)(4 * cy) * Ws + 4 * cx;
+        const float4 r0 = *reinterpret_cast<const float4*>(xp), r1 = *reinterpret_cast<const float4*>(xp + Ws);
+        const float4 r2 = *reinterpret_cast<const float4*>(xp + 2 * (size_t)Ws), r3 = *reinterpret_cast<const float4*>(xp + 3 * (size_t)Ws);
+        const float a00 = 0.25f * ((r0.x + r0.y) + (r1.x + r1.y)), a01 = 0.25f * ((r0.z + r0.w) + (r1.z + r1.w));
+        const float a10 = 0.25f * ((r2.x + r2.y) + (r3.x + r3.y)), a11 = 0.25f * ((r2.z + r2.w) + (r3.z + r3.w));
+        const int W1 = Ws >> 1;
+        *reinterpret_cast<float2*>(d1 + (size_t)(2 * cy) * W1 + 2 * cx) = make_float2(a00, a01);
+        *reinterpret_cast<float2*>(d1 + (size_t)(2 * cy + 1) * W1 + 2 * cx) = make_float2(a10, a11);
+        d2[(size_t)cy * (Ws >> 2) + cx] = 0.25f * ((a00 + a01) + (a10 + a11));
+    }
+}
+
+struct PrepArgs {
+    const float *tgt, *ref, *depth;          // level 0: [B,3,H,W], [B,3,H,W], [B,1,H,W]
+    float *t1, *r1, *d1, *t2, *r2, *d2;      // levels 1 (and 2) of the three tensors
+    float *sm_partials, *sd_raw;             // smoothness: block partials {Sx, Sy}, d term / d depth
+    unsigned long long* zero_acc;            // the geometric term's scatter accumulators to clear (or null)
+    float inv_nx, inv_ny;
+    int B, H, W;
+    int sm_blocks;                           // B * ceil(H W / 256) when the smoothness term is on, else 0
+};
+
+// Everything the one-pass kernels wait for, in ONE launch: blocks [0, sm_blocks) evaluate the smoothness term (value partials
+// and gradient, k_smooth_both's body), the rest build NL levels of the pyramid (one thread per cell of every plane).
+template <int NL>
+__global__ __launch_bounds__(NT) void k_full_prepare(PrepArgs a) {
+    const int H = a.H, W = a.W, B = a.B;
+    if ((int)blockIdx.x >= a.sm_blocks) {
+        if constexpr (NL > 0) {
+            const int hc = H >> NL, wc = W >> NL;
+            const size_t cells = (size_t)hc * wc;
+            const size_t q = (size_t)(blockIdx.x - a.sm_blocks) * NT + threadIdx.x;
+            if (q >= cells * 7 * B) return;
+            int p = (int)(q / cells);
+            const size_t c = q - (size_t)p * cells;
+            const int cy = (int)(c / wc), cx = (int)(c - (size_t)cy * wc);
+            const float* src; float *d1, *d2;
+            if (p < 3 * B) { src = a.tgt; d1 = a.t1; d2 = a.t2; } else if (p < 6 * B) { src = a.ref; d1 = a.r1; d2 = a.r2; p -= 3 * B; }
+            else { src = a.depth; d1 = a.d1; d2 = a.d2; p -= 6 * B; }
+            const size_t plane = (size_t)H * W;
+            pyramid_cell<NL>(src + p * plane, H, W, cy, cx, d1 + p * (plane >> 2), NL > 1 ? d2 + p * (plane >> 4) : nullptr);
+        }
+        return;
+    }
     __shared__ float red[4][2];
-    const int b = blockIdx.y;
     const size_t plane = (size_t)H * W;
-    const size_t o = (size_t)blockIdx.x * NT + threadIdx.x;
+    const int nb = a.sm_blocks / B;
+    const int b = blockIdx.x / nb;
+    const size_t o = (size_t)(blockIdx.x - b * nb) * NT + threadIdx.x;
     float sx = 0.0f, sy = 0.0f;
     if (o < plane) {
         const int v = (int)(o / W), u = (int)(o - (size_t)v * W);
-        const float* dp = depth + (size_t)b * plane;
-        const float* ip = img + (size_t)b * 3 * plane;
+        const float* dp = a.depth + (size_t)b * plane;
+        const float* ip = a.tgt + (size_t)b * 3 * plane;
         const float d0 = 1.0f / dp[o];
         float gd = 0.0f;
         if (u + 1 < W) {
             const float dd = 1.0f / dp[o + 1] - d0, w = edge_w(ip, plane, o, o + 1);
             sx = fabsf(dd) * w;
-            gd -= sgnf(dd) * w * inv_nx;
+            gd -= sgnf(dd) * w * a.inv_nx;
         }
-        if (u >= 1) gd += sgnf(d0 - 1.0f / dp[o - 1]) * edge_w(ip, plane, o - 1, o) * inv_nx;
+        if (u >= 1) gd += sgnf(d0 - 1.0f / dp[o - 1]) * edge_w(ip, plane, o - 1, o) * a.inv_nx;
         if (v + 1 < H) {
             const float dd = 1.0f / dp[o + W] - d0, w = edge_w(ip, plane, o, o + W);
             sy = fabsf(dd) * w;
-            gd -= sgnf(dd) * w * inv_ny;
+            gd -= sgnf(dd) * w * a.inv_ny;
         }
-        if (v >= 1) gd += sgnf(d0 - 1.0f / dp[o - W]) * edge_w(ip, plane, o - W, o) * inv_ny;
-        d_raw[(size_t)b * plane + o] = gd * (-d0 * d0);
-        if (zero_acc) zero_acc[(size_t)b * plane + o] = 0ull;
+        if (v >= 1) gd += sgnf(d0 - 1.0f / dp[o - W]) * edge_w(ip, plane, o - W, o) * a.inv_ny;
+        a.sd_raw[(size_t)b * plane + o] = gd * (-d0 * d0);
+        if (a.zero_acc) a.zero_acc[(size_t)b * plane + o] = 0ull;
     }
     sx = wave_sum(sx); sy = wave_sum(sy);
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = sx; red[threadIdx.x >> 6][1] = sy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const size_t blk = (size_t)b * gridDim.x + blockIdx.x;
-        partials[2 * blk] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-        partials[2 * blk + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        a.sm_partials[2 * (size_t)blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+        a.sm_partials[2 * (size_t)blockIdx.x + 1] = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     }
 }
 
@@ -1388,12 +1522,12 @@ struct FullLevels {
 
 // Blocks 0 .. S*B-1: the 14 gradient sums of one image at one level (still unnormalised) -> gpart[s][b][14].
 // Last block: every term's value and normaliser -> state, the weighted total -> state[0] and loss_out: each thread gathers
-// its share of all (at most 11) sums, the waves reduce them by DPP, thread 0 adds the four wave totals.  Fixed orders.
-__global__ __launch_bounds__(NT) void k_full_finalize(FullLevels lv, const float* __restrict__ geo_partials,
+// its share of all (at most 11) sums at once.  Fixed orders: deterministic.
+__global__ __launch_bounds__(FT) void k_full_finalize(FullLevels lv, const float* __restrict__ geo_partials,
                                                       const float* __restrict__ sm_partials, int sm_nblk, float inv_nx,
                                                       float inv_ny, float w_geo, float w_sm, float* __restrict__ gpart,
                                                       float* __restrict__ state, float* __restrict__ loss_out) {
-    __shared__ float sh[NT];
+    __shared__ float sh[FT];
     const int tid = threadIdx.x, B = lv.B;
     if ((int)blockIdx.x == B * lv.S) {
         constexpr int NV = 2 * FULL_MAX_LEVELS + 3;
@@ -1405,96 +1539,74 @@ __global__ __launch_bounds__(NT) void k_full_finalize(FullLevels lv, const float
             if (s < lv.S) {
                 const int n = B * lv.items_per_image[s];
                 const float* pp = lv.partials[s];
-                for (int i = tid; i < n; i += NT) { v[2 * s] += pp[(size_t)i * NPART_F + 14]; v[2 * s + 1] += pp[(size_t)i * NPART_F + 15]; }
+                for (int i = tid; i < n; i += FT) { v[2 * s] += pp[(size_t)i * NPART_F + 14]; v[2 * s + 1] += pp[(size_t)i * NPART_F + 15]; }
             }
         }
         if (geo_partials) {
             const int n = B * lv.items_per_image[0];
-            for (int i = tid; i < n; i += NT) v[2 * FULL_MAX_LEVELS] += geo_partials[i];
+            for (int i = tid; i < n; i += FT) v[2 * FULL_MAX_LEVELS] += geo_partials[i];
         }
         if (sm_partials)
-            for (int i = tid; i < sm_nblk; i += NT) {
+            for (int i = tid; i < sm_nblk; i += FT) {
                 v[2 * FULL_MAX_LEVELS + 1] += sm_partials[2 * i];
                 v[2 * FULL_MAX_LEVELS + 2] += sm_partials[2 * i + 1];
             }
-#pragma unroll
-        for (int q = 0; q < NV; ++q) {
-            const float t = wave_sum(v[q]);
-            if ((tid & 63) == 0) sh[(tid >> 6) * NV + q] = t;
-        }
-        __syncthreads();
+        block_sums<NV>(v, sh);
         if (tid == 0) {
-            float tot[NV];
-#pragma unroll
-            for (int q = 0; q < NV; ++q) tot[q] = (sh[q] + sh[NV + q]) + (sh[2 * NV + q] + sh[3 * NV + q]);
             float total = 0.0f;
             const float w = 1.0f / (float)lv.S;
             for (int s = 0; s < lv.S; ++s) {
-                const float denom = fmaxf(3.0f * tot[2 * s + 1], 1.0f), l = tot[2 * s] / denom;
+                const float denom = fmaxf(3.0f * v[2 * s + 1], 1.0f), l = v[2 * s] / denom;
                 total += w * l;
-                state[4 + 4 * s] = l; state[4 + 4 * s + 1] = w / denom; state[4 + 4 * s + 2] = tot[2 * s + 1]; state[4 + 4 * s + 3] = 0.0f;
+                state[4 + 4 * s] = l; state[4 + 4 * s + 1] = w / denom; state[4 + 4 * s + 2] = v[2 * s + 1]; state[4 + 4 * s + 3] = 0.0f;
             }
             float geo = 0.0f, sm = 0.0f;
-            if (geo_partials) { geo = tot[2 * FULL_MAX_LEVELS] / fmaxf(tot[1], 1.0f); total += w_geo * geo; }
-            if (sm_partials) { sm = tot[2 * FULL_MAX_LEVELS + 1] * inv_nx + tot[2 * FULL_MAX_LEVELS + 2] * inv_ny; total += w_sm * sm; }
+            if (geo_partials) { geo = v[2 * FULL_MAX_LEVELS] / fmaxf(v[1], 1.0f); total += w_geo * geo; }
+            if (sm_partials) { sm = v[2 * FULL_MAX_LEVELS + 1] * inv_nx + v[2 * FULL_MAX_LEVELS + 2] * inv_ny; total += w_sm * sm; }
             state[0] = total; state[1] = geo; state[2] = sm; state[3] = 0.0f;
             loss_out[0] = total;
         }
         return;
     }
     const int s = blockIdx.x / B, b = blockIdx.x - s * B;
-    constexpr int ROWS = NT / NPART;  // 18 partial rows per pass
-    const int k = tid % NPART, r = tid / NPART;
-    const int bpi = lv.items_per_image[s];
-    const float* pp = lv.partials[s];
-    float acc = 0.0f;
-    if (r < ROWS) {
-        for (int i = r; i < bpi; i += ROWS) acc += pp[((size_t)b * bpi + i) * NPART_F + k];
-        sh[k * ROWS + r] = acc;
-    }
-    __syncthreads();
-    if (tid < NPART) {
-        float t = 0.0f;
-        for (int i = 0; i < ROWS; ++i) t += sh[tid * ROWS + i];
-        gpart[((size_t)s * B + b) * NPART + tid] = t;
-    }
+    const float t = image_sums(lv.partials[s], b, lv.items_per_image[s], sh);
+    if (tid < NPART) gpart[((size_t)s * B + b) * NPART + tid] = t;
 }
 
-// backward of the whole objective: every gradient in one launch.
-//   d_dt = g (sum_s c_s / 4^s raw_s[y >> s, x >> s] + c_0 geo_raw + w_sm sd_raw)   (the pooling chain is the index shift)
-//   d_dr = g c_0 acc / 2^32                                             (fixed-point scatter of the geometric term)
-//   blocks 0..B-1, thread 0: pose / LCC gradients of one image from gpart (dR -> Euler angles)
+// backward of the whole objective: every gradient in one launch.  Grid (ceil(H W / 256), B + 1):
+//   y < B:  d_dt = g (sum_s c_s / 4^s raw_s[y >> s, x >> s] + c_0 geo_raw + w_sm sd_raw)   (the pooling chain is the index shift)
+//           d_dr = g c_0 acc / 2^32                                     (fixed-point scatter of the geometric term)
+//   y == B: blocks x < B: pose / LCC gradients of image x from gpart (dR -> Euler angles)
 __global__ __launch_bounds__(NT) void k_full_combine(FullLevels lv, const float* __restrict__ state,
                                                      const float* __restrict__ grad_loss, const float* __restrict__ sd_raw,
-                                                     const float* __restrict__ geo_raw, const unsigned long long* __restrict__ acc, const float* __restrict__ gpart,
-                                                     const float* __restrict__ pose, int H, int W, float w_sm,
-                                                     float* __restrict__ d_dt, float* __restrict__ d_dr,
+                                                     const float* __restrict__ geo_raw, const unsigned long long* __restrict__ acc,
+                                                     const float* __restrict__ gpart, const float* __restrict__ pose, int H, int W,
+                                                     float w_sm, float* __restrict__ d_dt, float* __restrict__ d_dr,
                                                      float* __restrict__ d_pose, float* __restrict__ d_a, float* __restrict__ d_b) {
     const float g = grad_loss[0];
     const int B = lv.B;
     float c[FULL_MAX_LEVELS];
 #pragma unroll
     for (int s = 0; s < FULL_MAX_LEVELS; ++s) c[s] = (s < lv.S) ? g * state[4 + 4 * s + 1] : 0.0f;
-    const size_t plane = (size_t)H * W, n = (size_t)B * plane;
-    const size_t stride = (size_t)gridDim.x * NT;
-    const float gsm = g * w_sm;
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
-        const int b = (int)(i / plane);
-        const size_t o = i - (size_t)b * plane;
-        const int y = (int)(o / W), x = (int)(o - (size_t)y * W);
+    if ((int)blockIdx.y < B) {
+        const unsigned plane = (unsigned)H * W, o = blockIdx.x * NT + threadIdx.x;
+        if (o >= plane) return;
+        const unsigned b = blockIdx.y, y = o / W, x = o - y * W;
+        const size_t i = (size_t)b * plane + o;
         float v = c[0] * (geo_raw ? lv.raw[0][i] + geo_raw[i] : lv.raw[0][i]);
         float f = 0.25f;
 #pragma unroll
         for (int s = 1; s < FULL_MAX_LEVELS; ++s) {
             if (s < lv.S) {
-                const int ws = W >> s, hs = H >> s;
+                const unsigned ws = W >> s, hs = H >> s;
                 v = fmaf(c[s] * f, lv.raw[s][((size_t)b * hs + (y >> s)) * ws + (x >> s)], v);
                 f *= 0.25f;
             }
         }
-        if (sd_raw) v = fmaf(gsm, sd_raw[i], v);
+        if (sd_raw) v = fmaf(g * w_sm, sd_raw[i], v);
         d_dt[i] = v;
         if (d_dr) d_dr[i] = c[0] * ((float)(long long)acc[i] * (1.0f / GEO_FIX));
+        return;
     }
     if ((int)blockIdx.x >= B) return;
     __shared__ float tot[NPART + 2];
@@ -1643,7 +1755,7 @@ extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const f
                        K, lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, (const float*)nullptr,
                        (const float*)nullptr, d_depth_raw, workspace, 0, GeoArgs{});
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<fused>");
-    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(NT), 0, s, workspace, nseg * strips_x, B, pose,
+    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(FT), 0, s, workspace, nseg * strips_x, B, pose,
                        grad_partials, grad_unit, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_finalize");
     return 0;
@@ -1792,52 +1904,71 @@ extern "C" int colvo_full_objective_fwd(const float* tgt, const float* ref, cons
     const bool geo = geo_weight != 0.0f, smooth = smooth_weight != 0.0f;
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(workspace + p.acc);
     const size_t plane = (size_t)H * W;
-    // (1) smoothness: value partials + raw gradient; clears the scatter accumulators on the way
     const float inv_nx = 1.0f / ((float)B * H * (W - 1)), inv_ny = 1.0f / ((float)B * (H - 1) * W);      // (H, W >= 2)
-    if (smooth) {
-        hipLaunchKernelGGL(k_smooth_both, dim3((unsigned)((plane + NT - 1) / NT), B), dim3(NT), 0, s, depth_t, tgt, H, W,
-                           inv_nx, inv_ny, workspace + p.sm_part, workspace + p.sd, geo ? acc : nullptr);
-        COLVO_CHECK_LAUNCH("k_smooth_both");
-    } else if (geo) {
-        hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * plane * 8, s);
-        if (e != hipSuccess) { set_error("colvo_full_objective_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+    // (1) one launch: smoothness (value partials + raw gradient; clears the scatter accumulators on the way) and the first two
+    //     pyramid levels of both frames and the target depth; a fourth level (num_scales = 4) takes a launch of its own
+    {
+        const int NL = std::min(num_scales - 1, 2);
+        PrepArgs a{};
+        a.tgt = tgt; a.ref = ref; a.depth = depth_t;
+        if (NL >= 1) { a.t1 = workspace + p.tgt[1]; a.r1 = workspace + p.ref[1]; a.d1 = workspace + p.dep[1]; }
+        if (NL >= 2) { a.t2 = workspace + p.tgt[2]; a.r2 = workspace + p.ref[2]; a.d2 = workspace + p.dep[2]; }
+        a.sm_partials = workspace + p.sm_part; a.sd_raw = workspace + p.sd;
+        a.zero_acc = (geo && smooth) ? acc : nullptr;
+        a.inv_nx = inv_nx; a.inv_ny = inv_ny;
+        a.B = B; a.H = H; a.W = W;
+        a.sm_blocks = smooth ? p.sm_nblk : 0;
+        if (geo && !smooth) {
+            hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * plane * 8, s);
+            if (e != hipSuccess) { set_error("colvo_full_objective_fwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
+        const size_t cells = NL ? 7 * (size_t)B * (plane >> (2 * NL)) : 0;
+        const unsigned blocks = (unsigned)(a.sm_blocks + (cells + NT - 1) / NT);
+        if (blocks) {
+            if (NL == 2) hipLaunchKernelGGL((k_full_prepare<2>), dim3(blocks), dim3(NT), 0, s, a);
+            else if (NL == 1) hipLaunchKernelGGL((k_full_prepare<1>), dim3(blocks), dim3(NT), 0, s, a);
+            else hipLaunchKernelGGL((k_full_prepare<0>), dim3(blocks), dim3(NT), 0, s, a);
+            COLVO_CHECK_LAUNCH("k_full_prepare");
+        }
+        for (int l = 3; l < num_scales; ++l) {
+            const size_t px = (size_t)p.h[l] * p.w[l];
+            hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((px + NT - 1) / NT), 7 * B), dim3(NT), 0, s, workspace + p.tgt[l - 1],
+                               workspace + p.ref[l - 1], workspace + p.dep[l - 1], B, p.h[l], p.w[l], workspace + p.tgt[l],
+                               workspace + p.ref[l], workspace + p.dep[l]);
+            COLVO_CHECK_LAUNCH("k_pyramid_level");
+        }
     }
-    // (2) pyramid
-    const float *lt = tgt, *lr = ref, *ld = depth_t;
+    // (2) one launch: the one-pass photometric loss + gradients of every level; level 0 carries the geometric term
     FullLevels lv{};
     lv.S = num_scales; lv.B = B;
+    MarchLevels ml{};
+    ml.S = num_scales;
+    unsigned grid = 0;
     for (int l = 0; l < num_scales; ++l) {
-        if (l > 0) {
-            float *nt = workspace + p.tgt[l], *nr = workspace + p.ref[l], *nd = workspace + p.dep[l];
-            const size_t px = (size_t)p.h[l] * p.w[l];
-            hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((px + NT - 1) / NT), 7 * B), dim3(NT), 0, s, lt, lr, ld, B, p.h[l],
-                               p.w[l], nt, nr, nd);
-            COLVO_CHECK_LAUNCH("k_pyramid_level");
-            lt = nt; lr = nr; ld = nd;
-        }
-        // (3) one-pass photometric loss + gradients of the level; level 0 carries the geometric term
         const long long nitems = (long long)B * p.nseg[l] * p.strips[l];
-        COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_full_objective_fwd: too many strips");
+        COLVO_CHECK_ARG(nitems < (1ll << 28), "colvo_full_objective_fwd: too many strips");
         lv.items_per_image[l] = p.nseg[l] * p.strips[l];
         lv.partials[l] = workspace + p.part[l];
         lv.raw[l] = workspace + p.raw[l];
-        if (l == 0 && geo) {
-            // both terms are masked means over the SAME valid pixels (photometric: 3 channels each, weight 1/S): relative to the
-            // photometric gradient the term's weighs  geo_weight / n  over  (1/S) / (3 n)
-            GeoArgs ga{depth_r, acc, workspace + p.geo_part, workspace + p.geo_raw, 3.0f * (float)num_scales * geo_weight};
-            hipLaunchKernelGGL((k_warp_loss_bwd_march<true, true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, lt, lr, ld,
-                               pose, K, lcc_a, lcc_b, B, p.h[l], p.w[l], p.strips[l], p.nseg[l], p.seg_rows[l], ssim_weight,
-                               (const float*)nullptr, (const float*)nullptr, workspace + p.raw[l], workspace + p.part[l], l, ga);
-        } else {
-            hipLaunchKernelGGL((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, lt, lr, ld, pose,
-                               K, lcc_a, lcc_b, B, p.h[l], p.w[l], p.strips[l], p.nseg[l], p.seg_rows[l], ssim_weight,
-                               (const float*)nullptr, (const float*)nullptr, workspace + p.raw[l], workspace + p.part[l], l,
-                               GeoArgs{});
-        }
-        COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<full objective>");
+        MarchLevel& L = ml.lv[l];
+        L.tgt = l ? workspace + p.tgt[l] : tgt; L.ref = l ? workspace + p.ref[l] : ref; L.depth = l ? workspace + p.dep[l] : depth_t;
+        L.d_depth = workspace + p.raw[l]; L.partials = workspace + p.part[l];
+        L.H = p.h[l]; L.W = p.w[l]; L.strips_x = p.strips[l]; L.nseg = p.nseg[l]; L.seg_rows = p.seg_rows[l];
+        L.wg8 = (int)(((nitems + 3) / 4 + 7) / 8);
+        grid += 8u * (unsigned)L.wg8;
     }
-    // (4) every term's value, the total, the per-image gradient sums
-    hipLaunchKernelGGL(k_full_finalize, dim3(B * num_scales + 1), dim3(NT), 0, s, lv, geo ? workspace + p.geo_part : (const float*)nullptr,
+    if (geo) {
+        // both terms are masked means over the SAME valid pixels (photometric: 3 channels each, weight 1/S): relative to the
+        // photometric gradient the term's weighs  geo_weight / n  over  (1/S) / (3 n)
+        GeoArgs ga{depth_r, acc, workspace + p.geo_part, workspace + p.geo_raw, 3.0f * (float)num_scales * geo_weight};
+        hipLaunchKernelGGL((k_warp_loss_march_levels<true>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight, ga);
+    } else {
+        hipLaunchKernelGGL((k_warp_loss_march_levels<false>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight,
+                           GeoArgs{});
+    }
+    COLVO_CHECK_LAUNCH("k_warp_loss_march_levels");
+    // (3) every term's value, the total, the per-image gradient sums
+    hipLaunchKernelGGL(k_full_finalize, dim3(B * num_scales + 1), dim3(FT), 0, s, lv, geo ? workspace + p.geo_part : (const float*)nullptr,
                        smooth ? workspace + p.sm_part : (const float*)nullptr, p.sm_nblk, inv_nx, inv_ny, geo_weight, smooth_weight,
                        workspace + p.gpart, workspace + p.state, loss);
     COLVO_CHECK_LAUNCH("k_full_finalize");
@@ -1866,10 +1997,9 @@ extern "C" int colvo_full_objective_bwd(const float* workspace, const float* gra
         lv.raw[l] = workspace + p.raw[l];
     }
     const bool geo = geo_weight != 0.0f, smooth = smooth_weight != 0.0f;
-    const size_t n = (size_t)B * H * W;
-    unsigned blocks = (unsigned)std::min<size_t>((n + NT * 4 - 1) / (NT * 4), 4096);
-    if (blocks < (unsigned)B) blocks = (unsigned)B;
-    hipLaunchKernelGGL(k_full_combine, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, lv, workspace + p.state, grad_loss,
+    unsigned nbx = (unsigned)(((size_t)H * W + NT - 1) / NT);
+    if (nbx < (unsigned)B) nbx = (unsigned)B;
+    hipLaunchKernelGGL(k_full_combine, dim3(nbx, B + 1), dim3(NT), 0, (hipStream_t)stream, lv, workspace + p.state, grad_loss,
                        smooth ? workspace + p.sd : (const float*)nullptr, geo ? workspace + p.geo_raw : (const float*)nullptr,
                        geo ? reinterpret_cast<const unsigned long long*>(workspace + p.acc) : (const unsigned long long*)nullptr,
                        workspace + p.gpart, pose, H, W, smooth_weight, d_depth_t, geo ? d_depth_r : (float*)nullptr, d_pose, d_a, d_b);
