@@ -74,9 +74,11 @@ def parse():
                          "RCCL plumbing on a one-GPU box; the collectives are trivial, the stream interplay is not")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: all ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks on one device)")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from one captured hipGraph (coivo_amd/graph.py); auto = the configuration's setting: on "
-                         "for configs[4], off otherwise")
+    ap.add_argument("--graph", choices=["auto", "on", "off", "best"], default="auto",
+                    help="replay the step from one captured hipGraph (coivo_amd/graph.py); best = capture it, time 20 eager and 20 "
+                         "replayed steps and run the timed region with the faster form (replay is level with eager on an idle host and "
+                         "immune to a busy one: the eager step needs ~0.9 ms of host time per 1.5 ms step); auto = the "
+                         "configuration's setting: on for configs[4], best on one GPU, off on several")
     ap.add_argument("--graph-policy", type=int, choices=[0, 1, 2, 3], default=2,
                     help="how the weight-gradient chain hangs off the main chain in the graph (include/colvo.h "
                          "colvo_set_capture_policy): 0 one branch, 1 one edge per layer, 2 segments of --graph-group commands")
@@ -104,7 +106,9 @@ def resolve_config(args):
     args.width = w if args.width is None else args.width
     args.grad_transport = transport if args.grad_transport is None else args.grad_transport
     if args.graph == "auto":
-        args.graph = graph
+        # one GPU: whichever form is faster on this host; several: eager unless the configuration names the graph (the replayed
+        # RCCL path has run with one rank only)
+        args.graph = graph if (graph == "on" or args.gpus > 1 or args.rccl_single) else "best"
     return args
 
 
@@ -399,11 +403,14 @@ def main():
 
     one = torch.ones((), device=dev)      # dL/dloss, persistent (no ones_like() fill kernel per step)
     graphed = None
-    if args.graph == "on":
+    graph_error = graph_trial = None
+
+    def capture_graph():
+        nonlocal graphed, graph_error
         from coivo_amd.graph import GraphedTrainStep
         try:
             graphed = GraphedTrainStep(dn, pn, opt, B, H, W, ddp=ddp, capture_policy=args.graph_policy,
-                                       capture_group=args.graph_group)
+                                       capture_group=args.graph_group, full_loss=args.full_loss)
             graphed.frames.copy_(frames)
             graphed.K.copy_(K)
             graphed.capture()
@@ -414,9 +421,12 @@ def main():
             graph_error = f"{type(e).__name__}: {e}"[:200]
             torch.cuda.synchronize()
 
-    def fast_step():
+    if args.graph == "on" and not args.spec_calls:
+        capture_graph()
+
+    def fast_step(full=args.full_loss):
         opt.zero_grad()
-        if args.full_loss:
+        if full:            # the widened objective: two native calls, no torch kernels
             loss = hnn.dcdp_forward(dn, pn, None, None, K, full_loss=True, frames=frames)[0]
         else:
             d_t, d_r, d_l = dn.forward_pair_split(frames)     # d_l: depth_t again, the loss's own gradient path (nn.py)
@@ -465,6 +475,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.graph == "best" and not args.spec_calls:
+        # Eager launches need the host to stay ahead of the GPU (~0.9 ms of enqueue work per 1.5 ms step at configs[1]); on a busy
+        # host they do not, and the replayed graph -- level with eager otherwise, within 2 % -- is immune.  Decide from 20 eager
+        # steps: host-bound (enqueue time above 80 % of the step) -> capture and replay.  The decision must come BEFORE a
+        # capture: the streams a capture leaves behind push eager steps of the same process over the hardware-queue cliff
+        # (measured 4.6 ms per eager step after a capture).
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(20):
+            eager_step()
+        t_host = (time.perf_counter() - t_) / 20 * 1e3
+        torch.cuda.synchronize()
+        t_eager = (time.perf_counter() - t_) / 20 * 1e3
+        graph_trial = {"eager_ms": t_eager, "eager_host_enqueue_ms": t_host, "steps": 20, "chosen": "eager"}
+        if t_host > float(os.environ.get("COLVO_BENCH_GRAPH_THRESHOLD", "0.8")) * t_eager:     # (developer probe: 0 forces the replay)
+            capture_graph()
+            if graphed is not None:
+                graph_trial.update(replay_ms=timed_run(graphed, 20), chosen="replay")
     use_graph = graphed is not None
     for _ in range(args.warmup):
         step(False)
@@ -533,6 +563,11 @@ def main():
         other = fast_step if args.spec_calls else spec_step
         ms2 = timed_run(other, min(args.steps, 20))
         side["spec_sequence_ms" if not args.spec_calls else "fast_path_ms"] = ms2
+        ms3 = timed_run(lambda: fast_step(True), min(args.steps, 20))
+        side["full_objective"] = {"ms_per_step": ms3, "value": B / (ms3 * 1e-3),
+                                  "what": "the same step with the widened objective (multi-scale photometric + geometric "
+                                          "consistency + smoothness, SURVEY.md section 8f-1/8f-2; bench.py --full-loss times it "
+                                          "as the main measurement)"}
     if world > 1:
         dist.barrier()
 
@@ -543,16 +578,19 @@ def main():
         f_us = [e0.elapsed_time(e1) for e0, e1 in ev["fwd"]]
         b_us = [e0.elapsed_time(e1) for e0, e1 in ev["bwd"]]
         Fh.enable_timing(False)
-        # --full-loss: the fused op runs at 3 scales per step; per step sum the three calls, and the byte model becomes
-        # sum_s 60 * px / 4^s -- the geometric and smoothness kernels are separate launches, not in this figure
-        per = 3 if args.full_loss else 1
+        # --full-loss: ONE forward call per step runs the whole widened objective (smoothness + pyramid, the one-pass kernel over the
+        # three levels with the geometric term inside level 0, finalize) and one backward call the combine kernel; the byte model
+        # is the photometric one, sum_s 60 * px / 4^s -- the other terms' bytes are not credited
+        per = 1
         f_ms, b_ms = sum(f_us) / len(f_us) * per, sum(b_us) / len(b_us) * per
         px = B * H * W * (1.0 + 0.25 + 0.0625 if args.full_loss else 1.0)
         # plain step: the backward call launches nothing (gradient handover), so the op's duration is the forward call's;
         # --full-loss: the general path's scaling kernels run in the backward calls and count
         ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + (b_ms if args.full_loss else 0.0)) * 1e-3) / 1e9
-        roof = {"kernel": "k_warp_loss_bwd_march<fused> + k_warp_loss_fused_finalize (project/sample/LCC/SSIM/L1: loss and all "
-                          "gradients in one pass)",
+        roof = {"kernel": ("k_full_prepare + k_warp_loss_march_levels<geo> + k_full_finalize, backward k_full_combine (the widened "
+                           "objective: every term's value and gradients)" if args.full_loss else
+                           "k_warp_loss_bwd_march<fused> + k_warp_loss_fused_finalize (project/sample/LCC/SSIM/L1: loss and all "
+                           "gradients in one pass)"),
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 # the committed PMC summary holds the two BASELINE shapes; any other invocation (or --full-loss) has none
                 "traffic": (None if args.full_loss else
@@ -578,7 +616,7 @@ def main():
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},
-               "final_loss": final_loss, "hipgraph": use_graph,
+               "final_loss": final_loss, "hipgraph": use_graph, "hipgraph_trial": graph_trial, "hipgraph_error": graph_error,
                "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group} if use_graph else None),
                "roofline": roof}
         out.update(side)

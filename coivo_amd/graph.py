@@ -29,11 +29,11 @@ from .functional import photometric_loss
 
 class GraphedTrainStep:
     def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
-                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2):
+                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2, full_loss: bool = False):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
         self.capture_policy, self.capture_group = int(capture_policy), int(capture_group)
-        self.B, self.ssim_weight = B, ssim_weight
+        self.B, self.ssim_weight, self.full_loss = B, ssim_weight, bool(full_loss)
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
         self.loss = torch.zeros((), device=dev)
@@ -45,10 +45,15 @@ class GraphedTrainStep:
     def _step(self) -> torch.Tensor:
         B = self.B
         self.opt.zero_grad()
-        d_t, d_r, d_l = self.depth_net.forward_pair_split(self.frames)
-        tgt, ref = self.frames[:B], self.frames[B:]
-        pose, a, b = self.pose_net(tgt, ref, d_t, d_r)
-        loss = photometric_loss(tgt, ref, d_l, pose, self.K, a, b, ssim_weight=self.ssim_weight)
+        if self.full_loss:      # the widened objective: two native calls, capture-safe (its workspace comes from the graph's pool)
+            from .nn import dcdp_forward
+            loss = dcdp_forward(self.depth_net, self.pose_net, None, None, self.K, ssim_weight=self.ssim_weight, full_loss=True,
+                                frames=self.frames)[0]
+        else:
+            d_t, d_r, d_l = self.depth_net.forward_pair_split(self.frames)
+            tgt, ref = self.frames[:B], self.frames[B:]
+            pose, a, b = self.pose_net(tgt, ref, d_t, d_r)
+            loss = photometric_loss(tgt, ref, d_l, pose, self.K, a, b, ssim_weight=self.ssim_weight)
         loss.backward(gradient=self._one)
         if self.ddp is not None:
             self.ddp.finish()

@@ -24,7 +24,7 @@ def test_plan_single_gpu_defaults():
     import bench
     a = _args([])
     assert (a.gpus, a.batch_per_gpu, a.height, a.width, a.dtype) == (1, 8, 256, 320, "bf16")
-    assert a.config_id == "1" and a.graph == "auto" and not a.custom_shape and not a.spec_calls
+    assert a.config_id == "1" and a.graph == "best" and not a.custom_shape and not a.spec_calls   # one GPU: eager or replay, the faster
     p = bench.plan_distributed(a, {})
     assert p["world"] == 1 and p["backend"] is None and p["device"] == ("cuda", 0) and p["global_batch"] == 8
     assert p["grad_transport"] is None
@@ -60,7 +60,8 @@ def test_baseline_configs_map_to_bench_flags():
     assert (a.batch_per_gpu, a.grad_transport, a.graph) == (64, "bf16", "on")
     assert bench.plan_distributed(a, {"RANK": "3", "LOCAL_RANK": "3", "WORLD_SIZE": "8"})["global_batch"] == 512
     a = _args(["--config", "3"])                       # the scaling denominator: 32 pairs on ONE GPU
-    assert (a.gpus, a.batch_per_gpu) == (1, 32) and "configs[3]" in bench.workload_name(a, 32, 256, 320)
+    assert (a.gpus, a.batch_per_gpu, a.graph) == (1, 32, "best") and "configs[3]" in bench.workload_name(a, 32, 256, 320)
+    assert _args(["--rccl-single"]).graph == "auto"     # the RCCL path is timed eagerly unless the configuration names the graph
     a = _args(["--config", "2"])
     assert (a.batch_per_gpu, a.height, a.width) == (32, 512, 640)
     a = _args(["--gpus", "2", "--batch-per-gpu", "8"])  # explicit flags win and are reported as a custom shape

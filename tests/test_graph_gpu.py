@@ -76,6 +76,30 @@ def test_graphed_step_is_bitwise_the_eager_step_in_deterministic_mode():
     assert torch.equal(dn1.flat_grad, dn2.flat_grad) and torch.equal(pn1.flat_grad, pn2.flat_grad)
 
 
+def test_graphed_full_objective_step_is_bitwise_the_eager_one():
+    """The widened objective inside the captured step: its scatter is fixed-point, so in deterministic mode the replayed and the
+    eager trajectory agree bit for bit here too."""
+    from coivo_amd import nn as hnn
+    from coivo_amd.graph import GraphedTrainStep
+    B, H, W, seed = 2, 64, 96, 66
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+    frames = torch.cat([b["tgt"], b["ref"]])
+    dn1, pn1, opt1 = _setup(seed, torch.bfloat16)
+    dn2, pn2, opt2 = _setup(seed, torch.bfloat16)
+    for n in (dn1, pn1, dn2, pn2):
+        n.deterministic = True
+    step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, full_loss=True)
+    for _ in range(3):
+        opt1.zero_grad()
+        l1 = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"], full_loss=True)[0]
+        l1.backward()
+        opt1.step()
+        l2 = step(frames, b["K"])
+        assert l1.item() == l2.item()
+    torch.cuda.synchronize()
+    assert torch.equal(dn1.flat_param, dn2.flat_param) and torch.equal(pn1.flat_param, pn2.flat_param)
+
+
 def test_graph_is_built_with_explicit_dependencies():
     """The captured graph has ONE root (the capture is one stream) and more than one branch: under capture colvo_run_commands
     hangs the weight-gradient chain off the main chain by dependency edits, not by a second captured stream."""
