@@ -146,11 +146,15 @@ class _ArenaModule(nn.Module):
     def attach_grads(self) -> None:
         """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
         layers = self._layers()
-        if any(L.weight.grad is None or L.bias.grad is None for L in layers):
-            ops.zero_(self.flat_grad)
-            for L in layers:
-                L.weight.grad = L._gw_view
-                L.bias.grad = L.g_bias
+        for p in self.__dict__["_param_list"]:          # (the Parameter objects themselves: no nn.Module attribute lookups)
+            if p.grad is None:
+                break
+        else:
+            return
+        ops.zero_(self.flat_grad)
+        for L in layers:
+            L.weight.grad = L._gw_view
+            L.bias.grad = L.g_bias
 
     def zero_grad(self, set_to_none: bool = False) -> None:   # arena semantics: grads stay attached
         self.join_side()

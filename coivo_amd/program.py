@@ -107,7 +107,7 @@ class Program:
             return
         lib = _lib.load()
         base = C.addressof(self._arr) + begin * C.sizeof(_lib.Cmd)
-        _lib.check(lib.colvo_run_commands(base, n - begin, torch.cuda.current_stream().cuda_stream,
+        _lib.check(lib.colvo_run_commands(base, n - begin, _lib.stream_ptr(),
                                           0 if side is None else side.cuda_stream), "colvo_run_commands")
 
     def __len__(self) -> int:

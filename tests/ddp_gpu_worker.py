@@ -24,6 +24,7 @@ def main():
     torch.cuda.set_device(dev)
     B, H, W, seed = 1, 64, 96, 71
     det = os.environ.get("DDP_DET") is not None
+    obj = dict(full_loss=True) if os.environ.get("DDP_FULL") is not None else {}      # DDP_FULL=1: the widened objective
     dn_o, pn_o = S.make_models(seed)
 
     def fresh():
@@ -40,7 +41,7 @@ def main():
     ddp = GradBuckets([dn, pn], bucket_bytes=2 << 20)          # several buckets per arena
     opt.grad_scale = ddp.grad_scale
     opt.zero_grad()
-    loss = hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl])[0]
+    loss = hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl], **obj)[0]
     loss.backward()
     ddp.finish()
     torch.cuda.synchronize()
@@ -60,7 +61,7 @@ def main():
         opt2.zero_grad()
         for r in range(world):
             s2 = slice(r * B, (r + 1) * B)
-            hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2])[0].backward()
+            hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2], **obj)[0].backward()
         torch.cuda.synchronize()
         for a, b, name in ((g_dn, dn2.flat_grad, "DepthNet"), (g_pn, pn2.flat_grad, "PoseNet")):
             scale = b.abs().max().item()
@@ -90,7 +91,7 @@ def main():
     def ddp_backward():
         calls[0] = 0
         opt.zero_grad()
-        hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl])[0].backward()
+        hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl], **obj)[0].backward()
         ddp.finish()
         torch.cuda.synchronize()
         return dn.flat_grad.clone(), pn.flat_grad.clone(), calls[0]
@@ -110,7 +111,7 @@ def main():
         if det:
             assert torch.equal(a, b), f"{name}: deterministic mode, yet the learned split points changed the gradient bits"
     if rank == 0:
-        print("DDP_OK" + (" DET" if det else ""), f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
+        print("DDP_OK" + (" DET" if det else "") + (" FULL" if obj else ""), f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

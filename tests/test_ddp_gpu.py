@@ -42,6 +42,14 @@ def test_two_rank_dp_deterministic_is_bitwise_the_accumulated_batch():
     assert "DDP_OK DET" in r.stdout
 
 
+def test_two_rank_dp_with_the_widened_objective_is_bitwise_too():
+    """The same with dcdp_forward(full_loss=True): the objective's own scatter (the geometric term's tap gradients) is fixed-point,
+    so data parallel == accumulated batches holds bit for bit for the widened step as well."""
+    r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")], extra_env={"DDP_DET": "1", "DDP_FULL": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DDP_OK DET FULL" in r.stdout
+
+
 def test_bench_multiprocess_path():
     r = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
               "--no-roofline-cfg2", "--batch-per-gpu", "2", "--height", "64", "--width", "96", "--rehearse-on-one-gpu"])

@@ -122,7 +122,7 @@ def test_full_loss_golden_and_step(golden_dir):
 
 
 @pytest.mark.parametrize("B,H,W,geo,smooth,scales", [(2, 48, 64, 0.5, 0.1, 3), (1, 32, 32, 0.0, 0.1, 2), (3, 64, 96, 0.5, 0.0, 1),
-                                                     (8, 256, 320, 0.5, 0.1, 3)])
+                                                     (2, 40, 56, 0.0, 0.0, 1), (2, 40, 56, 0.0, 0.0, 3), (8, 256, 320, 0.5, 0.1, 3)])
 def test_full_loss_one_node_equals_composite(B, H, W, geo, smooth, scales):
     """The one-node form of the widened objective against the term-by-term form: same value, same gradients."""
     from coivo_amd import functional as Fh

@@ -41,6 +41,17 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         print(f"rep {rep}: enqueue {1e3 * (t1 - t0) / N:.3f} ms/step   total {1e3 * (t2 - t0) / N:.3f} ms/step")
+    if len(sys.argv) > 2 and sys.argv[2] == "profile":          # where the host time goes (cProfile, cumulative, top 45)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(N):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(25)
 
 
 if __name__ == "__main__":
