@@ -23,6 +23,14 @@ class ConvDesc(C.Structure):
         "C0", "up0", "C1", "up1", "Hi", "Wi")]
 
 
+class AdamArena(C.Structure):
+    """Mirror of ColvoAdamArena (include/colvo.h)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t)]
+
+
+MAX_ARENAS = 4
+
+
 # name -> (restype, argtypes); lists every symbol include/colvo.h declares
 class Cmd(C.Structure):
     """Mirror of ColvoCmd (include/colvo.h)."""
@@ -52,6 +60,8 @@ SIGNATURES = {
     "colvo_smooth_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "colvo_avgpool2_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "colvo_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "colvo_adam_step_multi": (_i, [_vp, _i, _f, _f, _f, _f, _f, _i, _vp]),
+    "colvo_zero_multi": (_i, [_vp, _vp, _i, _vp]),
     "colvo_full_objective_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "colvo_full_objective_fwd": (_i, [_vp] * 8 + [_i] * 4 + [_f] * 3 + [_vp] * 3),
     "colvo_full_objective_bwd": (_i, [_vp] * 3 + [_i] * 4 + [_f, _f] + [_vp] * 6),

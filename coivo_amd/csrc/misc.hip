@@ -150,8 +150,9 @@ __global__ __launch_bounds__(NT) void k_pack_nchw8(Planes src, int HW, void* __r
 // PX pixels per thread: the reads are 2 / 4 useful bytes per 16 / 32-byte pixel, so a thread needs several in flight
 template <int ES, int PX = 4>
 __global__ __launch_bounds__(NT) void k_unpack_nhwc(const void* __restrict__ src, int HW, int Cpad, int c_begin,
-                                                    int c_count, float* __restrict__ dst, int accumulate) {
+                                                    int c_count, float* __restrict__ dst, int flags) {
     const int b = blockIdx.y;
+    const bool accumulate = flags & 1, by_channel = flags & 2;      // by_channel: dst is [c_count][B][H][W]
     const size_t pix0 = (size_t)blockIdx.x * NT * PX + threadIdx.x;
     for (int c = 0; c < c_count; ++c) {
         float v[PX];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NT) void k_unpack_nhwc(const void* __restrict__ src
         for (int j = 0; j < PX; ++j) {
             const size_t pix = pix0 + (size_t)j * NT;
             if (pix >= (size_t)HW) continue;
-            float* d = dst + ((size_t)b * c_count + c) * HW + pix;
+            float* d = dst + (by_channel ? (size_t)c * gridDim.y + b : (size_t)b * c_count + c) * HW + pix;
             *d = accumulate ? (*d + v[j]) : v[j];
         }
     }
@@ -736,6 +737,70 @@ __global__ __launch_bounds__(NT) void k_adam(float* __restrict__ p, const float*
 
 __global__ void k_inc_step(int32_t* step_count) { step_count[0] += 1; }
 
+// Several arenas in ONE launch (a dependent launch costs ~2.7 us before it does anything, tools/ubench/launch_floor.hip, and the
+// small arena alone does not fill the memory system): workgroups [first[i], first[i + 1]) walk arena i.
+struct AdamArenas {
+    int count;
+    unsigned first[COLVO_MAX_ARENAS + 1];
+    ColvoAdamArena a[COLVO_MAX_ARENAS];
+};
+__global__ __launch_bounds__(NT) void k_adam_multi(AdamArenas as, float lr, float b1, float b2, float eps, float gscale, int t_host) {
+    const AdamCoef c = adam_coef(lr, b1, b2, nullptr, t_host);
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < COLVO_MAX_ARENAS; ++q)
+        if (q < as.count && blockIdx.x >= as.first[q]) i = q;
+    ColvoAdamArena A = as.a[0];
+    unsigned b0 = as.first[0], b1x = as.first[1];
+#pragma unroll
+    for (int q = 1; q < COLVO_MAX_ARENAS; ++q)
+        if (i == q) { A = as.a[q]; b0 = as.first[q]; b1x = as.first[q + 1]; }
+    const size_t n4 = A.n / 4, stride = (size_t)(b1x - b0) * NT;
+    float4* p4 = reinterpret_cast<float4*>(A.param);
+    const float4* g4 = reinterpret_cast<const float4*>(A.grad);
+    float4* m4 = reinterpret_cast<float4*>(A.exp_avg);
+    float4* v4 = reinterpret_cast<float4*>(A.exp_avg_sq);
+    const size_t start = (size_t)(blockIdx.x - b0) * NT + threadIdx.x;
+    for (size_t k = start; k < n4; k += stride) {
+        float4 pi = p4[k], mi = m4[k], vi = v4[k];
+        const float4 gi = g4[k];
+        adam_one(pi.x, gi.x, mi.x, vi.x, b1, b2, eps, gscale, c);
+        adam_one(pi.y, gi.y, mi.y, vi.y, b1, b2, eps, gscale, c);
+        adam_one(pi.z, gi.z, mi.z, vi.z, b1, b2, eps, gscale, c);
+        adam_one(pi.w, gi.w, mi.w, vi.w, b1, b2, eps, gscale, c);
+        m4[k] = mi;
+        v4[k] = vi;
+        p4[k] = pi;
+    }
+    for (size_t k = n4 * 4 + start; k < A.n; k += stride) {
+        float pi = A.param[k], mi = A.exp_avg[k], vi = A.exp_avg_sq[k];
+        adam_one(pi, A.grad[k], mi, vi, b1, b2, eps, gscale, c);
+        A.exp_avg[k] = mi; A.exp_avg_sq[k] = vi; A.param[k] = pi;
+    }
+}
+
+// zero several buffers in one launch (16-byte stores; sizes are multiples of 16 bytes)
+struct ZeroArenas {
+    int count;
+    unsigned first[COLVO_MAX_ARENAS + 1];
+    void* p[COLVO_MAX_ARENAS];
+    size_t n16[COLVO_MAX_ARENAS];
+};
+__global__ __launch_bounds__(NT) void k_zero_multi(ZeroArenas zs) {
+    int i = 0;
+#pragma unroll
+    for (int q = 1; q < COLVO_MAX_ARENAS; ++q)
+        if (q < zs.count && blockIdx.x >= zs.first[q]) i = q;
+    void* p = zs.p[0]; size_t n16 = zs.n16[0];
+    unsigned b0 = zs.first[0], b1 = zs.first[1];
+#pragma unroll
+    for (int q = 1; q < COLVO_MAX_ARENAS; ++q)
+        if (i == q) { p = zs.p[q]; n16 = zs.n16[q]; b0 = zs.first[q]; b1 = zs.first[q + 1]; }
+    float4* d = reinterpret_cast<float4*>(p);
+    const size_t stride = (size_t)(b1 - b0) * NT;
+    for (size_t k = (size_t)(blockIdx.x - b0) * NT + threadIdx.x; k < n16; k += stride) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + NT - 1) / NT); }
 inline bool head_dgrad_generic() { return TUNE(head_dgrad_generic) != 0; }   // A/B switch
 
@@ -1025,6 +1090,52 @@ extern "C" int colvo_adam_step_t(float* param, const float* grad, float* exp_avg
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, grad_scale, (const int32_t*)nullptr, t);
     COLVO_CHECK_LAUNCH("k_adam");
+    return 0;
+}
+
+extern "C" int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, float lr, float beta1, float beta2, float eps,
+                                     float grad_scale, int t, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(arenas && count >= 1 && count <= COLVO_MAX_ARENAS && t >= 1, "colvo_adam_step_multi: bad arguments");
+    AdamArenas as{};
+    as.count = count;
+    unsigned total = 0;
+    for (int i = 0; i < count; ++i) {
+        const ColvoAdamArena& a = arenas[i];
+        COLVO_CHECK_ARG(a.param && a.grad && a.exp_avg && a.exp_avg_sq, "colvo_adam_step_multi: null pointer in arena %d", i);
+        COLVO_CHECK_ARG(((uintptr_t)a.param | (uintptr_t)a.grad | (uintptr_t)a.exp_avg | (uintptr_t)a.exp_avg_sq) % 16 == 0,
+                        "colvo_adam_step_multi: arenas must be 16-byte aligned");
+        unsigned blocks = nblk((a.n + 3) / 4);
+        if (blocks > 4096) blocks = 4096;
+        if (blocks == 0) blocks = 1;
+        as.a[i] = a;
+        as.first[i] = total;
+        total += blocks;
+    }
+    for (int i = count; i <= COLVO_MAX_ARENAS; ++i) as.first[i] = total;
+    hipLaunchKernelGGL(k_adam_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, as, lr, beta1, beta2, eps, grad_scale, t);
+    COLVO_CHECK_LAUNCH("k_adam_multi");
+    return 0;
+}
+
+extern "C" int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int count, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(ptrs && bytes && count >= 1 && count <= COLVO_MAX_ARENAS, "colvo_zero_multi: bad arguments");
+    ZeroArenas zs{};
+    zs.count = count;
+    unsigned total = 0;
+    for (int i = 0; i < count; ++i) {
+        COLVO_CHECK_ARG(ptrs[i] && (uintptr_t)ptrs[i] % 16 == 0 && bytes[i] % 16 == 0,
+                        "colvo_zero_multi: buffer %d must be 16-byte aligned and a multiple of 16 bytes long", i);
+        zs.p[i] = ptrs[i];
+        zs.n16[i] = bytes[i] / 16;
+        unsigned blocks = nblk((zs.n16[i] + 3) / 4);          // four 16-byte stores per thread
+        if (blocks > 2048) blocks = 2048;
+        if (blocks == 0) blocks = 1;
+        zs.first[i] = total;
+        total += blocks;
+    }
+    for (int i = count; i <= COLVO_MAX_ARENAS; ++i) zs.first[i] = total;
+    hipLaunchKernelGGL(k_zero_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, zs);
+    COLVO_CHECK_LAUNCH("k_zero_multi");
     return 0;
 }
 

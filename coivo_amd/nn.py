@@ -705,8 +705,9 @@ class PoseNet(_ArenaModule):
         grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}
         grads = {k: v.contiguous() for k, v in grads.items() if v is not None}
         grads = dict(zip(grads.keys(), _dealias(list(grads.values()))))
-        d_t = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
-        d_r = torch.empty(B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
+        # both depth gradients from one launch: [2][B,1,H,W], each half a contiguous tensor of its own
+        d_tr = torch.empty(2, B, 1, H, W, device=dev, dtype=torch.float32) if has_depth else None
+        d_t, d_r = (d_tr[0], d_tr[1]) if has_depth else (None, None)
 
         def body():
             self._bwd_begin()
@@ -727,12 +728,11 @@ class PoseNet(_ArenaModule):
                     g = dx
             self._bwd_end()
             if has_depth:
-                ops.unpack_nhwc_grad(g, 6, 1, d_t, False)
-                ops.unpack_nhwc_grad(g, 7, 1, d_r, False)
+                ops.unpack_nhwc_grad(g, 6, 2, d_tr, False, by_channel=True)
 
         ext = dict(grads)
         if has_depth:
-            ext["d_t"], ext["d_r"] = d_t, d_r
+            ext["d_tr"] = d_tr
         which = "bwd:" + ",".join(sorted(grads))       # a missing (None) gradient changes the recorded commands
         self._run_pass(inst, which, ext, body)
         return d_t, d_r

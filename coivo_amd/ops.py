@@ -139,16 +139,20 @@ def pack_nchw(srcs: Sequence[torch.Tensor], Cpad: int, dtype: torch.dtype, out: 
     return out
 
 
-def unpack_nhwc_grad(dsrc: torch.Tensor, c_begin: int, c_count: int, dst: torch.Tensor, accumulate: bool) -> None:
+def unpack_nhwc_grad(dsrc: torch.Tensor, c_begin: int, c_count: int, dst: torch.Tensor, accumulate: bool,
+                     by_channel: bool = False) -> None:
+    """Channels [c_begin, c_begin + c_count) of an NHWC gradient -> fp32 planes: dst [B,c_count,H,W], or with by_channel
+    [c_count,B,1,H,W] (every channel a contiguous [B,1,H,W] tensor of its own: one launch for several consumers)."""
     _need_cuda(dsrc, dst)
     B, H, W, Cpad = dsrc.shape
+    flags = int(bool(accumulate)) | (2 if by_channel else 0)
     rec = program.recording()
     if rec is not None:
         return rec.add(_lib.CMD_UNPACK_NHWC_GRAD, None, (dsrc, dst),
-                       (dt_code(dsrc.dtype), B, H, W, Cpad, c_begin, c_count, int(accumulate)))
+                       (dt_code(dsrc.dtype), B, H, W, Cpad, c_begin, c_count, flags))
     lib = _lib.load()
     _lib.check(lib.colvo_unpack_nhwc_grad(dt_code(dsrc.dtype), _lib.ptr(dsrc), B, H, W, Cpad, c_begin, c_count,
-                                          _lib.ptr(dst), int(accumulate), _lib.stream_ptr()), "colvo_unpack_nhwc_grad")
+                                          _lib.ptr(dst), flags, _lib.stream_ptr()), "colvo_unpack_nhwc_grad")
 
 
 def relu_bwd_inplace(y: torch.Tensor, dy: torch.Tensor) -> None:
@@ -200,6 +204,35 @@ def depth_head_bwd_parts(x, w, depth, g_first, g_second, g_raw, scale_a, scale_b
                                               _lib.ptr(scale_b),
                                               B, H, W, Cc, MIN_DEPTH, MAX_DEPTH, _lib.ptr(scratch), _lib.ptr(dx), 0, 0,
                                               _lib.stream_ptr()), "colvo_depth_head_bwd_parts")
+
+
+def zero_multi(tensors) -> None:
+    """Zero up to four contiguous device tensors (16-byte aligned, sizes multiples of 16 bytes: the gradient arenas) in ONE
+    launch on the current stream."""
+    tensors = [t for t in tensors if t is not None and t.numel()]
+    _need_cuda(*tensors)
+    if not tensors:
+        return
+    if len(tensors) > _lib.MAX_ARENAS or any(not t.is_contiguous() or (t.numel() * t.element_size()) % 16 or t.data_ptr() % 16
+                                             for t in tensors):
+        for t in tensors:
+            zero_(t)
+        return
+    n = len(tensors)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    sizes = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    _lib.check(_lib.load().colvo_zero_multi(ptrs, sizes, n, _lib.stream_ptr()), "colvo_zero_multi")
+
+
+def adam_step_multi(arenas, t: int, *, lr, beta1, beta2, eps, grad_scale=1.0) -> None:
+    """Adam over several (param, grad, exp_avg, exp_avg_sq) arena quadruples with one host-side step number, one launch."""
+    n = len(arenas)
+    arr = (_lib.AdamArena * n)()
+    for i, (p, g, m, v) in enumerate(arenas):
+        _need_cuda(p, g, m, v)
+        arr[i].param, arr[i].grad, arr[i].exp_avg, arr[i].exp_avg_sq, arr[i].n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+    _lib.check(_lib.load().colvo_adam_step_multi(arr, n, lr, beta1, beta2, eps, grad_scale, int(t), _lib.stream_ptr()),
+               "colvo_adam_step_multi")
 
 
 def zero_(t: torch.Tensor) -> None:

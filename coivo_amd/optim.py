@@ -7,7 +7,7 @@ from typing import Iterable, List
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .nn import _ArenaModule
 
 
@@ -24,6 +24,7 @@ class FusedAdam:
                 raise TypeError("FusedAdam takes the HIP-backed networks (coivo_amd.nn.DepthNet / PoseNet)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.grad_scale = 1.0
+        self._multi = _lib.dev_env("COLVO_NO_MULTI_ARENA") is None          # developer A/B switch (COLVO_DEV=1)
         # Step numbers live on the host (one launch per network); while a hipGraph is being captured the device counters of
         # the state are used instead (a captured step number would repeat at every replay) and kept in step with the host's.
         self._t = 0
@@ -34,8 +35,16 @@ class FusedAdam:
                                    step=torch.zeros(1, dtype=torch.int32, device=dev)))
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        # arena semantics: the gradients stay attached; every network's arena is cleared by ONE launch
+        if not self._multi:
+            for m in self.modules:
+                m.zero_grad()
+            return
         for m in self.modules:
-            m.zero_grad()
+            m.join_side()
+        ops.zero_multi([m.flat_grad for m in self.modules])
+        for m in self.modules:
+            m.attach_grads()
 
     @torch.no_grad()
     def step(self) -> None:
@@ -43,6 +52,16 @@ class FusedAdam:
         if capturing and not self._device_steps:
             raise RuntimeError("FusedAdam: call use_device_step_counter() before capturing a step into a graph")
         self._t += 1
+        if self._multi and not self._device_steps and len(self.modules) <= _lib.MAX_ARENAS:
+            # one launch for all networks (the step number comes from the host)
+            for m in self.modules:
+                m.join_side()
+                m.attach_grads()
+            ops.adam_step_multi([(m.flat_param, m.flat_grad, st["exp_avg"], st["exp_avg_sq"]) for m, st in zip(self.modules, self.state)],
+                                self._t, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
+            for m in self.modules:
+                m.mark_params_changed()
+            return
         for m, st in zip(self.modules, self.state):
             m.join_side()
             m.attach_grads()

@@ -222,6 +222,8 @@ int colvo_pack_weights_multi(int dtype, const float* master, const void* table, 
  * src[i] points to an [B,c_i,H,W] tensor; up to 4 sources are concatenated along channels. */
 int colvo_pack_nchw(int dtype, const float* const* src, const int32_t* src_channels, int nsrc,
                     int B, int H, int W, int Cpad, void* dst, colvo_stream_t stream);
+/* accumulate: bit 0 = add to dst instead of overwriting it; bit 1 = dst is laid out [c_count][B][H][W] (each channel a contiguous
+ * [B,1,H,W] tensor of its own) instead of [B,c_count,H,W]. */
 int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H, int W, int Cpad,
                            int c_begin, int c_count, float* dst_nchw, int accumulate, colvo_stream_t stream);
 
@@ -271,6 +273,20 @@ int colvo_adam_step_t(float* param, const float* grad, float* exp_avg, float* ex
                       float lr, float beta1, float beta2, float eps, float grad_scale, int t, colvo_stream_t stream);
 /* Zero `bytes` bytes of device memory on `stream` (the gradient arenas, once per step). */
 int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream);
+/* Both networks' arenas in ONE launch each (a dependent launch costs ~2.7 us on MI355X before it does anything and the small
+ * arena alone does not fill the memory system): colvo_adam_step_t over up to COLVO_MAX_ARENAS arenas with one step number, and
+ * the zeroing of up to as many buffers (16-byte aligned, multiples of 16 bytes). */
+#define COLVO_MAX_ARENAS 4
+typedef struct ColvoAdamArena {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    size_t n;
+} ColvoAdamArena;
+int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, float lr, float beta1, float beta2, float eps,
+                          float grad_scale, int t, colvo_stream_t stream);
+int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int count, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * SURVEY.md §8f-3  inference: dense depth maps stitched along the integrated trajectory into a  *
