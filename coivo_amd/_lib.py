@@ -29,6 +29,7 @@ class AdamArena(C.Structure):
 
 
 MAX_ARENAS = 4
+ADAM_PLAIN_PER_WG = 2048          # COLVO_ADAM_PLAIN_PER_WG
 
 
 # name -> (restype, argtypes); lists every symbol include/colvo.h declares
@@ -62,6 +63,7 @@ SIGNATURES = {
     "colvo_avgpool2_bwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "colvo_adam_step_multi": (_i, [_vp, _i, _f, _f, _f, _f, _f, _i, _vp]),
     "colvo_zero_multi": (_i, [_vp, _vp, _i, _vp]),
+    "colvo_adam_pack_step": (_i, [_i, _vp, _i, _i, _f, _f, _f, _f, _f, _vp, _i, _vp]),
     "colvo_full_objective_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "colvo_full_objective_fwd": (_i, [_vp] * 8 + [_i] * 4 + [_f] * 3 + [_vp] * 3),
     "colvo_full_objective_bwd": (_i, [_vp] * 3 + [_i] * 4 + [_f, _f] + [_vp] * 6),

@@ -44,6 +44,7 @@ struct PackEntry {
     int Cout, kk, Cin, blk_begin;
 };
 constexpr int PK_CO = 32, PK_C = 64;       // transpose tile: 32 output channels x 64 input channels of one tap
+constexpr int ADAM_PLAIN_PER_WG = COLVO_ADAM_PLAIN_PER_WG;
 template <int ES>
 __global__ __launch_bounds__(NT) void k_pack_weights_multi(const float* __restrict__ master, const PackEntry* __restrict__ tab,
                                                            int nlayers, void* __restrict__ fwd, void* __restrict__ bwd) {
@@ -779,6 +780,73 @@ __global__ __launch_bounds__(NT) void k_adam_multi(AdamArenas as, float lr, floa
     }
 }
 
+// Adam AND the operand copies of the updated weights in one pass (both networks, one launch): the update has every new weight in
+// a register, so the bf16 / transposed copies the next forward and backward pass read cost 4 more bytes per parameter here
+// instead of a 12-byte-per-parameter repacking pass of their own (k_pack_weights_multi) plus its launches.  Table-driven like
+// that kernel: an entry of kind 0 is one 3x3 layer's weights, walked in 32 x 64 transpose tiles of one tap; an entry of kind 1
+// a plain range of the arena (biases, heads, padding) that only takes the update.  Same arithmetic as k_adam, element for element.
+template <int ES>
+__global__ __launch_bounds__(NT) void k_adam_pack(const ColvoAdamPackEntry* __restrict__ tab, int nentries, float lr, float b1,
+                                                  float b2, float eps, float gscale, const int32_t* __restrict__ step_count,
+                                                  int t_host) {
+    __shared__ float tile[PK_CO][PK_C + 1];
+    const AdamCoef c = adam_coef(lr, b1, b2, step_count, t_host);
+    int l = 0;
+    for (int i = 1; i < nentries; ++i)
+        if ((int)blockIdx.x >= tab[i].blk_begin) l = i;
+    const ColvoAdamPackEntry e = tab[l];
+    const int lb = blockIdx.x - e.blk_begin, tid = threadIdx.x;
+    float* __restrict__ P = e.param + e.w_off;
+    const float* __restrict__ G = e.grad + e.w_off;
+    float* __restrict__ M = e.exp_avg + e.w_off;
+    float* __restrict__ V = e.exp_avg_sq + e.w_off;
+    if (e.kind != 0) {                     // plain range: ADAM_PLAIN_PER_WG elements per workgroup
+        const long long k0 = (long long)lb * ADAM_PLAIN_PER_WG;
+        for (long long k = k0 + tid; k < e.n && k < k0 + ADAM_PLAIN_PER_WG; k += NT) {
+            float pi = P[k], mi = M[k], vi = V[k];
+            adam_one(pi, G[k], mi, vi, b1, b2, eps, gscale, c);
+            M[k] = mi; V[k] = vi; P[k] = pi;
+        }
+        return;
+    }
+    const int nct = (e.Cin + PK_C - 1) / PK_C, ncot = (e.Cout + PK_CO - 1) / PK_CO;
+    const int t = lb / (ncot * nct), r = lb - t * (ncot * nct);
+    const int cot = r / nct, ct = r - cot * nct;
+    const int co0 = cot * PK_CO, c0 = ct * PK_C;
+    {
+        const int cc = c0 + (tid & 63);
+        float pv[PK_CO / 4], gv[PK_CO / 4], mv[PK_CO / 4], vv[PK_CO / 4];
+#pragma unroll
+        for (int i = 0; i < PK_CO / 4; ++i) {           // all loads first: 32 in flight per thread
+            const int co = co0 + (tid >> 6) + 4 * i;
+            const bool ok = co < e.Cout && cc < e.Cin;
+            const size_t idx = ok ? ((size_t)co * e.kk + t) * e.Cin + cc : 0;
+            pv[i] = P[idx]; gv[i] = G[idx]; mv[i] = M[idx]; vv[i] = V[idx];
+        }
+#pragma unroll
+        for (int i = 0; i < PK_CO / 4; ++i) {
+            const int row = (tid >> 6) + 4 * i, co = co0 + row;
+            if (co < e.Cout && cc < e.Cin) {
+                const size_t idx = ((size_t)co * e.kk + t) * e.Cin + cc;
+                adam_one(pv[i], gv[i], mv[i], vv[i], b1, b2, eps, gscale, c);
+                M[idx] = mv[i]; V[idx] = vv[i]; P[idx] = pv[i];
+                tile[row][tid & 63] = pv[i];
+                if (e.fwd && e.fwd_off >= 0) Elem<ES>::st(e.fwd, e.fwd_off + idx, pv[i]);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int co = co0 + (tid & 31);
+#pragma unroll
+        for (int i = 0; i < PK_C / 8; ++i) {
+            const int col = (tid >> 5) + 8 * i, cc = c0 + col;
+            if (co < e.Cout && cc < e.Cin)
+                Elem<ES>::st(e.bwd, e.bwd_off + ((size_t)cc * e.kk + (e.kk - 1 - t)) * e.Cout + co, tile[tid & 31][col]);   // taps flipped
+        }
+    }
+}
+
 // zero several buffers in one launch (16-byte stores; sizes are multiples of 16 bytes)
 struct ZeroArenas {
     int count;
@@ -1114,6 +1182,21 @@ extern "C" int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, fl
     for (int i = count; i <= COLVO_MAX_ARENAS; ++i) as.first[i] = total;
     hipLaunchKernelGGL(k_adam_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, as, lr, beta1, beta2, eps, grad_scale, t);
     COLVO_CHECK_LAUNCH("k_adam_multi");
+    return 0;
+}
+
+extern "C" int colvo_adam_pack_step(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
+                                    float eps, float grad_scale, int32_t* step_count, int t, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(table && nentries >= 1 && nblocks >= 1 && (step_count || t >= 1), "colvo_adam_pack_step: bad arguments");
+    COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_adam_pack_step: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_adam_pack<ES>), dim3(nblocks), dim3(NT), 0, s, (const ColvoAdamPackEntry*)table,
+                                          nentries, lr, beta1, beta2, eps, grad_scale, (const int32_t*)step_count, t));
+    COLVO_CHECK_LAUNCH("k_adam_pack");
+    if (step_count) {
+        hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
+        COLVO_CHECK_LAUNCH("k_inc_step");
+    }
     return 0;
 }
 

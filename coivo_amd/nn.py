@@ -165,13 +165,42 @@ class _ArenaModule(nn.Module):
     def mark_params_changed(self) -> None:
         self._manual_version += 1
 
-    def _prepare_weights(self) -> None:
-        """Refresh the operand-layout copies of the weights when the master changed (one launch per network)."""
+    def _weights_version(self):
         # in-place updates of the parameters (any optimizer, load_state_dict) bump their version counters
         self._layers()
-        ver = (sum(p._version for p in self.__dict__["_param_list"]), self._manual_version, self.compute_dtype)
+        return (sum(p._version for p in self.__dict__["_param_list"]), self._manual_version, self.compute_dtype)
+
+    def _prepare_weights(self) -> None:
+        """Refresh the operand-layout copies of the weights when the master changed (one launch per network)."""
+        ver = self._weights_version()
         if ver == self._packed_version:
             return
+        self._ensure_operand_buffers()
+        ops.pack_weights_multi(self.flat_param, self._pack_table, self._pack_n, self._pack_blocks, self.compute_dtype, self._op_fwd,
+                               self._op_bwd)
+        self._packed_version = ver
+
+    def operand_layout(self):
+        """For an optimizer that writes the operand copies itself (optim.FusedAdam -> colvo_adam_pack_step):
+        -> (layers, rest, op_fwd, op_bwd): layers = [(w_off, fwd_off or -1, bwd_off, Cout, Cin_pad)] of the 3x3 layers whose
+        weights have operand copies, rest = [(offset, n)] every other range of the arena, the two operand buffers."""
+        self._ensure_operand_buffers()
+        layers, rest, at = [], [], 0
+        for w_off, fwd_off, bwd_off, cout, cin in self._pack_layers:
+            if w_off > at:
+                rest.append((at, w_off - at))
+            layers.append((w_off, fwd_off, bwd_off, cout, cin))
+            at = w_off + cout * 9 * cin
+        if self.flat_param.numel() > at:
+            rest.append((at, self.flat_param.numel() - at))
+        return layers, rest, self._op_fwd, self._op_bwd
+
+    def operands_written(self) -> None:
+        """The caller has just rewritten the master weights AND both operand copies (see operand_layout)."""
+        self._manual_version += 1
+        self._packed_version = self._weights_version()
+
+    def _ensure_operand_buffers(self) -> None:
         dt = self.compute_dtype
         dev = self.flat_param.device
         if self._pack_table is None or self._pack_dtype != dt:
@@ -183,18 +212,18 @@ class _ArenaModule(nn.Module):
             self._op_bwd = torch.empty(total, device=dev, dtype=dt)
             self._op_fwd = None if dt == torch.float32 else torch.empty(total, device=dev, dtype=dt)
             off = blk = 0
+            self._pack_layers = []
             for i, L in enumerate(layers):
                 n = L.cout * 9 * L.cin_pad
                 tab[i] = (L.span[0], -1 if self._op_fwd is None else off, off, L.cout, 9, L.cin_pad, blk)
+                self._pack_layers.append((L.span[0], -1 if self._op_fwd is None else off, off, L.cout, L.cin_pad))
                 L.w_bwd = self._op_bwd[off:off + n].view(L.cin_pad, 9, L.cout)
                 L.w_fwd = L.w_master if self._op_fwd is None else self._op_fwd[off:off + n].view(L.cout, 9, L.cin_pad)
                 off += n
                 blk += 9 * ((L.cout + 31) // 32) * ((L.cin_pad + 63) // 64)   # include/colvo.h: colvo_pack_weights_multi
             self._pack_table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
             self._pack_n, self._pack_blocks, self._pack_dtype = len(layers), blk, dt
-        ops.pack_weights_multi(self.flat_param, self._pack_table, self._pack_n, self._pack_blocks, dt, self._op_fwd,
-                               self._op_bwd)
-        self._packed_version = ver
+            self._packed_version = None
 
     # ---- recorded passes ------------------------------------------------------------------------------- #
     def clear_programs(self) -> None:

@@ -24,7 +24,8 @@ class FusedAdam:
                 raise TypeError("FusedAdam takes the HIP-backed networks (coivo_amd.nn.DepthNet / PoseNet)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.grad_scale = 1.0
-        self._multi = _lib.dev_env("COLVO_NO_MULTI_ARENA") is None          # developer A/B switch (COLVO_DEV=1)
+        self._multi = _lib.dev_env("COLVO_NO_MULTI_ARENA") is None          # developer A/B switches (COLVO_DEV=1)
+        self._fused_pack = _lib.dev_env("COLVO_NO_ADAM_PACK") is None
         # Step numbers live on the host (one launch per network); while a hipGraph is being captured the device counters of
         # the state are used instead (a captured step number would repeat at every replay) and kept in step with the host's.
         self._t = 0
@@ -52,6 +53,8 @@ class FusedAdam:
         if capturing and not self._device_steps:
             raise RuntimeError("FusedAdam: call use_device_step_counter() before capturing a step into a graph")
         self._t += 1
+        if self._fused_pack and self._pack_step():
+            return
         if self._multi and not self._device_steps and len(self.modules) <= _lib.MAX_ARENAS:
             # one launch for all networks (the step number comes from the host)
             for m in self.modules:
@@ -73,6 +76,54 @@ class FusedAdam:
                                 beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
             m.mark_params_changed()
 
+    # ---- update + operand copies in one pass (include/colvo.h colvo_adam_pack_step) -------------------------------------- #
+    def _pack_step(self) -> bool:
+        """One launch: Adam over every network's arena AND the bf16 / transposed operand copies of the updated 3x3 weights, so
+        that the next forward pass finds them current.  False when the networks do not share one compute dtype."""
+        dts = {m.compute_dtype for m in self.modules}
+        if len(dts) != 1:
+            return False
+        dt = dts.pop()
+        for m in self.modules:
+            m.join_side()
+            m.attach_grads()
+        tab = self._pack_table()
+        step_ptr = _lib.ptr(self.state[0]["step"]) if self._device_steps else 0
+        _lib.check(_lib.load().colvo_adam_pack_step(ops.dt_code(dt), _lib.ptr(tab[0]), tab[1], tab[2], self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, self.grad_scale, step_ptr, self._t, _lib.stream_ptr()),
+                   "colvo_adam_pack_step")
+        # (with device-side step numbers only the first network's counter is advanced here; _sync_step_state() brings the
+        # others in line when the state is read)
+        for m in self.modules:
+            m.operands_written()
+        return True
+
+    def _pack_table(self):
+        import numpy as np
+        key = tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), m.compute_dtype, id(m._pack_table)) for m in self.modules)
+        if self._pack_cache is not None and self._pack_cache[0] == key and all(m._pack_table is not None for m in self.modules):
+            return self._pack_cache[1]
+        ent = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"),
+                        ("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"), ("n", "<i8"),
+                        ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+        rows, blk = [], 0
+        for m, st in zip(self.modules, self.state):
+            layers, rest, op_fwd, op_bwd = m.operand_layout()
+            base = (m.flat_param.data_ptr(), m.flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                    0 if op_fwd is None else op_fwd.data_ptr(), op_bwd.data_ptr())
+            for w_off, fwd_off, bwd_off, cout, cin in layers:
+                rows.append(base + (w_off, fwd_off, bwd_off, 0, cout, 9, cin, blk, 0, 0))
+                blk += 9 * ((cout + 31) // 32) * ((cin + 63) // 64)
+            for off, n in rest:
+                rows.append(base + (off, -1, 0, n, 0, 0, 0, blk, 1, 0))
+                blk += (n + _lib.ADAM_PLAIN_PER_WG - 1) // _lib.ADAM_PLAIN_PER_WG
+        tab = np.array(rows, dtype=ent)
+        dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.modules[0].flat_param.device)
+        key = tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), m.compute_dtype, id(m._pack_table)) for m in self.modules)
+        self._pack_cache = (key, (dev_tab, len(rows), blk))
+        return self._pack_cache[1]
+
+    _pack_cache = None
     _device_steps = False
 
     def use_device_step_counter(self) -> None:
@@ -85,6 +136,8 @@ class FusedAdam:
     def _sync_step_state(self) -> None:
         if self._device_steps:
             self._t = int(self.state[0]["step"].item()) if self.state else self._t
+            for st in self.state[1:]:
+                st["step"].fill_(self._t)
         else:
             for st in self.state:
                 st["step"].fill_(self._t)

@@ -287,6 +287,28 @@ typedef struct ColvoAdamArena {
 int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, float lr, float beta1, float beta2, float eps,
                           float grad_scale, int t, colvo_stream_t stream);
 int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int count, colvo_stream_t stream);
+/* Adam and the operand copies of the updated weights in ONE pass over any number of arenas: colvo_adam_step[_t] followed by
+ * colvo_pack_weights_multi, without the second pass over the parameters (12 bytes per parameter) and its launches.  `table`
+ * (device memory) is an array of ColvoAdamPackEntry: kind 0 = the weights of one 3x3 layer ([Cout][kk][Cin] fp32 at element
+ * w_off of the four arenas; forward copy at element fwd_off of `fwd` (skipped when fwd is NULL or fwd_off < 0), transposed /
+ * tap-flipped copy at bwd_off of `bwd`, both in `dtype`), taking kk * ceil(Cout/32) * ceil(Cin/64) workgroups from blk_begin on;
+ * kind 1 = a plain range of n elements at w_off (biases, heads, padding: update only), ceil(n / COLVO_ADAM_PLAIN_PER_WG)
+ * workgroups.  nblocks = the sum.  step_count: device step counter (incremented by a second launch; for steps captured into a
+ * hipGraph) or NULL, then t is the 1-based step number. */
+#define COLVO_ADAM_PLAIN_PER_WG 2048
+typedef struct ColvoAdamPackEntry {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* fwd;
+    void* bwd;
+    int64_t w_off, fwd_off, bwd_off, n;
+    int32_t Cout, kk, Cin, blk_begin;
+    int32_t kind, pad_;
+} ColvoAdamPackEntry;
+int colvo_adam_pack_step(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
+                         float eps, float grad_scale, int32_t* step_count, int t, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * SURVEY.md §8f-3  inference: dense depth maps stitched along the integrated trajectory into a  *

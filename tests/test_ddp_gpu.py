@@ -76,7 +76,9 @@ def test_rccl_path_with_one_rank():
         r = subprocess.run(common + extra, capture_output=True, text=True, env=env, timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = json.loads(r.stdout.strip().split("\n")[-1])
-    assert abs(out["rccl"]["final_loss"] - out["plain"]["final_loss"]) < 2e-3
-    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) < 2e-3
+    # the final loss of 35 steps on one batch varies by +-1.5e-3 (0.0234 .. 0.0257) from run to run of ONE configuration: float
+    # atomics in the weight gradients, amplified by Adam's sign-like first steps; the plumbing check only needs "the same problem"
+    assert abs(out["rccl"]["final_loss"] - out["plain"]["final_loss"]) < 5e-3
+    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) < 5e-3
     assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
     assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]

@@ -257,3 +257,47 @@ def test_zero_grad_is_ordered_with_both_backward_streams():
     dn.zero_grad()
     dn.join_side()                                  # what FusedAdam.step() does before it reads the arena
     assert float(dn.flat_grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adam_with_operand_copies_in_one_pass_equals_the_two_pass_form(dtype):
+    """FusedAdam's default step (colvo_adam_pack_step: the update and the bf16 / transposed operand copies of the new weights in
+    ONE launch for both networks) against update + colvo_pack_weights_multi: parameters, optimizer state and operand copies
+    bit for bit, over three steps (deterministic weight gradients make the trajectories comparable exactly)."""
+    from coivo_amd import nn as hnn
+    from coivo_amd.optim import FusedAdam
+    d = to_dev(synth.make_batch(2, 64, 96, seed=14))
+
+    def run(fused):
+        _, _, dn, pn = _models(14, dtype)
+        dn.deterministic = pn.deterministic = True
+        opt = FusedAdam([dn, pn], lr=1e-3)
+        opt._fused_pack = fused
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            loss = hnn.dcdp_forward(dn, pn, d["tgt"], d["ref"], d["K"])[0]
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        for n in (dn, pn):
+            n._prepare_weights()                     # a no-op after the fused step, the packing pass after the plain one
+        torch.cuda.synchronize()
+        return (losses, [n.flat_param.clone() for n in (dn, pn)], [n._op_bwd.clone() for n in (dn, pn)],
+                [None if n._op_fwd is None else n._op_fwd.clone() for n in (dn, pn)],
+                [st["exp_avg_sq"].clone() for st in opt.state], opt)
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0]
+    for k in (1, 2, 4):
+        for x, y in zip(a[k], b[k]):
+            assert torch.equal(x, y)
+    for x, y in zip(a[3], b[3]):
+        assert (x is None and y is None) or torch.equal(x, y)
+    # the fused step leaves the operand copies current: the next forward launches no packing pass
+    opt = a[5]
+    dn = opt.modules[0]
+    assert dn._packed_version == dn._weights_version()
+    # state_dict round trip keeps the step number
+    sd = opt.state_dict()
+    assert int(sd["state"][0]["step"].item()) == 3 and int(sd["state"][1]["step"].item()) == 3
