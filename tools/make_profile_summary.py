@@ -25,7 +25,7 @@ f = newest(f"{SRC}/bench_trace/*/*_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 with open(f"profiles/{R}_bench_kernel_stats.csv", "w", newline="") as o:
     w = csv.writer(o)
-    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline: 48 fast-path steps (23 of the eager-or-replay decision + 5 warm-up + 20 timed), 23 steps of the spec call sequence (spec_sequence_ms side measurement: 3 + 20), 23 steps with the widened objective (full_objective side measurement) and the configs[2] roofline probe of the fused loss (25 launches)"])
+    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph off: 25 fast-path steps (5 warm-up + 20 timed), 23 steps of the spec call sequence (spec_sequence_ms side measurement: 3 + 20), 23 steps with the widened objective (full_objective side measurement) and the configs[2] roofline probe of the fused loss (25 launches)"])
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"].replace("colvo::(anonymous namespace)::", "")[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
@@ -38,7 +38,7 @@ try:
     rows = list(csv.DictReader(open(f)))
     with open(f"profiles/{R}_full_objective_kernel_stats.csv", "w", newline="") as o:
         w = csv.writer(o)
-        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-cfg2 --full-loss: 48 steps with the widened objective (multi-scale photometric + geometric consistency + smoothness): per step k_full_prepare + k_warp_loss_march_levels + k_full_finalize forward and k_full_combine backward; no at::native kernel inside the step (CatArrayBatchedCopy / copy / fill rows are the set-up)"])
+        w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-cfg2 --full-loss --graph off: 25 steps with the widened objective (multi-scale photometric + geometric consistency + smoothness): per step k_full_prepare + k_warp_loss_march_levels + k_full_finalize forward and k_full_combine backward; no at::native kernel inside the step (CatArrayBatchedCopy / copy / fill rows are the set-up)"])
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r["Name"].replace("colvo::(anonymous namespace)::", "")[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
