@@ -315,6 +315,36 @@ def test_adam_matches_torch():
     assert torch.allclose(p.cpu(), pr.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_multi_arena_adam_and_zero_match_the_single_arena_calls():
+    """colvo_adam_step_multi / colvo_zero_multi: up to four arenas of ragged lengths in one launch == one call per arena, bit for
+    bit; lengths that are not multiples of four take the scalar tail."""
+    from coivo_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    sizes = [100003, 64, 7, 4096 * 5 + 4]
+    kw = dict(lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=0.5)
+    for count in (1, 2, 4):
+        arenas_a, arenas_b = [], []
+        for n in sizes[:count]:
+            base = [torch.randn(n, generator=g), torch.randn(n, generator=g), torch.rand(n, generator=g) * 0.1, torch.rand(n, generator=g) * 0.01]
+            arenas_a.append([t.to(d) for t in base])
+            arenas_b.append([t.to(d) for t in base])
+        for t in (1, 2, 7):
+            ops.adam_step_multi([tuple(a) for a in arenas_a], t, **kw)
+            for a in arenas_b:
+                ops.adam_step_t(a[0], a[1], a[2], a[3], t, **kw)
+        for a, b in zip(arenas_a, arenas_b):
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    bufs = [torch.full((n,), 3.0, device=d) for n in (64, 4096 * 3 + 16, 1 << 20, 4)]
+    guard = [torch.full((8,), 5.0, device=d) for _ in bufs]
+    ops.zero_multi(bufs)
+    assert all(float(b.abs().max()) == 0.0 for b in bufs) and all(float(gd.min()) == 5.0 for gd in guard)
+    odd = [torch.full((6,), 1.0, device=d)[1:], torch.full((64,), 1.0, device=d)]      # misaligned / not a multiple of 16 bytes
+    ops.zero_multi(odd)                                                                 # falls back to one memset each
+    assert all(float(b.abs().max()) == 0.0 for b in odd)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pack_weights_multi_matches_permute(dtype):
