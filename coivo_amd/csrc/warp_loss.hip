@@ -1456,7 +1456,8 @@ struct PrepArgs {
 };
 
 // Everything the one-pass kernels wait for, in ONE launch: blocks [0, sm_blocks) evaluate the smoothness term (value partials
-// and gradient, k_smooth_both's body), the rest build NL levels of the pyramid (one thread per cell of every plane).
+// and gradient in one pass, gather form as k_smooth_bwd), the rest build NL levels of the pyramid (one thread per cell of every
+// plane).
 template <int NL>
 __global__ __launch_bounds__(NT) void k_full_prepare(PrepArgs a) {
     const int H = a.H, W = a.W, B = a.B;

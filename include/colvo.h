@@ -116,14 +116,14 @@ int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, float* dx, col
  *   + smooth_weight * smoothness_loss, value AND every gradient.                               *
  *   README.md:1 "Considering Geometric and Photometric Consistency", :7.                       *
  * ------------------------------------------------------------------------------------------- */
-/* Forward: 4 + num_scales launches, no host synchronisation -- smoothness (value + raw gradient), the 2x2-average pyramid
- * of both frames and the target depth (one launch per level, intrinsics scaled inside the kernels), the one-pass
- * photometric kernel per level (loss + unnormalised gradients), whose level-0 launch ALSO evaluates the geometric-
- * consistency term on the projection and bilinear taps it has anyway (the reference frame's depth depth_r is a fourth
- * sampled plane), and one finalize.  The gradient w.r.t. depth_r is scattered as 64-bit fixed-point atomics (2^-32 units):
- * bit-reproducible.  tgt, ref [B,3,H,W]; depth_t, depth_r [B,1,H,W] (depth_r may be NULL when geo_weight == 0);
- * H, W divisible by 2^(num_scales-1), 1 <= num_scales <= 4.  workspace: colvo_full_objective_workspace_floats() floats,
- * 16-byte aligned, kept untouched until the backward call; loss: one device float.
+/* Forward: 3 launches, no host synchronisation -- (1) smoothness (value partials + raw gradient) and two levels of the 2x2-average
+ * pyramid of both frames and the target depth in one launch (a fourth level takes one more), (2) the one-pass photometric kernel
+ * over ALL levels in one launch (loss + unnormalised gradients; the intrinsics of level s are scaled inside the kernel), whose
+ * level-0 part ALSO evaluates the geometric-consistency term on the projection and bilinear taps it has anyway (the reference
+ * frame's depth depth_r is a fourth sampled plane), (3) one finalize.  The gradient w.r.t. depth_r is scattered as 64-bit fixed-point
+ * atomics (2^-32 units): bit-reproducible.  tgt, ref [B,3,H,W]; depth_t, depth_r [B,1,H,W] (depth_r may be NULL when
+ * geo_weight == 0); H, W divisible by 2^(num_scales-1), 1 <= num_scales <= 4.  workspace: colvo_full_objective_workspace_floats()
+ * floats, 16-byte aligned, kept untouched until the backward call; loss: one device float.
  * Backward: ONE launch; grad_loss: device scalar dL/dloss; d_depth_t, d_depth_r [B,1,H,W] (d_depth_r may be NULL when
  * geo_weight == 0), d_pose [B,6], d_a, d_b [B].  colvo_full_objective_terms: *state -> 32 device floats inside the workspace:
  * [0] total, [1] geometric term, [2] smoothness term, [4+4s ..] level s: {photometric loss, (1/S)/max(3 n_valid,1), n_valid}. */
