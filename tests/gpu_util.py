@@ -67,7 +67,11 @@ def grad_parity_table(named_hip, named_o32, named_o64, out_path=None):
 # Round-3 tables of the final round-2 build (gpurun_out/grad_parity_*.txt): HIP / fp32-oracle worst tensors 2.1e-6 / 1.6e-6
 # (B=2 64x96), 7.8e-4 / 4.9e-4 (configs[1]), 2.0e-3 / 1.9e-3 (B=1 256x320); a gradient 3x worse than the oracle's own
 # rounding noise fails at every shape.
-GRAD_K, GRAD_MAX_SLACK = 3.0, 2.0
+# Tensors of at most GRAD_TINY elements (the heads' biases: 1, 8, 16 values): their L2 norm is a small-sample statistic like
+# the maximum -- for the depth head's ONE bias value the two are the same number -- so the maximum's slack applies to it too
+# (seen: that scalar at 1.73e-6 against 3 x 5.7e-7 = 1.72e-6 and a worst oracle tensor of 1.61e-6 in one run of several; it is
+# summed with float atomics and moves in the last digits from run to run).
+GRAD_K, GRAD_MAX_SLACK, GRAD_TINY = 3.0, 2.0, 16
 
 
 def grad_parity_failures(rows):
@@ -75,7 +79,8 @@ def grad_parity_failures(rows):
     worst_max = max(r[4] / r[2] for r in rows)
     bad = []
     for name, n, scale, eh, eo, lh, lo in rows:
-        if lh > max(GRAD_K * lo, worst_l2) or eh > max(GRAD_K * eo, GRAD_MAX_SLACK * worst_max * scale):
+        l2_bar = max(GRAD_K * lo, (GRAD_MAX_SLACK if n <= GRAD_TINY else 1.0) * worst_l2)
+        if lh > l2_bar or eh > max(GRAD_K * eo, GRAD_MAX_SLACK * worst_max * scale):
             bad.append(f"{name}: relL2 hip {lh:.3e} vs o32 {lo:.3e} (worst o32 {worst_l2:.3e}); max err/scale hip "
                        f"{eh / scale:.3e} vs o32 {eo / scale:.3e} (worst o32 {worst_max:.3e})")
     return bad
