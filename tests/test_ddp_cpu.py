@@ -61,7 +61,8 @@ def _worker_buckets(rank, world, port, transport):
         dist.all_gather(ref_a, ga)
         ref_b = [torch.zeros(37) for _ in range(world)]
         dist.all_gather(ref_b, gbv)
-        tol = dict(rtol=0, atol=0) if transport is None else dict(rtol=2e-2, atol=2e-2)
+        # fp32 transport: two ranks add commutatively (exact); more ranks are summed in the collective's own order (rounding)
+        tol = (dict(rtol=0, atol=0 if world == 2 else 1e-5) if transport is None else dict(rtol=2e-2, atol=1e-2 * world))
         assert torch.allclose(a.flat_grad, sum(ref_a), **tol), f"step {step}"
         assert torch.allclose(b.flat_grad, sum(ref_b), **tol), f"step {step}"
     assert abs(gb.grad_scale - 1.0 / world) < 1e-12
@@ -71,6 +72,13 @@ def _worker_buckets(rank, world, port, transport):
 @pytest.mark.parametrize("transport", [None, torch.bfloat16])
 def test_bucketed_allreduce_world2(transport):
     mp.spawn(_worker_buckets, args=(2, _free_port(), transport), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("transport", [None, torch.bfloat16])
+def test_bucketed_allreduce_world8(transport):
+    """The same exchange at the rank count of BASELINE configs[3] / [4] (8 GPUs): bucket order, deferred and missing layers, the
+    1/8 gradient scale; the only rehearsal of N = 8 this build can run."""
+    mp.spawn(_worker_buckets, args=(8, _free_port(), transport), nprocs=8, join=True)
 
 
 class OracleArena:
