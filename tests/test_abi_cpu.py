@@ -64,6 +64,39 @@ def test_argument_validation_fails_loudly_without_gpu(lib):
     assert rc != 0 and b"multiples of 8" in lib.colvo_last_error()
 
 
+def test_round3_entry_points_validate_their_arguments(lib):
+    """The widened objective, the multi-arena optimizer calls: rejected before any launch, with a message."""
+    buf = (C.c_float * 64)()
+    p = C.addressof(buf)
+    # workspace size: 0 for shapes the call would refuse (H, W not divisible by 2^(scales-1); more than 4 scales)
+    assert lib.colvo_full_objective_workspace_floats(2, 48, 64, 3) > 0
+    assert lib.colvo_full_objective_workspace_floats(2, 48, 62, 3) == 0
+    assert lib.colvo_full_objective_workspace_floats(2, 48, 64, 5) == 0
+    assert lib.colvo_full_objective_workspace_floats(2, 48, 64, 1) < lib.colvo_full_objective_workspace_floats(2, 48, 64, 3)
+    rc = lib.colvo_full_objective_fwd(p, p, p, 0, p, p, p, p, 2, 48, 64, 3, 0.85, 0.5, 0.1, p, p, 0)      # geo term without depth_r
+    assert rc != 0 and b"reference depth" in lib.colvo_last_error()
+    rc = lib.colvo_full_objective_fwd(p, p, p, p, p, p, p, p, 2, 48, 62, 3, 0.85, 0.5, 0.1, p, p, 0)
+    assert rc != 0 and b"bad shape" in lib.colvo_last_error()
+    rc = lib.colvo_full_objective_fwd(p, p, p, p, p, p, p, p, 2, 48, 64, 3, 0.85, 0.5, 0.1, p + 4, p, 0)  # misaligned workspace
+    assert rc != 0 and b"16-byte aligned" in lib.colvo_last_error()
+    rc = lib.colvo_full_objective_bwd(p, p, p, 2, 48, 64, 3, 0.5, 0.1, p, 0, p, p, p, 0)                   # geo term without d_depth_r
+    assert rc != 0 and b"d_depth_r" in lib.colvo_last_error()
+    rc = lib.colvo_adam_step_multi(0, 2, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1, 0)
+    assert rc != 0 and b"colvo_adam_step_multi" in lib.colvo_last_error()
+    from coivo_amd._lib import AdamArena
+    arr = (AdamArena * 1)()
+    arr[0].param, arr[0].grad, arr[0].exp_avg, arr[0].exp_avg_sq, arr[0].n = p + 4, p, p, p, 8              # misaligned arena
+    rc = lib.colvo_adam_step_multi(arr, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1, 0)
+    assert rc != 0 and b"16-byte aligned" in lib.colvo_last_error()
+    rc = lib.colvo_adam_step_multi(arr, 5, 1e-3, 0.9, 0.999, 1e-8, 1.0, 1, 0)                               # more than COLVO_MAX_ARENAS
+    assert rc != 0
+    ptrs, sizes = (C.c_void_p * 1)(p), (C.c_size_t * 1)(20)                                                  # not a multiple of 16 bytes
+    rc = lib.colvo_zero_multi(ptrs, sizes, 1, 0)
+    assert rc != 0 and b"multiple of 16" in lib.colvo_last_error()
+    rc = lib.colvo_adam_pack_step(0, 0, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0, 1, 0)                         # no table
+    assert rc != 0 and b"colvo_adam_pack_step" in lib.colvo_last_error()
+
+
 def test_python_ops_refuse_cpu_tensors():
     from coivo_amd import functional as Fh
     t = torch.zeros(1, 3, 8, 8)
