@@ -188,8 +188,8 @@ def shard_indices(n: int, batch: int, rank: int, world_size: int, *, shuffle: bo
 
 
 class PairLoader:
-    """Iterating yields dict(tgt, ref [B,3,H,W] fp32 in [0,1] on `device`, K [B,3,3] at (H,W)).  Every batch's frames must
-    share one native size (a sequence folder from one camera does)."""
+    """Iterating yields dict(tgt, ref [B,3,H,W] fp32 in [0,1] on `device`, K [B,3,3] at (H,W), frames [2B,3,H,W] = the buffer tgt
+    and ref are the two halves of).  Every batch's frames must share one native size (a sequence folder from one camera does)."""
 
     def __init__(self, dataset: SequenceFolder, batch_size: int, size: Tuple[int, int], *, rank: int = 0,
                  world_size: int = 1, shuffle: bool = True, seed: int = 0, device="cuda", workers: int = 8, prefetch: int = 2,
@@ -409,7 +409,9 @@ class PairLoader:
                     for t in (out, Kd, raw):
                         t.record_stream(torch.cuda.current_stream(self.device))
                     B = out.shape[0] // 2
-                    yield {"tgt": out[:B], "ref": out[B:], "K": Kd}
+                    # "frames": the stacked buffer itself, [target frames | reference frames] = what DepthNet.forward_pair* and
+                    # nn.dcdp_forward(frames=...) take -- no torch.cat in the train loop
+                    yield {"tgt": out[:B], "ref": out[B:], "K": Kd, "frames": out}
                 pending = nxt
         finally:
             self._drain()           # generator closed early (break / exception): no staging task outlives its iterator

@@ -70,7 +70,8 @@ def test_loader_feeds_a_training_step(tmp_path):
     opt = optim.FusedAdam([dn, pn])
     losses = []
     for batch in ld:
-        loss = hnn.dcdp_forward(dn, pn, batch["tgt"], batch["ref"], batch["K"])[0]
+        assert batch["frames"].data_ptr() == batch["tgt"].data_ptr() and batch["frames"].shape[0] == 2 * batch["tgt"].shape[0]
+        loss = hnn.dcdp_forward(dn, pn, None, None, batch["K"], frames=batch["frames"])[0]      # the stacked buffer: no torch.cat
         loss.backward()
         opt.step()
         losses.append(loss.item())

@@ -57,7 +57,7 @@ def main():
 
             def step(b):
                 opt.zero_grad()
-                frames = torch.cat([b["tgt"], b["ref"]])
+                frames = b["frames"]                 # the loader's stacked buffer: [target frames | reference frames]
                 d_t, d_r, d_l = dn.forward_pair_split(frames)
                 pose, a, bb = pn(frames[:B], frames[B:], d_t, d_r)
                 Fh.photometric_loss(frames[:B], frames[B:], d_l, pose, b["K"], a, bb).backward(gradient=one)
