@@ -616,7 +616,8 @@ def main():
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},
-               "final_loss": final_loss, "hipgraph": use_graph, "hipgraph_trial": graph_trial, "hipgraph_error": graph_error,
+               "final_loss": final_loss, "deterministic_weight_gradients": bool(dn.deterministic and pn.deterministic),
+               "hipgraph": use_graph, "hipgraph_trial": graph_trial, "hipgraph_error": graph_error,
                "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group} if use_graph else None),
                "roofline": roof}
         out.update(side)

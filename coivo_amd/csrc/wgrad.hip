@@ -366,13 +366,30 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     }
 }
 
-// deterministic form, second launch: dst[i] += slabs[0][i] + slabs[1][i] + ... in split order
-__global__ __launch_bounds__(NT) void k_wgrad_reduce(const float* __restrict__ slabs, int nsplit, size_t n, float* __restrict__ dst) {
-    for (size_t i = (size_t)blockIdx.x * NT + threadIdx.x; i < n; i += (size_t)gridDim.x * NT) {
+// deterministic form, second launch: dst[i] += slabs[0][i] + slabs[1][i] + ... in split order; the bias slabs ride in the same launch
+// (blocks beyond `wblocks`).  Eight slab loads are in flight before the adds consume them in order (one load per add was a chain of
+// up to 32 dependent trips to L2: 20 us a launch on average).
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ slabs, int nsplit, size_t n, float* __restrict__ dst,
+                                             size_t first, size_t stride) {
+    for (size_t i = first; i < n; i += stride) {
         float t = 0.0f;
-        for (int q = 0; q < nsplit; ++q) t += slabs[(size_t)q * n + i];
+        int q = 0;
+        for (; q + 8 <= nsplit; q += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slabs[(size_t)(q + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; q < nsplit; ++q) t += slabs[(size_t)q * n + i];
         dst[i] += t;
     }
+}
+__global__ __launch_bounds__(NT) void k_wgrad_reduce(const float* __restrict__ slabs, int nsplit, size_t n, float* __restrict__ dst,
+                                                     unsigned wblocks, const float* __restrict__ bslabs, size_t nb,
+                                                     float* __restrict__ bdst) {
+    if (blockIdx.x < wblocks) reduce_slabs(slabs, nsplit, n, dst, (size_t)blockIdx.x * NT + threadIdx.x, (size_t)wblocks * NT);
+    else reduce_slabs(bslabs, nsplit, nb, bdst, (size_t)(blockIdx.x - wblocks) * NT + threadIdx.x, (size_t)(gridDim.x - wblocks) * NT);
 }
 
 // plan-only calls report the split count; deterministic calls point the kernel at the caller's scratch.  Returns 1 when the
@@ -398,9 +415,10 @@ inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
 inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
     if (!k.slabs) return 0;
     const size_t wsize = (size_t)k.Cout * 9 * k.Ctot;
-    unsigned blocks = (unsigned)std::min<size_t>((wsize + NT - 1) / NT, 2048);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks), dim3(NT), 0, s, (const float*)k.slabs, nsplit, wsize, k.dw);
-    if (k.db) hipLaunchKernelGGL(k_wgrad_reduce, dim3(1), dim3(NT), 0, s, (const float*)k.db_slabs, nsplit, (size_t)k.Cout, k.db);
+    const unsigned blocks = (unsigned)std::min<size_t>((wsize + NT - 1) / NT, 2048);
+    const unsigned bblocks = k.db ? (unsigned)((k.Cout + NT - 1) / NT) : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks + bblocks), dim3(NT), 0, s, (const float*)k.slabs, nsplit, wsize, k.dw, blocks,
+                       (const float*)k.db_slabs, (size_t)k.Cout, k.db);
     COLVO_CHECK_LAUNCH("k_wgrad_reduce");
     return 0;
 }
