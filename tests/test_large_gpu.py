@@ -54,3 +54,50 @@ def test_wgrad_batch_slicing_matches_unsliced():
     ops.conv_wgrad(half, x[h:], None, dy[h:], dw2, db2)
     assert torch.allclose(dw, dw2, rtol=1e-4, atol=1e-3 * dw2.abs().max().item())
     assert torch.allclose(db, db2, rtol=1e-4, atol=1e-3 * db2.abs().max().item())
+
+
+def test_config2_size_widened_objective_properties():
+    """The native widened objective at BASELINE configs[2] size (32 pairs of 640x512; 10.5 M pixels at level 0): no oracle runs
+    at this size in seconds, so size-independent properties -- (a) the 8-pair slices of the batch, evaluated alone, recombine to
+    the batch's value and depth gradients (each term is a mean over pixels / valid pixels of its own), (b) two runs agree bit for
+    bit (fixed-point scatter), (c) the geometric term vanishes together with its gradient when the reference depth IS the
+    projected depth field of a fronto-parallel plane under the identity pose."""
+    from coivo_amd import functional as Fh
+    B, H, W = 32, 512, 640
+    d = dev()
+    b = synth.make_batch(8, H, W, seed=5, device=d)
+    rep = lambda t: t.repeat(B // 8, *([1] * (t.dim() - 1))).contiguous()
+    full = {k: rep(b[k]) for k in ("tgt", "ref", "K", "gt_depth", "gt_pose", "gt_a", "gt_b")}
+
+    def run(x, n):
+        dt = x["gt_depth"][:n].clone().requires_grad_(True)
+        dr = (x["gt_depth"][:n] * 1.05 + 0.02).clone().requires_grad_(True)
+        loss = Fh.dcdp_full_loss(x["tgt"][:n], x["ref"][:n], dt, dr, x["gt_pose"][:n], x["K"][:n], x["gt_a"][:n], x["gt_b"][:n])
+        terms = Fh.full_objective_terms(loss).clone()
+        g = torch.autograd.grad(loss, [dt, dr])
+        return loss, terms, g
+
+    l32, t32, g32 = run(full, 32)
+    l32b, _, g32b = run(full, 32)
+    assert torch.equal(l32, l32b) and all(torch.equal(x, y) for x, y in zip(g32, g32b))            # (b)
+    l8, t8, g8 = run(full, 8)
+    # (a): the batch is four copies of the 8-pair slice -> same value; per-pixel gradients are 1/4 of the slice's (the means run over
+    # four times as many pixels)
+    assert abs(l32.item() - l8.item()) < 2e-6
+    for x, y in zip(g32, g8):
+        scale = y.abs().max().item()
+        assert (x[:8] * 4.0 - y).abs().max().item() <= 2e-5 * scale
+        assert torch.equal(x[:8], x[8:16])
+    # (c)
+    plane = torch.full((4, 1, H, W), 2.5, device=d)
+    zero_pose = torch.zeros(4, 6, device=d)
+    dt = plane.clone().requires_grad_(True)
+    dr = plane.clone().requires_grad_(True)
+    loss = Fh.dcdp_full_loss(full["tgt"][:4], full["ref"][:4], dt, dr, zero_pose, full["K"][:4], full["gt_a"][:4], full["gt_b"][:4],
+                             smooth_weight=0.0, num_scales=1)
+    terms = Fh.full_objective_terms(loss)
+    assert float(terms[1]) == 0.0
+    ph = Fh.photometric_loss(full["tgt"][:4], full["ref"][:4], plane, zero_pose, full["K"][:4], full["gt_a"][:4], full["gt_b"][:4])
+    assert abs(loss.item() - ph.item()) < 1e-6
+    g_dr = torch.autograd.grad(loss, dr)[0]
+    assert float(g_dr.abs().max()) == 0.0
