@@ -100,8 +100,12 @@ class FusedAdam:
 
     def _pack_table(self):
         import numpy as np
-        key = tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), m.compute_dtype, id(m._pack_table)) for m in self.modules)
-        if self._pack_cache is not None and self._pack_cache[0] == key and all(m._pack_table is not None for m in self.modules):
+        def current_key():      # every address the table holds: a rebuilt arena / operand buffer / moment tensor invalidates it
+            return tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                          m.compute_dtype) + tuple(None if getattr(m, a, None) is None else getattr(m, a).data_ptr()
+                                                   for a in ("_op_bwd", "_op_fwd"))
+                         for m, st in zip(self.modules, self.state))
+        if self._pack_cache is not None and all(m._pack_table is not None for m in self.modules) and self._pack_cache[0] == current_key():
             return self._pack_cache[1]
         ent = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"),
                         ("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"), ("n", "<i8"),
@@ -119,8 +123,7 @@ class FusedAdam:
                 blk += (n + _lib.ADAM_PLAIN_PER_WG - 1) // _lib.ADAM_PLAIN_PER_WG
         tab = np.array(rows, dtype=ent)
         dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.modules[0].flat_param.device)
-        key = tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), m.compute_dtype, id(m._pack_table)) for m in self.modules)
-        self._pack_cache = (key, (dev_tab, len(rows), blk))
+        self._pack_cache = (current_key(), (dev_tab, len(rows), blk))
         return self._pack_cache[1]
 
     _pack_cache = None
