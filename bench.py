@@ -75,9 +75,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: all ranks share cuda:0 and talk over gloo (RCCL cannot place two ranks on one device)")
     ap.add_argument("--graph", choices=["auto", "on", "off", "best"], default="auto",
-                    help="replay the step from one captured hipGraph (coivo_amd/graph.py); best = capture it, time 20 eager and 20 "
-                         "replayed steps and run the timed region with the faster form (replay is level with eager on an idle host and "
-                         "immune to a busy one: the eager step needs ~0.9 ms of host time per 1.5 ms step); auto = the "
+                    help="replay the step from one captured hipGraph (coivo_amd/graph.py); best = time 20 eager steps and, only if the host is their "
+                         "limit (enqueue time above 95 %% of the step), capture the graph and replay it (the replay is 2-4 %% behind eager on "
+                         "an idle host and immune to a busy one: the eager step needs ~0.9 ms of host time per 1.5 ms step); auto = the "
                          "configuration's setting: on for configs[4], best on one GPU, off on several")
     ap.add_argument("--graph-policy", type=int, choices=[0, 1, 2, 3], default=2,
                     help="how the weight-gradient chain hangs off the main chain in the graph (include/colvo.h "
@@ -479,7 +479,8 @@ def main():
     if args.graph == "best" and not args.spec_calls:
         # Eager launches need the host to stay ahead of the GPU (~0.9 ms of enqueue work per 1.5 ms step at configs[1]); on a busy
         # host they do not, and the replayed graph -- level with eager otherwise, within 2 % -- is immune.  Decide from 20 eager
-        # steps: host-bound (enqueue time above 80 % of the step) -> capture and replay.  The decision must come BEFORE a
+        # steps: host-bound (enqueue time above 95 % of the step: the GPU waits for the host) -> capture and replay -- not earlier:
+        # at 82 % the eager step still ran at its 1.48 ms and the replay chosen by an 80 % rule cost 6 %.  The decision must come BEFORE a
         # capture: the streams a capture leaves behind push eager steps of the same process over the hardware-queue cliff
         # (measured 4.6 ms per eager step after a capture).
         for _ in range(3):
@@ -492,7 +493,7 @@ def main():
         torch.cuda.synchronize()
         t_eager = (time.perf_counter() - t_) / 20 * 1e3
         graph_trial = {"eager_ms": t_eager, "eager_host_enqueue_ms": t_host, "steps": 20, "chosen": "eager"}
-        if t_host > float(os.environ.get("COLVO_BENCH_GRAPH_THRESHOLD", "0.8")) * t_eager:     # (developer probe: 0 forces the replay)
+        if t_host > float(os.environ.get("COLVO_BENCH_GRAPH_THRESHOLD", "0.95")) * t_eager:     # (developer probe: 0 forces the replay)
             capture_graph()
             if graphed is not None:
                 graph_trial.update(replay_ms=timed_run(graphed, 20), chosen="replay")
