@@ -52,6 +52,24 @@ def main():
         torch.cuda.synchronize()
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
         pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+        # the backward bodies run in autograd's device thread, which the profile above does not see: profile them there
+        prb = cProfile.Profile()
+        for net in (dn, pn):
+            orig = net._backward_impl
+
+            def wrapped(*a, _orig=orig, **kw):
+                prb.enable()
+                try:
+                    return _orig(*a, **kw)
+                finally:
+                    prb.disable()
+            net._backward_impl = wrapped
+        t0 = time.perf_counter()
+        for _ in range(N):
+            step()
+        torch.cuda.synchronize()
+        print(f"backward bodies (autograd thread), {N} steps:")
+        pstats.Stats(prb).sort_stats("cumulative").print_stats(30)
 
 
 if __name__ == "__main__":
