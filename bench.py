@@ -8,7 +8,11 @@
 A "step" = one full training step on one batch of synthetic frame pairs already resident in HBM:
 DepthNet (both frames) + PoseNet forward, fused warp/LCC/SSIM/L1 loss, backward through everything,
 gradient all-reduce (N > 1), Adam.  N = 1 runs BASELINE configs[1]: batch 8, 320x256, bf16 conv / fp32 loss.
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the fused warp/loss op at BASELINE configs[2],
+where SURVEY.md section 8d reads the HBM roofline; `roofline_in_step`: the same op inside this run's steps) and `cpu_baseline`.
+Protocol (round 4): W warm-up steps, barrier + synchronize, EXACTLY K steps and nothing else, barrier + synchronize; then, outside
+the timed region: the same K steps started without draining (`ms_per_step_pipeline_full`), the three call-sequence forms
+interleaved A-B-C in blocks (`forms_interleaved`), the fused op bracketed inside 10 extra steps, the op alone at configs[2].
 """
 from __future__ import annotations
 
@@ -22,12 +26,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--rccl-single" in sys.argv:
     # Data parallel: the main stream, the weight-gradient side stream and RCCL's stream must not share a hardware queue.  With the
     # runtime's default of 4 queues the side stream landed on the main stream's queue once the communicator existed and the
     # backward pass serialised (1.96 ms per step against 1.68 with 8 queues, one rank through the RCCL path).  Read at HIP
-    # initialisation, so it has to be in the environment before torch is imported.
-    try:
-        if int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) < 8:
-            os.environ["GPU_MAX_HW_QUEUES"] = "8"
-    except ValueError:
-        os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    # initialisation, so it has to be in the environment before torch is imported.  A value the user exported is left alone
+    # (coivo_amd.streams warns about 3..7); the effective value is reported in the JSON line (`hw_queues`).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 
@@ -57,7 +58,13 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
-    ap.add_argument("--no-roofline-cfg2", action="store_true")
+    ap.add_argument("--no-roofline-cfg2", action="store_true",
+                    help="skip the fused-loss measurement at BASELINE configs[2] (then `roofline` falls back to the in-step figure)")
+    ap.add_argument("--no-side-measurements", action="store_true",
+                    help="skip everything outside the K timed steps (interleaved call-sequence forms, in-step fused-op brackets, "
+                         "scaling denominator): the process then runs warm-up + K steps only (tests compare final_loss bit for bit)")
+    ap.add_argument("--forms-block", type=int, default=10, help="steps per block of the interleaved A-B-C side measurement")
+    ap.add_argument("--forms-rounds", type=int, default=3, help="rounds of the interleaved A-B-C side measurement")
     ap.add_argument("--full-loss", action="store_true",
                     help="train on the widened objective (SURVEY.md 8f-1/2: 3-scale photometric + geometric consistency + "
                          "smoothness) instead of BASELINE's plain DCDP+LCC step; reported as such in config.workload")
@@ -498,10 +505,11 @@ def main():
             if graphed is not None:
                 graph_trial.update(replay_ms=timed_run(graphed, 20), chosen="replay")
     use_graph = graphed is not None
-    for _ in range(args.warmup):
-        step(False)
-    if not use_graph:
-        Fh.enable_timing(rank == 0)     # HIP events around the fused-op launches inside the timed steps
+    first_loss = None
+    for i in range(args.warmup):
+        l_ = step(False)
+        if i == 0:
+            first_loss = l_                       # read after the timed region (no host synchronisation inside the warm-up)
     barrier()
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     # a cyclic-GC pass of the interpreter inside the K steps is a multi-millisecond host stall that has nothing to do with the
@@ -510,6 +518,11 @@ def main():
     gc.collect()
     gc.disable()
     t0 = time.perf_counter()
+    # The headline: EXACTLY K steps between barrier + synchronize on both sides (the task's contract), nothing else inside -- the
+    # hip-event brackets around the fused op that rounds 1-3 kept in these steps (two event records per call, ~10 us per step) are
+    # gone; the op is timed in a side measurement below.  The region starts on a DRAINED GPU (the contract's synchronize): the
+    # first step's kernels wait for the host's first enqueues (~0.5 ms of a 20-step run); `ms_per_step_pipeline_full` below is the
+    # same loop started without draining.
     # developer probes (tools/README.md): COLVO_BENCH_HOST_SPIN_US burns host time in every step (does the step time move? then
     # the host is the limit), COLVO_BENCH_HOST_LEAD prints how far the host ran ahead of the GPU (host enqueue time per step)
     spin_us = float(os.environ.get("COLVO_BENCH_HOST_SPIN_US", "0"))
@@ -536,22 +549,44 @@ def main():
     if os.environ.get("COLVO_BENCH_DUMP_STEPS") and rank == 0:
         print("step ms:", " ".join(f"{v:.2f}" for v in ev_raw), file=sys.stderr)
     ev_ms = sorted(ev_raw)
-    if use_graph:
-        # kernels inside a replayed graph cannot be bracketed by events: time the fused op in the same process
-        # with the same step launched eagerly right after the timed region (not part of `value`)
-        Fh.enable_timing(rank == 0)
-        for _ in range(10):
-            step(True)
-        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+    first_loss = first_loss.item() if first_loss is not None else final_loss
+
+    def event_medians(plan):
+        """plan: [(tag, fn, n)] run back to back WITHOUT draining in between, one hip event per step boundary -> {tag: sorted ms}."""
+        evs, tags = [torch.cuda.Event(enable_timing=True)], []
+        evs[0].record()
+        for tag, fn, n in plan:
+            for _ in range(n):
+                fn()
+                e_ = torch.cuda.Event(enable_timing=True)
+                e_.record()
+                evs.append(e_)
+                tags.append(tag)
+        torch.cuda.synchronize()
+        out_ = {}
+        for i_, tag in enumerate(tags):
+            out_.setdefault(tag, []).append(evs[i_].elapsed_time(evs[i_ + 1]))
+        return {k: sorted(v) for k, v in out_.items()}
+
+    med = lambda v: v[len(v) // 2]
+    main_fn = graphed if use_graph else eager_step
+    pipeline_full = None
+    if not args.no_side_measurements:
+        # the same K steps behind 3 lead-in steps, the start event recorded WITHOUT draining the GPU in front of it (VERDICT r3
+        # item 5): what a training loop sees per step once it runs
+        gc.collect(); gc.disable()
+        m_ = event_medians([("lead", main_fn, 3), ("timed", main_fn, args.steps)])
+        gc.enable()
+        pipeline_full = sum(m_["timed"]) / len(m_["timed"])
 
     # ---- side measurements, outside the timed region (every rank runs them: no rank idles at a collective) ----
     side = {}
-    if ddp is not None and not use_graph:
+    if ddp is not None and not use_graph and not args.no_side_measurements:
         # SURVEY.md section 8d: scaling = fps(N GPUs, b pairs each) / fps(1 GPU, b pairs).  The denominator, measured here on
         # this rank's GPU: the same step at the same per-GPU batch with the gradient exchange detached.
         ddp.pause()          # hooks off, but the communicator's hardware queue stays claimed (coivo_amd/streams.py)
@@ -561,38 +596,70 @@ def main():
                                          "what": "the same step on ONE GPU at the same per-GPU batch without the gradient "
                                                  "exchange (rank 0's GPU, 20 steps): the denominator of the scaling ratio"}
         opt.grad_scale = scale_was
-    if world == 1 and not args.full_loss and not use_graph:
-        other = fast_step if args.spec_calls else spec_step
-        ms2 = timed_run(other, min(args.steps, 20))
-        side["spec_sequence_ms" if not args.spec_calls else "fast_path_ms"] = ms2
-        ms3 = timed_run(lambda: fast_step(True), min(args.steps, 20))
-        side["full_objective"] = {"ms_per_step": ms3, "value": B / (ms3 * 1e-3),
+        ddp.resume()
+    if world == 1 and not use_graph and not args.no_side_measurements and ddp is None:
+        # The three forms of the step -- fast path (forward_pair_split + gradient handover), the spec's verbatim call sequence, the
+        # widened objective -- INTERLEAVED A-B-C-A-B-C in blocks after a common warm-up, hip-event medians per form: their order is
+        # then measurable inside one short driver run (measured one after the other, 20 steps each, the record
+        # showed them in the opposite order of DESIGN.md's claim).
+        forms = [("fast", lambda: fast_step(False)), ("spec", spec_step), ("full", lambda: fast_step(True))]
+        for _, fn in forms:
+            for _ in range(3):
+                fn()
+        gc.collect(); gc.disable()
+        # (the first step of a block runs behind another form's tail: it gets a tag of its own and stays out of the medians)
+        plan = [(t_, fn, n_) for _ in range(args.forms_rounds) for tag, fn in forms
+                for t_, n_ in ((tag + "_first", 1), (tag, max(1, args.forms_block - 1)))]
+        m_ = event_medians(plan)
+        gc.enable()
+        side["forms_interleaved"] = {
+            "block": args.forms_block, "rounds": args.forms_rounds,
+            "fast_path_ms": med(m_["fast"]), "spec_sequence_ms": med(m_["spec"]), "full_objective_ms": med(m_["full"]),
+            "what": "hip-event medians per step of the three forms run A-B-C-A-B-C in blocks without draining in between: fast path "
+                    "(the timed form unless --spec-calls / --full-loss), the spec's call sequence (depth_net(cat), slices, "
+                    "photometric_loss on ordinary tensors, plain backward), the widened objective (3-scale photometric + geometric "
+                    "consistency + smoothness)"}
+        side["spec_sequence_ms"] = side["forms_interleaved"]["spec_sequence_ms"]
+        side["full_objective"] = {"ms_per_step": side["forms_interleaved"]["full_objective_ms"],
+                                  "value": B / (side["forms_interleaved"]["full_objective_ms"] * 1e-3),
                                   "what": "the same step with the widened objective (multi-scale photometric + geometric "
                                           "consistency + smoothness, SURVEY.md section 8f-1/8f-2; bench.py --full-loss times it "
-                                          "as the main measurement)"}
+                                          "as the main measurement); from forms_interleaved"}
+    if rank == 0 and not args.no_side_measurements:
+        # the fused op inside the step: hip-event brackets around its C-ABI calls in 10 EXTRA eager steps (never in the headline's)
+        Fh.enable_timing(True)
+        for _ in range(10):
+            eager_step()
+        torch.cuda.synchronize()
+    elif not args.no_side_measurements:
+        for _ in range(10):
+            eager_step()
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        ev = Fh.timing_events()
-        f_us = [e0.elapsed_time(e1) for e0, e1 in ev["fwd"]]
-        b_us = [e0.elapsed_time(e1) for e0, e1 in ev["bwd"]]
-        Fh.enable_timing(False)
-        # --full-loss: ONE forward call per step runs the whole widened objective (smoothness + pyramid, the one-pass kernel over the
-        # three levels with the geometric term inside level 0, finalize) and one backward call the combine kernel; the byte model
-        # is the photometric one, sum_s 60 * px / 4^s -- the other terms' bytes are not credited
-        per = 1
-        f_ms, b_ms = sum(f_us) / len(f_us) * per, sum(b_us) / len(b_us) * per
-        px = B * H * W * (1.0 + 0.25 + 0.0625 if args.full_loss else 1.0)
-        # plain step: the backward call launches nothing (gradient handover), so the op's duration is the forward call's;
-        # --full-loss: the general path's scaling kernels run in the backward calls and count
-        ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + (b_ms if args.full_loss else 0.0)) * 1e-3) / 1e9
-        roof = {"kernel": ("k_full_prepare + k_warp_loss_march_levels<geo> + k_full_finalize, backward k_full_combine (the widened "
+        roof_in_step = None
+        if not args.no_side_measurements:
+            ev = Fh.timing_events()
+            f_us = [e0.elapsed_time(e1) for e0, e1 in ev["fwd"]]
+            b_us = [e0.elapsed_time(e1) for e0, e1 in ev["bwd"]]
+            Fh.enable_timing(False)
+            # --full-loss: ONE forward call per step runs the whole widened objective (smoothness + pyramid, the one-pass kernel over the
+            # three levels with the geometric term inside level 0, finalize) and one backward call the combine kernel; the byte model
+            # is the photometric one, sum_s 60 * px / 4^s -- the other terms' bytes are not credited
+            f_ms, b_ms = sum(f_us) / len(f_us), sum(b_us) / len(b_us)
+            px = B * H * W * (1.0 + 0.25 + 0.0625 if args.full_loss else 1.0)
+            # plain step: the backward call launches nothing (gradient handover), so the op's duration is the forward call's;
+            # --full-loss: the general path's scaling kernels run in the backward calls and count
+            ach = LOSS_BYTES_PER_PIXEL * px / ((f_ms + (b_ms if args.full_loss else 0.0)) * 1e-3) / 1e9
+            roof_in_step = {
+                "kernel": ("k_full_prepare + k_warp_loss_march_levels<geo> + k_full_finalize, backward k_full_combine (the widened "
                            "objective: every term's value and gradients)" if args.full_loss else
                            "k_warp_loss_bwd_march<fused> + k_warp_loss_fused_finalize (project/sample/LCC/SSIM/L1: loss and all "
                            "gradients in one pass)"),
+                "workload": f"B={B} {W}x{H} fp32, inside the training step",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 # the committed PMC summary holds the two BASELINE shapes; any other invocation (or --full-loss) has none
                 "traffic": (None if args.full_loss else
@@ -603,12 +670,16 @@ def main():
                 "achieved_real_bytes": ach * LOSS_REAL_BYTES_PER_PIXEL / LOSS_BYTES_PER_PIXEL,
                 "frac_real_bytes": ach * LOSS_REAL_BYTES_PER_PIXEL / LOSS_BYTES_PER_PIXEL / HBM_PEAK_GBS,
                 "fwd_us": f_ms * 1e3, "bwd_us": b_ms * 1e3,
-                "timing": "hip events on the launch stream directly around the fused op's C-ABI calls inside the timed "
-                          "steps (forward call = one-pass loss + unnormalised gradients + finalize; the backward call launches nothing -- the gradients are normalised by the depth / pose head backward kernels -- so bwd_us is the cost of two event records and is not part of `achieved`), mean over steps; latency-dominated at this size "
-                          "(SURVEY.md §8d) -- the roofline is read at configs[2], see roofline_cfg2"}
+                "timing": "hip events on the launch stream directly around the fused op's C-ABI calls in 10 EXTRA eager steps after the "
+                          "timed region (never inside the headline's K steps); forward call = one-pass loss + unnormalised gradients + "
+                          "finalize; the backward call launches nothing -- the gradients are normalised by the depth / pose head "
+                          "backward kernels -- so bwd_us is the cost of two event records and is not part of `achieved`; mean over "
+                          "steps; latency-dominated at this size (SURVEY.md section 8d: the roofline is read at configs[2] = `roofline`)"}
+        from coivo_amd import streams as _streams
         out = {"metric": "training frame-pairs/sec at 320x256", "value": value, "unit": "frame-pairs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "ms_per_step_hipevent_median": ev_ms[len(ev_ms) // 2], "ms_per_step_hipevent_max": ev_ms[-1],
+               "ms_per_step_pipeline_full": pipeline_full,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
                "config": {"workload": workload_name(args, B, H, W),
@@ -618,15 +689,34 @@ def main():
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},
-               "final_loss": final_loss, "deterministic_weight_gradients": bool(dn.deterministic and pn.deterministic),
+               "timing": "value / ms_per_step: wall clock around EXACTLY `steps` steps between barrier + torch.cuda.synchronize() on both "
+                         "sides, max over ranks; nothing but the steps runs in between (no event brackets around the fused op).  The "
+                         "region starts on a drained GPU, as the contract's synchronize leaves it: ms_per_step_pipeline_full is the "
+                         "mean per step (hip events) of the same number of steps behind 3 lead-in steps with the start event recorded "
+                         "WITHOUT draining -- the per-step time of a running loop; ms_per_step_hipevent_median: median over the timed "
+                         "region's per-step hip events",
+               "first_loss": first_loss, "final_loss": final_loss,
+               "deterministic_weight_gradients": bool(dn.deterministic and pn.deterministic),
                "hipgraph": use_graph, "hipgraph_trial": graph_trial, "hipgraph_error": graph_error,
-               "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group} if use_graph else None),
-               "roofline": roof}
+               "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group, "carry": bool(graphed.carry),
+                                    "graph": graphed.stats} if use_graph else None),
+               # what the stream policy saw in this process (a first multi-GPU SCALE record should explain itself: DESIGN.md
+               # section 5): the runtime's hardware-queue limit as exported before HIP initialised, queues claimed by parties other
+               # than the step's main + weight-gradient stream (RCCL's communicator stream, a loader's copy stream), and how many
+               # library-owned auxiliary side streams colvo_run_commands may use as a consequence
+               "hw_queues": {"GPU_MAX_HW_QUEUES": _streams.hw_queue_limit(), "external_claims": _streams.external_queues(),
+                             "aux_side_streams": _streams.aux_side_streams(), "folded": _streams.folded(),
+                             "rccl_env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))}}}
         out.update(side)
         if not args.spec_calls and "spec_sequence_ms" in side:
             out["spec_sequence_value"] = world * B / (side["spec_sequence_ms"] * 1e-3)
+        # `roofline` is the figure SURVEY.md section 8d prescribes: the fused op alone at BASELINE configs[2] (B=32, 640x512), where it
+        # is bandwidth- and not latency-dominated.  The same op inside this run's steps: roofline_in_step.
         if not args.no_roofline_cfg2:
-            out["roofline_cfg2"] = roofline_cfg2(dev)
+            out["roofline"] = roofline_cfg2(dev)
+            out["roofline_in_step"] = roof_in_step
+        else:
+            out["roofline"] = roof_in_step
         fl = conv_flops_per_step(B, H, W)
         peak = 2500.0 if args.dtype == "bf16" else 157.3
         out["mfma_step"] = {"what": "conv flops of the whole step (fwd + dgrad + wgrad, both networks) / step time: a lower "

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -99,6 +99,10 @@ SIGNATURES = {
     "colvo_run_commands": (_i, [_vp, _i, _vp, _vp]),
     "colvo_set_aux_side_streams": (_i, [_i]),
     "colvo_set_capture_policy": (_i, [_i, _i]),
+    "colvo_set_capture_carry": (_i, [_i]),
+    "colvo_capture_join": (_i, [_vp]),
+    "colvo_graph_stats": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
+    "colvo_graph_stats_reset": (_i, []),
     "colvo_tune_set": (_i, [C.c_char_p, C.c_double]),
     "colvo_tune_get": (_i, [C.c_char_p, C.POINTER(C.c_double)]),
 }

@@ -41,6 +41,16 @@ constexpr int BM = 128;   // output pixels per workgroup (4 waves x 2 fragments 
 constexpr int pitch_slots(int n) { return n + ((2 - n % 4) + 4) % 4; }
 constexpr int pitch_bytes(int payload) { return pitch_slots(payload / 16) * 16; }
 constexpr int wrow_bytes(int granules) { return pitch_slots(granules) * 16; }
+// Pixel pitch where consecutive fragment rows are TWO patch pixels apart (stride-2 forward / weight-gradient patches, the dy patch
+// of k_dgrad_up2): the 8 rows of a ds_read_b128 half group then sit at {2 r l mod 16}, distinct even slots iff r is ODD -- with the
+// r = 6 of pitch_bytes(64) every such read took two passes (profiles/r3_conv_pmc.json: 35-44 % of the LDS-active cycles of exactly
+// these kernels were bank conflicts).  The transposed 8-byte reads of the weight gradient (two 32-lane groups, 8 pixels x 32 bytes
+// each) need 2 x pitch = an odd multiple of 32 bytes: the same condition.  64-byte payload -> 80, 32 -> 48, 16 -> 16.
+constexpr int pitch_bytes_s2(int payload) { return ((payload / 16) | 1) * 16; }
+// LDS row pitch (in pixels, >= pw) of a weight-gradient patch such that the LDS pixel index of tile pixel p = oy * tow + ox is
+// congruent to p modulo 8: a read group's 8 CONSECUTIVE tile pixels then keep their conflict-free spacing across a tile-row
+// boundary as well (tiles whose width is not a multiple of 8: the 16x20, 8x10, 4x5 ... maps).  Multiples of 8 need no padding.
+inline int wgrad_row_pitch(int pw, int tow) { return (tow % 8 == 0) ? pw : pw + (((tow - pw) % 8) + 8) % 8; }
 
 enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
 
@@ -102,6 +112,7 @@ struct WgradK {
     int toh, tow, tiles_x, tiles_y, ntiles, tiles_per_split;
     uint32_t m_pw, m_tow;     // see ConvK
     int nsplit, cot, xcd;     // 1-D grid: (co tile, chunk) fastest, pixel-range split slowest; XCD remap on/off
+    int pwl;                  // LDS pitch of a patch row, in pixels (wgrad_row_pitch)
     // Deterministic form (colvo_conv_wgrad_det): every pixel-range split STORES its sums into a slab of its own instead of
     // adding them to dw / db with float atomics; k_wgrad_reduce then adds the slabs in split order.  null: atomics.
     float* slabs;             // [nsplit][Cout * 9 * Ctot]
@@ -110,6 +121,9 @@ struct WgradK {
     const char* scratch;
     long long scratch_bytes;
     int* plan_out;            // non-null: write the number of splits the launch WOULD use and do not launch
+#ifdef COLVO_WTRACE
+    long long* trace;         // developer build only (tools/wtrace_wgrad.sh): [workgroup][8] shader-clock stamps of the kernel phases
+#endif
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (private L2s): give each XCD a CONTIGUOUS range of the logical work ids,
@@ -217,9 +231,10 @@ __device__ __forceinline__ void st16(char* p, u32x4 v) { *reinterpret_cast<u32x4
 struct Tile { int toh, tow, pwp; };   // pwp: LDS pitch of a patch row in pixels (>= patch width; 0: not chosen, use the width)
 
 // LDS cycles of the patch-fragment ds_read_b128 of the conv kernels, relative to conflict-free (1.0 ... 4.0): lane (l15, kg)
-// of wave w, fragment mf reads 16 bytes at ((oy*S)*pwp + ox*S)*96 + kg*16 with (oy, ox) = divmod(w*32 + mf*16 + l15, tow).
+// of wave w, fragment mf reads 16 bytes at ((oy*S)*pwp + ox*S)*16r + kg*16 with (oy, ox) = divmod(w*32 + mf*16 + l15, tow)
+// (r = 6: pitch_bytes(64); r = 5 where S = 2: pitch_bytes_s2(64)).
 // The instruction is serviced in the four 16-lane groups below, 64 banks of 4 bytes (MI355X_MICROARCH.md, LDS).
-inline double patch_read_conflicts(int toh, int tow, int pwp, int S) {
+inline double patch_read_conflicts(int toh, int tow, int pwp, int S, int r = 6) {
     static const int grp[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
@@ -235,7 +250,7 @@ inline double patch_read_conflicts(int toh, int tow, int pwp, int S) {
                     int p = w * 32 + mf * 16 + l15;
                     if (p >= npix) p = 0;
                     const int oy = p / tow, ox = p - oy * tow;
-                    slot_of[j] = ((oy * S) * pwp + ox * S) * 6 + kg;
+                    slot_of[j] = ((oy * S) * pwp + ox * S) * r + kg;      // r: 16-byte slots per patch pixel
                 }
                 int worst = 1;                              // distinct addresses on one bank set serialise; equal ones broadcast
                 for (int r = 0; r < 16; ++r) {
@@ -290,7 +305,7 @@ inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool 
             continue;
         }
         for (int pad = 0; pad <= max_pad; ++pad) {
-            const double cf = patch_read_conflicts(toh, tow, pw + pad, stride);
+            const double cf = patch_read_conflicts(toh, tow, pw + pad, stride, stride == 2 ? 5 : 6);
             const double cost = base * (1.0 + 0.2 * (cf - 1.0)) * (1.0 + 0.002 * pad);
             if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow, pw + pad}; }
         }

@@ -143,20 +143,22 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
 //                       the weight gradients of one segment run beside the input-gradient chain that follows it;
 //   policy 3:           policy 2 with the segments alternating between TWO side chains (the eager schedule's auxiliary stream).
 // (ROCm 7.2 replays a graph's branches on streams of its own; every cross-branch edge costs a marker with a signal -- the
-// two-stream capture of round 2, one edge per layer, replayed 2.4 x slower than eager.)  Each call ends joined: the next captured
-// node depends on both chains.  Commands are re-ordered only within what the eager schedule already allows: a side command never
+// two-stream capture of round 2, one edge per layer, replayed 2.4 x slower than eager.)  Each call ends joined (the next captured
+// node depends on both chains) unless carry mode is on (colvo_set_capture_carry: the side chain stays open from call to call, as
+// the eager schedule's deferred join leaves the side stream running, until colvo_capture_join).  Commands are re-ordered only within what the eager schedule already allows: a side command never
 // runs before the main-chain node it was forked from, nothing but the join depends on it, and every buffer it reads is private to
 // its recorded pass (coivo_amd/program.py keeps them alive for the life of the program).
 static std::atomic<int> g_capture_policy{2};
 static std::atomic<int> g_capture_group{2};
+static std::atomic<int> g_capture_carry{0};
 
 struct CaptureTail {
     std::vector<hipGraphNode_t> nodes;
-    int get(hipStream_t s) {
+    int get(hipStream_t s, unsigned long long* id = nullptr, hipGraph_t* graph = nullptr) {
         hipStreamCaptureStatus st;
         const hipGraphNode_t* deps = nullptr;
         size_t n = 0;
-        hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, nullptr, nullptr, &deps, &n);
+        hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, id, graph, &deps, &n);
         if (e != hipSuccess || st != hipStreamCaptureStatusActive) {
             set_error("colvo_run_commands: hipStreamGetCaptureInfo_v2 failed under capture: %s", hipGetErrorString(e));
             return e != hipSuccess ? (int)e : (int)hipErrorIllegalState;
@@ -175,69 +177,111 @@ struct CaptureTail {
     }
 };
 
+// What one capture keeps between colvo_run_commands calls (carry mode, colvo_set_capture_carry): the open side chain(s), the side
+// commands not yet turned into nodes -- COPIES: the caller may patch or free its list between calls -- and the fork point of
+// policy 1.  Keyed by the capture's id: a new capture starts empty whatever an aborted one left behind.  One capture at a time per
+// process (the step is captured by one thread); the mutex only keeps a stray concurrent call from corrupting the vectors.
+struct CaptureState {
+    unsigned long long id = 0;
+    CaptureTail sides[2], fork_at;
+    int seg = 0;
+    std::vector<ColvoCmd> pending;
+    // statistics of what was built since colvo_graph_stats_reset (colvo_graph_stats)
+    long long calls = 0, main_nodes = 0, side_nodes = 0, segments = 0, joins = 0, carried = 0, max_entry_deps = 0;
+};
+static CaptureState g_cap;
+static std::mutex g_cap_mu;
+
+// Capture the pending side commands as one segment of the side chain: it depends on `at` (a point of the main chain) and on the
+// previous segment.  ORDER MATTERS: ROCm's graph executor keeps a node's FIRST child on the node's stream and opens a new
+// stream for every further child, so a segment is captured AFTER the main command that follows its fork point -- the main
+// chain then stays on one stream and the side chain (each segment the first child of the previous one) on a second.  Captured
+// the other way round every fork moved the main chain to a fresh stream: four or more hardware queues, the serialised
+// mode of DESIGN.md section 3.4 (profiles/r3_graph_replay.md).
+static int capture_flush(CaptureState& st, const CaptureTail& at, int nchains, hipStream_t ms) {
+    if (st.pending.empty()) return 0;
+    CaptureTail cur;
+    if (int rc = cur.get(ms)) return rc;                    // the main chain as far as it has been captured
+    CaptureTail& side = st.sides[st.seg++ % nchains];
+    CaptureTail deps = at;
+    deps.merge(side);
+    if (int rc = deps.set(ms)) return rc;
+    for (size_t k = 0; k < st.pending.size(); ++k)
+        if (int rc = run_one(st.pending[k], (int)k, (colvo_stream_t)ms)) return rc;
+    st.side_nodes += (long long)st.pending.size();
+    st.segments += 1;
+    st.pending.clear();
+    if (int rc = side.get(ms)) return rc;
+    return cur.set(ms);                                     // back on the main chain
+}
+
+// the next captured node depends on the main chain AND on every open side chain
+static int capture_join_all(CaptureState& st, int policy, int nchains, hipStream_t ms) {
+    if (policy == 0) return 0;
+    if (!st.pending.empty()) {
+        if (policy >= 2 || st.fork_at.nodes.empty()) { if (int rc = st.fork_at.get(ms)) return rc; }
+        if (int rc = capture_flush(st, st.fork_at, nchains, ms)) return rc;
+    }
+    if (!st.sides[0].nodes.empty() || !st.sides[1].nodes.empty()) {
+        CaptureTail cur;
+        if (int rc = cur.get(ms)) return rc;
+        for (CaptureTail& sd : st.sides) { cur.merge(sd); sd.nodes.clear(); }
+        if (int rc = cur.set(ms)) return rc;
+        st.joins += 1;
+    }
+    return 0;
+}
+
 static int run_commands_captured(const ColvoCmd* cmds, int n, hipStream_t ms) {
     const int policy = g_capture_policy.load(std::memory_order_relaxed);
     const int group = std::max(1, g_capture_group.load(std::memory_order_relaxed));
+    const bool carry = g_capture_carry.load(std::memory_order_relaxed) != 0 && policy != 0;
     const int nchains = policy == 3 ? 2 : 1;   // policy 3 = policy 2 with the segments alternating between TWO side chains
-    CaptureTail sides[2], fork_at, cur;
-    int seg = 0;
-    std::vector<int> pending;               // side commands not yet captured
-    // Capture the pending side commands as one segment of the side chain: it depends on `at` (a point of the main chain) and on the
-    // previous segment.  ORDER MATTERS: ROCm's graph executor keeps a node's FIRST child on the node's stream and opens a new
-    // stream for every further child, so a segment is captured AFTER the main command that follows its fork point -- the main
-    // chain then stays on one stream and the side chain (each segment the first child of the previous one) on a second.  Captured
-    // the other way round every fork moved the main chain to a fresh stream: four or more hardware queues, the serialised
-    // mode of DESIGN.md section 3.4 (profiles/r3_graph_replay.md).
-    auto flush = [&](const CaptureTail& at) -> int {
-        if (pending.empty()) return 0;
-        if (int rc = cur.get(ms)) return rc;                    // the main chain as far as it has been captured
-        CaptureTail& side = sides[seg++ % nchains];
-        CaptureTail deps = at;
-        deps.merge(side);
-        if (int rc = deps.set(ms)) return rc;
-        for (int k : pending)
-            if (int rc = run_one(cmds[k], k, (colvo_stream_t)ms)) return rc;
-        pending.clear();
-        if (int rc = side.get(ms)) return rc;
-        return cur.set(ms);                                     // back on the main chain
-    };
+    std::lock_guard<std::mutex> lock(g_cap_mu);
+    CaptureState& st = g_cap;
+    {
+        unsigned long long id = 0;
+        CaptureTail entry;
+        if (int rc = entry.get(ms, &id)) return rc;
+        if (id != st.id) {                      // a new capture: nothing is carried over from an earlier (ended or aborted) one
+            st.id = id; st.seg = 0; st.pending.clear(); st.fork_at.nodes.clear();
+            for (CaptureTail& sd : st.sides) sd.nodes.clear();
+        }
+        st.calls += 1;
+        st.max_entry_deps = std::max(st.max_entry_deps, (long long)entry.nodes.size());
+        if (!st.pending.empty()) st.carried += 1;
+    }
+    // commands carried over from the previous call are due at this call's first main command whatever the group size: they have
+    // waited for a main node to exist behind their fork point, nothing else
+    bool carried_due = !st.pending.empty();
     for (int k = 0; k < n; ++k) {
         const ColvoCmd& c = cmds[k];
         if (c.op == COLVO_CMD_FORK) {
             // policy 1: the side commands that follow depend on the main chain as it stands NOW (consecutive forks without a
             // main command in between share the point)
-            if (policy == 1 && pending.empty()) { if (int rc = fork_at.get(ms)) return rc; }
+            if (policy == 1 && st.pending.empty()) { if (int rc = st.fork_at.get(ms)) return rc; }
             continue;
         }
         if (c.op == COLVO_CMD_JOIN) {
-            if (policy == 0) continue;
-            if (policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }
-            if (int rc = flush(fork_at)) return rc;
-            if (int rc = cur.get(ms)) return rc;
-            for (CaptureTail& sd : sides) { cur.merge(sd); sd.nodes.clear(); }
-            if (int rc = cur.set(ms)) return rc;
+            if (int rc = capture_join_all(st, policy, nchains, ms)) return rc;
             continue;
         }
         if (c.stream == 1 && policy != 0) {
-            pending.push_back(k);
+            st.pending.push_back(c);
             continue;
         }
-        const bool due = !pending.empty() && (policy == 1 || (int)pending.size() >= group);
-        if (due && policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }   // every pending command's inputs exist by now
-        if (int rc = run_one(c, k, (colvo_stream_t)ms)) return rc;             // first child of the fork point: stays on its stream
-        if (due) { if (int rc = flush(fork_at)) return rc; }
+        const bool due = !st.pending.empty() && (policy == 1 || (int)st.pending.size() >= group || carried_due);
+        carried_due = false;
+        if (due && policy >= 2) { if (int rc = st.fork_at.get(ms)) return rc; }   // every pending command's inputs exist by now
+        if (int rc = run_one(c, k, (colvo_stream_t)ms)) return rc;                // first child of the fork point: stays on its stream
+        st.main_nodes += 1;
+        if (due) { if (int rc = capture_flush(st, st.fork_at, nchains, ms)) return rc; }
     }
-    if (policy != 0) {                      // the call ends joined
-        if (!pending.empty()) {
-            if (policy >= 2) { if (int rc = fork_at.get(ms)) return rc; }
-            if (int rc = flush(fork_at)) return rc;
-        }
-        if (!sides[0].nodes.empty() || !sides[1].nodes.empty()) {
-            if (int rc = cur.get(ms)) return rc;
-            for (CaptureTail& sd : sides) cur.merge(sd);
-            if (int rc = cur.set(ms)) return rc;
-        }
-    }
+    // Carry mode: the side chain stays open and the commands still pending are held back until the NEXT call has captured its first
+    // main command (or colvo_capture_join is called) -- created now, while the main chain has no successor yet, the segment would
+    // become the first child of the main chain's last node and the next call's main nodes would open a new stream
+    // (profiles/r3_graph_replay.md section 3: 1.52 -> 1.93 ms).  Otherwise the call ends joined.
+    if (!carry) return capture_join_all(st, policy, nchains, ms);
     return 0;
 }
 
@@ -245,6 +289,74 @@ extern "C" int colvo_set_capture_policy(int policy, int group) {
     COLVO_CHECK_ARG(policy >= 0 && policy <= 3 && group >= 1, "colvo_set_capture_policy: policy 0..3, group >= 1");
     g_capture_policy.store(policy, std::memory_order_relaxed);
     g_capture_group.store(group, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int colvo_set_capture_carry(int on) {
+    g_capture_carry.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
+extern "C" int colvo_capture_join(colvo_stream_t stream) {
+    hipStream_t ms = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ms, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) return 0;   // eager: the host joins streams
+    std::lock_guard<std::mutex> lock(g_cap_mu);
+    CaptureState& st = g_cap;
+    unsigned long long id = 0;
+    CaptureTail entry;
+    if (int rc = entry.get(ms, &id)) return rc;
+    if (id != st.id) return 0;                  // nothing of this capture is open
+    const int policy = g_capture_policy.load(std::memory_order_relaxed);
+    return capture_join_all(st, policy, policy == 3 ? 2 : 1, ms);
+}
+
+extern "C" int colvo_graph_stats_reset(void) {
+    std::lock_guard<std::mutex> lock(g_cap_mu);
+    g_cap.calls = g_cap.main_nodes = g_cap.side_nodes = g_cap.segments = g_cap.joins = g_cap.carried = g_cap.max_entry_deps = 0;
+    return 0;
+}
+
+extern "C" int colvo_graph_stats(colvo_stream_t stream, long long* out, int n) {
+    COLVO_CHECK_ARG(out && n >= COLVO_GRAPH_STATS_N, "colvo_graph_stats: out must hold COLVO_GRAPH_STATS_N values");
+    for (int i = 0; i < n; ++i) out[i] = -1;
+    {
+        std::lock_guard<std::mutex> lock(g_cap_mu);
+        out[8] = g_cap.calls; out[9] = g_cap.main_nodes; out[10] = g_cap.side_nodes; out[11] = g_cap.segments;
+        out[12] = g_cap.joins; out[13] = g_cap.carried; out[14] = g_cap.max_entry_deps;
+        out[15] = (long long)g_cap.pending.size();
+    }
+    hipStream_t ms = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (!ms || hipStreamIsCapturing(ms, &cap) != hipSuccess || cap == hipStreamCaptureStatusNone) return 0;
+    // the graph under construction on `stream`: node / edge / root counts and its fork / join structure
+    hipGraph_t graph = nullptr;
+    CaptureTail tail;
+    if (int rc = tail.get(ms, nullptr, &graph)) return rc;
+    size_t nn = 0, ne = 0, nr = 0;
+    hipError_t e = hipGraphGetNodes(graph, nullptr, &nn);
+    if (e == hipSuccess) e = hipGraphGetRootNodes(graph, nullptr, &nr);
+    if (e == hipSuccess) e = hipGraphGetEdges(graph, nullptr, nullptr, &ne);
+    if (e != hipSuccess) { set_error("colvo_graph_stats: %s", hipGetErrorString(e)); return (int)e; }
+    std::vector<hipGraphNode_t> from(ne), to(ne), nodes(nn);
+    if (ne) e = hipGraphGetEdges(graph, from.data(), to.data(), &ne);
+    if (e == hipSuccess && nn) e = hipGraphGetNodes(graph, nodes.data(), &nn);
+    if (e != hipSuccess) { set_error("colvo_graph_stats: %s", hipGetErrorString(e)); return (int)e; }
+    std::sort(nodes.begin(), nodes.end());
+    std::vector<int> outdeg(nn, 0), indeg(nn, 0);
+    for (size_t i = 0; i < ne; ++i) {
+        const size_t a = std::lower_bound(nodes.begin(), nodes.end(), from[i]) - nodes.begin();
+        const size_t b = std::lower_bound(nodes.begin(), nodes.end(), to[i]) - nodes.begin();
+        if (a < nn) ++outdeg[a];
+        if (b < nn) ++indeg[b];
+    }
+    long long forks = 0, joins = 0, max_out = 0, max_in = 0, leaves = 0;
+    for (size_t i = 0; i < nn; ++i) {
+        forks += outdeg[i] >= 2; joins += indeg[i] >= 2; leaves += outdeg[i] == 0;
+        max_out = std::max(max_out, (long long)outdeg[i]); max_in = std::max(max_in, (long long)indeg[i]);
+    }
+    out[0] = (long long)nn; out[1] = (long long)ne; out[2] = (long long)nr; out[3] = leaves;
+    out[4] = forks; out[5] = joins; out[6] = max_out; out[7] = max_in;
     return 0;
 }
 

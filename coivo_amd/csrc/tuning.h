@@ -11,8 +11,9 @@
 // at 64 / 128 images of 256x320 (the per-GPU shapes of configs[3] / [4]) and at 64 images of 512x640 (configs[2]):
 // profiles/r3_tuning_check.md.
 #pragma once
-#include <string.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace colvo {
 namespace tune {

@@ -493,10 +493,15 @@ struct BwdState {
 // taps is scattered into `dr_acc` as 64-bit FIXED-POINT atomics (2^-32 units): integer addition is associative, so the
 // scatter is bit-reproducible whatever order the waves arrive in.
 constexpr float GEO_FIX = 4294967296.0f;     // 2^32
-// q * 2^32 as a two's-complement 64-bit integer (|q| < 2^31; truncated below 2^-32): floor and fraction are exact in fp32
+// q * 2^32 as a two's-complement 64-bit integer (|q| < 2^31; truncated below 2^-32).  floor(q) is exact in fp32 and so is the
+// fraction q - floor(q) -- except for a tiny negative q (-1e-10: floor -1, fraction ROUNDS to 1.0f), whose fraction times 2^32
+// would be out of range for the float -> unsigned conversion (undefined in C++; v_cvt_u32_f32 happens to saturate): such a q is
+// carried as the integer above it with fraction 0, i.e. rounded to zero, an error below 2^-24 of one unit of the integer part.
 __device__ __forceinline__ unsigned long long to_fix32(float q) {
-    const float h = floorf(q);
-    const unsigned lo = (unsigned)((q - h) * GEO_FIX);
+    float h = floorf(q);
+    float f = q - h;
+    if (f >= 1.0f) { h += 1.0f; f = 0.0f; }
+    const unsigned lo = (unsigned)(f * GEO_FIX);            // f in [0, 1 - 2^-24]: f * 2^32 <= 2^32 - 256
     return ((unsigned long long)(unsigned)(int)h << 32) | lo;
 }
 

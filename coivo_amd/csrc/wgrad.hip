@@ -55,6 +55,15 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int DYP = dy_pitch<T, MT>();         // dY row pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef COLVO_WTRACE
+    // developer build: shader-clock stamps taken right behind barriers only (a stamp is a scalar memory read: anywhere else its
+    // lgkmcnt wait would drain the LDS reads it is meant to observe)
+    long long wt_start = (long long)clock64(), wt_first = 0, wt_store = 0, wt_compute = 0, wt_b1 = 0, wt_b2 = 0, wt_loop_end = 0, wt_flush = 0;
+    long long wt_wall0 = (long long)wall_clock64();
+#define WT_STAMP(x) x = (long long)clock64()
+#else
+#define WT_STAMP(x) do {} while (0)
+#endif
     const int tid = threadIdx.x & (NT - 1), lane = tid & 63, wave = tid >> 6;       // inside the team
     const int team = (KS > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x / NT) : 0;
     const int l15 = lane & 15, kg = lane >> 4;
@@ -222,9 +231,17 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     if (t_begin < t_end) { const bool live = t_begin + team < t_end; load_dy(cur, live); load_p(cur, live); }
     for (int t = t_begin; t < t_end; t += KS) {
         __syncthreads();
+#ifdef COLVO_WTRACE
+        WT_STAMP(wt_b1);
+        if (t == t_begin) wt_first = wt_b1; else wt_compute += wt_b1 - wt_b2;
+#endif
         store_dy();
         store_p(cur, t + team < t_end);
         __syncthreads();
+#ifdef COLVO_WTRACE
+        WT_STAMP(wt_b2);
+        wt_store += wt_b2 - wt_b1;
+#endif
 #pragma unroll
         for (int q = 0; q < KS; ++q) tile_next(cur);
         if (t + KS < t_end) { const bool live = t + KS + team < t_end; load_dy(cur, live); load_p(cur, live); }   // in flight during the MFMAs below
@@ -311,6 +328,11 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     }
 
     mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
+#ifdef COLVO_WTRACE
+    __syncthreads();
+    WT_STAMP(wt_loop_end);
+    wt_compute += wt_loop_end - wt_b2;
+#endif
     float* sdb = reinterpret_cast<float*>(smem);
     if constexpr (KS > 1) {
         // The teams' accumulators meet in team 0 through LDS, one team per round with plain 16-byte stores (ds_add_f32
@@ -364,7 +386,20 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
             else atomicAdd(a.db + co0 + tid, t);
         }
     }
+#ifdef COLVO_WTRACE
+    if (a.trace) {
+        __builtin_amdgcn_s_waitcnt(0);          // the flush's atomics / stores have left the wave (vmcnt 0)
+        __syncthreads();
+        WT_STAMP(wt_flush);
+        if (threadIdx.x == 0) {
+            long long* r = a.trace + (size_t)blockIdx.x * 8;
+            r[0] = wt_start; r[1] = wt_first - wt_start; r[2] = wt_store; r[3] = wt_compute; r[4] = wt_flush - wt_loop_end;
+            r[5] = wt_flush - wt_start; r[6] = (long long)wall_clock64() - wt_wall0; r[7] = (t_end - t_begin + KS - 1) / KS;
+        }
+    }
+#endif
 }
+#undef WT_STAMP
 
 // deterministic form, second launch: dst[i] += slabs[0][i] + slabs[1][i] + ... in split order; the bias slabs ride in the same launch
 // (blocks beyond `wblocks`).  Eight slab loads are in flight before the adds consume them in order (one load per add was a chain of
@@ -391,6 +426,37 @@ __global__ __launch_bounds__(NT) void k_wgrad_reduce(const float* __restrict__ s
     if (blockIdx.x < wblocks) reduce_slabs(slabs, nsplit, n, dst, (size_t)blockIdx.x * NT + threadIdx.x, (size_t)wblocks * NT);
     else reduce_slabs(bslabs, nsplit, nb, bdst, (size_t)(blockIdx.x - wblocks) * NT + threadIdx.x, (size_t)(gridDim.x - wblocks) * NT);
 }
+
+#ifdef COLVO_WTRACE
+// developer build (tools/wtrace_wgrad.sh): per-workgroup phase stamps of k_wgrad3x3, printed as means over the workgroups
+static long long* g_wtrace = nullptr;
+static int g_wtrace_calls = 0;
+inline void wtrace_begin(WgradK& k, unsigned nwg, hipStream_t s) {
+    k.trace = nullptr;
+    if (!getenv("COLVO_WTRACE") || nwg > (1u << 14)) return;
+    if (!g_wtrace) (void)hipMalloc(&g_wtrace, (size_t)(1u << 14) * 8 * sizeof(long long));
+    (void)hipMemsetAsync(g_wtrace, 0, (size_t)nwg * 8 * sizeof(long long), s);
+    k.trace = g_wtrace;
+}
+inline void wtrace_end(const WgradK& k, unsigned nwg, int MT, int NG, bool tail, int ks, hipStream_t s) {
+    if (!k.trace || (++g_wtrace_calls % atoi(getenv("COLVO_WTRACE"))) != 0) return;
+    (void)hipStreamSynchronize(s);
+    std::vector<long long> h((size_t)nwg * 8);
+    (void)hipMemcpy(h.data(), g_wtrace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long t0 = h[0], t1 = 0;
+    for (unsigned i = 0; i < nwg; ++i) {
+        for (int j = 1; j < 8; ++j) m[j] += (double)h[(size_t)i * 8 + j] / nwg;
+        t0 = std::min(t0, h[(size_t)i * 8]); t1 = std::max(t1, h[(size_t)i * 8] + h[(size_t)i * 8 + 5]);
+    }
+    const double cyc_per_us = m[6] > 0 ? m[5] / (m[6] * 0.01) : 0.0;       // shader clocks per microsecond (wall clock: 100 MHz)
+    fprintf(stderr, "[wtrace] MT=%d NG=%d tail=%d KS=%d S=%d Cout=%d Ctot=%d %dx%d tile %dx%d grid=%u nsplit=%d tiles/wg %.1f | clock %.0f MHz | "
+            "span %.2f us | mean wg (us): life %.2f = setup+first-load %.2f + store %.2f + compute %.2f + flush %.2f | per tile: store %.3f compute %.3f\n",
+            MT, NG, (int)tail, ks, k.g.stride, k.Cout, k.Ctot, k.Ho, k.Wo, k.toh, k.tow, nwg, k.nsplit, m[7], cyc_per_us,
+            cyc_per_us > 0 ? (t1 - t0) / cyc_per_us : 0.0, m[5] / cyc_per_us, m[1] / cyc_per_us, m[2] / cyc_per_us, m[3] / cyc_per_us,
+            m[4] / cyc_per_us, m[2] / cyc_per_us / std::max(1.0, m[7]), m[3] / cyc_per_us / std::max(1.0, m[7]));
+}
+#endif
 
 // plan-only calls report the split count; deterministic calls point the kernel at the caller's scratch.  Returns 1 when the
 // caller has nothing more to do (plan written), 0 to go on, < 0 never; errors are reported through *err.
@@ -453,8 +519,14 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
+#ifdef COLVO_WTRACE
+    wtrace_begin(k, grid.x, s);
+#endif
     hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3 (teams)");
+#ifdef COLVO_WTRACE
+    wtrace_end(k, grid.x, MT, NG, TAIL, KS, s);
+#endif
     return wgrad_finish(k, nsplit, s);
 }
 
@@ -508,8 +580,14 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     k.nsplit = nsplit; k.cot = cot; k.xcd = xcd_on;
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
     dim3 grid((unsigned)(nsplit * cot * chunks), 1, 1);
+#ifdef COLVO_WTRACE
+    wtrace_begin(k, grid.x, s);
+#endif
     hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3");
+#ifdef COLVO_WTRACE
+    wtrace_end(k, grid.x, MT, NG, TAIL, 1, s);
+#endif
     return wgrad_finish(k, nsplit, s);
 }
 

@@ -27,18 +27,28 @@ import torch
 from .functional import photometric_loss
 
 
+GRAPH_STAT_NAMES = ("nodes", "edges", "roots", "leaves", "forks", "joins", "max_out_degree", "max_in_degree",
+                    "calls", "main_commands", "side_commands", "side_segments", "chain_joins", "calls_with_carried_commands",
+                    "max_entry_dependencies", "pending_commands")
+
+
 class GraphedTrainStep:
+    """carry (default on): the weight-gradient chain stays open from one recorded pass to the next inside the graph, as the eager
+    schedule's deferred join leaves PoseNet's weight gradients running beside DepthNet's backward pass (include/colvo.h
+    colvo_set_capture_carry); off: every pass ends joined (the round-3 form)."""
+
     def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
-                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2, full_loss: bool = False):
+                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2, full_loss: bool = False, carry: bool = True):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
-        self.capture_policy, self.capture_group = int(capture_policy), int(capture_group)
+        self.capture_policy, self.capture_group, self.carry = int(capture_policy), int(capture_group), bool(carry)
         self.B, self.ssim_weight, self.full_loss = B, ssim_weight, bool(full_loss)
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
         self.loss = torch.zeros((), device=dev)
         self._one = torch.ones((), device=dev)      # dL/dloss: a persistent scalar instead of a ones_like() fill per step
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.stats = None                           # colvo_graph_stats of the captured graph (GRAPH_STAT_NAMES)
         self._warmup = warmup
 
     # one eager step on the static buffers
@@ -60,8 +70,18 @@ class GraphedTrainStep:
         self.opt.step()
         return loss.detach()
 
+    def _operands_current(self) -> None:
+        """The captured optimizer step (colvo_adam_pack_step) rewrites the operand copies of the weights itself, so the graph holds
+        no repacking node: the copies the first forward kernels read must be current BEFORE a replay (round 3 captured
+        two k_pack_weights_multi launches per step that the fused update made redundant).  No-op when they are."""
+        if self.opt.writes_operand_copies():
+            self.depth_net._prepare_weights()
+            self.pose_net._prepare_weights()
+
     def capture(self) -> None:
         """Warm up (kernel attribute setup, side streams, allocator pools) without side effects, then capture."""
+        from . import _lib
+        lib = _lib.load()
         nets = (self.depth_net, self.pose_net)
         self.opt.use_device_step_counter()          # a captured host-side step number would repeat at every replay
         snap_p = [n.flat_param.clone() for n in nets]
@@ -83,12 +103,27 @@ class GraphedTrainStep:
                     for k in st:
                         st[k].copy_(src[k])
         restore()
-        from . import _lib
-        _lib.check(_lib.load().colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
+        # without the fused update the graph must hold the repacking nodes: leave the copies marked stale so that they are recorded
+        self._operands_current()
+        _lib.check(lib.colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
+        _lib.check(lib.colvo_set_capture_carry(int(self.carry)), "colvo_set_capture_carry")
+        _lib.check(lib.colvo_graph_stats_reset(), "colvo_graph_stats_reset")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = self._step()
-            self.loss.copy_(out)
+        try:
+            with torch.cuda.graph(g):
+                out = self._step()
+                self.loss.copy_(out)
+                # every open chain is joined by now (the optimizer joins before it reads the gradients)
+                import ctypes as C
+                buf = (C.c_longlong * 16)()
+                rc = lib.colvo_graph_stats(_lib.stream_ptr(), buf, 16)      # (the library's own counters are filled even if the
+                self.stats = dict(zip(GRAPH_STAT_NAMES, [int(v) for v in buf]))   # runtime refuses to list the graph's nodes)
+                if rc != 0:
+                    self.stats["error"] = lib.colvo_last_error().decode("utf-8", "replace")
+        finally:
+            lib.colvo_set_capture_carry(0)
+        if self.stats["pending_commands"]:
+            raise RuntimeError("hipGraph capture ended with weight-gradient commands still held back (a join is missing)")
         self.graph = g
         restore()          # capture itself does not execute, but keep the state exactly as the caller left it
         torch.cuda.synchronize()
@@ -100,8 +135,11 @@ class GraphedTrainStep:
             self.frames.copy_(frames, non_blocking=True)
         if K is not None:
             self.K.copy_(K, non_blocking=True)
+        self._operands_current()
         self.graph.replay()
-        # the captured Adam step rewrote the master weights: an eager forward afterwards must re-pack its operand copies
-        self.depth_net.mark_params_changed()
-        self.pose_net.mark_params_changed()
+        for n in (self.depth_net, self.pose_net):
+            if self.opt.writes_operand_copies():
+                n.operands_written()         # the captured update left master weights AND operand copies current
+            else:
+                n.mark_params_changed()      # the captured Adam step rewrote the master weights: an eager forward must re-pack
         return self.loss

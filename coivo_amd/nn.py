@@ -245,6 +245,10 @@ class _ArenaModule(nn.Module):
         """Run body() -- a sequence of ops.* calls -- as the pass `which` of `inst`: recorded on first use, replayed
         afterwards with the externals' pointers patched in.  Returns what body() returned when it was recorded."""
         if not self.use_programs:
+            if torch.cuda.is_current_stream_capturing():
+                # the layer-by-layer developer path forks the weight gradients onto a real side stream with events: captured, that
+                # is the multi-stream graph that aborted the runtime under GPU_MAX_HW_QUEUES=2 in round 2 (DESIGN.md section 3.4)
+                raise RuntimeError("hipGraph capture needs the recorded passes (COLVO_NO_PROGRAM / use_programs=False cannot be captured)")
             return body()
         entry = inst.passes.get(which)
         if entry is None:
@@ -274,11 +278,13 @@ class _ArenaModule(nn.Module):
             capturing = torch.cuda.is_current_stream_capturing()
 
             def call(L, on_side):
-                # (under hipGraph capture there is no side stream: colvo_run_commands has joined the weight-gradient chain at
-                # the end of the segment, the collective is captured behind it on the main stream)
+                # (under hipGraph capture there is no side stream: the weight-gradient chain the library keeps is joined here --
+                # in carry mode a segment does not end joined by itself -- and the collective is captured behind it)
                 if on_side and not capturing:
                     with torch.cuda.stream(self._side):
                         return self.grad_ready_hook(self, L.span[0], L.span[1])
+                if capturing:
+                    _lib.check(_lib.load().colvo_capture_join(_lib.stream_ptr()), "colvo_capture_join")
                 return self.grad_ready_hook(self, L.span[0], L.span[1])
 
             done = 0
@@ -377,8 +383,11 @@ class _ArenaModule(nn.Module):
             _final_join()
 
     def join_side(self) -> None:
-        """Make the current stream wait for the weight gradients still running on this network's side stream."""
-        if self._join_pending and self._side is not None and not torch.cuda.is_current_stream_capturing():
+        """Make the current stream wait for the weight gradients still running on this network's side stream.  Under hipGraph
+        capture the side chain lives in the library (csrc/program.hip, carry mode): the next captured node is made to depend on it."""
+        if torch.cuda.is_current_stream_capturing():
+            _lib.check(_lib.load().colvo_capture_join(_lib.stream_ptr()), "colvo_capture_join")
+        elif self._join_pending and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._join_pending = False
 

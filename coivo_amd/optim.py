@@ -76,6 +76,11 @@ class FusedAdam:
                                 beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, grad_scale=self.grad_scale)
             m.mark_params_changed()
 
+    def writes_operand_copies(self) -> bool:
+        """True when step() is the one-pass form (colvo_adam_pack_step) that leaves every network's operand copies current: a
+        captured step then needs no repacking node (graph.GraphedTrainStep packs once, eagerly, before the capture)."""
+        return self._fused_pack and len({m.compute_dtype for m in self.modules}) == 1
+
     # ---- update + operand copies in one pass (include/colvo.h colvo_adam_pack_step) -------------------------------------- #
     def _pack_step(self) -> bool:
         """One launch: Adam over every network's arena AND the bf16 / transposed operand copies of the updated 3x3 weights, so

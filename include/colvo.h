@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 6
+#define COLVO_ABI_VERSION 7
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -389,6 +389,25 @@ int colvo_set_aux_side_streams(int n);
  * Nodes are created so that the main chain stays the FIRST child of every fork point: ROCm's executor keeps the first child on the
  * parent's stream and opens a stream per further child. */
 int colvo_set_capture_policy(int policy, int group);
+/* Carry mode of the hipGraph form (default off: every captured colvo_run_commands call ends joined).  on: a list that ends without
+ * a JOIN leaves the side chain OPEN -- the next captured call continues it, exactly as the eager schedule's deferred join leaves the
+ * weight gradients of one network running beside the next network's backward pass -- and side commands still pending at the end of
+ * a call are held back (as copies) until the next call has captured its first main-chain node: created earlier they would become the
+ * first child of the main chain's last node and push the main chain onto a new stream (see colvo_set_capture_policy).  The caller
+ * must then call colvo_capture_join(stream) wherever the eager schedule joins its side stream (before the optimizer, before a
+ * collective that reads the gradients, before the capture ends). */
+int colvo_set_capture_carry(int on);
+/* The next node captured on `stream` depends on the main chain AND on everything the open side chain(s) hold, pending commands
+ * included.  No-op when `stream` is not being captured or nothing is open. */
+int colvo_capture_join(colvo_stream_t stream);
+/* Structure of what has been built (tests, tools): out[0..7] describe the graph under construction on `stream` when it is being
+ * captured -- nodes, edges, root nodes, leaf nodes, nodes with >= 2 children (forks), nodes with >= 2 parents (joins), largest
+ * out-degree, largest in-degree -- and are -1 otherwise; out[8..15] count what colvo_run_commands has captured since
+ * colvo_graph_stats_reset(): calls, main-chain commands, side-chain commands, side segments, joins, calls that started with
+ * carried-over commands, the largest dependency set a call started from, commands pending right now.  n >= COLVO_GRAPH_STATS_N. */
+#define COLVO_GRAPH_STATS_N 16
+int colvo_graph_stats(colvo_stream_t stream, long long* out, int n);
+int colvo_graph_stats_reset(void);
 
 /* Dispatch thresholds (coivo_amd/csrc/tuning.h: ONE table, defaults measured on MI355X; production reads no environment
  * variable).  Developer / test hooks: set or read an entry by name ("quad_min_wgs", "wgrad_atomic_mb", ...); with COLVO_DEV=1 in

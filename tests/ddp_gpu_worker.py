@@ -12,6 +12,67 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g_pn):
+    """DP == big batch against the SPEC: the all-reduced gradient x 1/world and the parameters after one Adam step vs the oracle's
+    single-process update on the mean of the per-rank losses (fp32 and fp64 oracle at the HIP path's ReLU decisions of each rank's
+    own slice: tests/gpu_util.py), at the bar of grad_parity_failures."""
+    from oracle import colvo_spec as S
+    from tests import gpu_util as G
+    masks = G.hip_relu_masks(dn, pn)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((masks, float(loss.item())), gathered, dst=0)
+    if rank != 0:
+        return
+    cpu = {k: v.detach().cpu() for k, v in full.items() if torch.is_tensor(v)}
+    acc = {}
+    for dtype in (torch.float32, torch.float64):
+        tot, tot_loss = None, 0.0
+        for r in range(world):
+            sl = slice(r * B, (r + 1) * B)
+            o = G.oracle_step(seed, {k: cpu[k][sl] for k in ("tgt", "ref", "K")}, dtype, gathered[r][0])
+            assert o["flip_worst"] < G.RELU_MARGIN, f"rank {r}: forced a ReLU decision at |pre| = {o['flip_worst']:.3e}"
+            tot_loss += o["loss"] / world
+            g = [(n, t.detach().double() / world) for n, t in o["grads"]]
+            tot = g if tot is None else [(n, a + b) for (n, a), (_, b) in zip(tot, g)]
+        acc[dtype] = (tot, tot_loss)
+    hip_loss = sum(l for _, l in gathered) / world
+    assert abs(hip_loss - acc[torch.float32][1]) < 1e-5, (hip_loss, acc[torch.float32][1])
+    hip = [("depth." + n, p.grad.detach().double() / world) for n, p in dn.named_parameters()] + \
+          [("pose." + n, p.grad.detach().double() / world) for n, p in pn.named_parameters()]
+    rows = G.grad_parity_table(hip, acc[torch.float32][0], acc[torch.float64][0])
+    bad = G.grad_parity_failures(rows)
+    assert not bad, "data-parallel gradient vs the oracle's mean-of-rank-losses gradient:\n" + "\n".join(bad)
+    # one Adam step of the oracle on that gradient vs FusedAdam(grad_scale = 1/world) on the all-reduced arena
+    dn_o, pn_o = S.make_models(seed)
+    params = list(dn_o.parameters()) + list(pn_o.parameters())
+    for p, (_, g) in zip(params, acc[torch.float32][0]):
+        p.grad = g.float()
+    torch.optim.Adam(params, **S.ADAM_KW).step()
+    dn2, pn2 = type(dn)(device=dn.flat_param.device), type(pn)(device=pn.flat_param.device)
+    dn2.load_state_dict(dn.state_dict()); pn2.load_state_dict(pn.state_dict())     # copies: the real step follows in main()
+    dn2.flat_grad.copy_(dn.flat_grad); pn2.flat_grad.copy_(pn.flat_grad)
+    from coivo_amd.optim import FusedAdam
+    opt2 = FusedAdam([dn2, pn2], lr=opt.lr)
+    opt2.grad_scale = opt.grad_scale
+    dn2.attach_grads(); pn2.attach_grads()
+    dn2.flat_grad.copy_(dn.flat_grad); pn2.flat_grad.copy_(pn.flat_grad)
+    opt2.step()
+    torch.cuda.synchronize()
+    worst, flipped, total = 0.0, 0, 0
+    hp = dict([("depth." + n, p) for n, p in dn2.named_parameters()] + [("pose." + n, p) for n, p in pn2.named_parameters()])
+    op = dict([("depth." + n, p) for n, p in dn_o.named_parameters()] + [("pose." + n, p) for n, p in pn_o.named_parameters()])
+    for n in hp:
+        d = (hp[n].detach().cpu() - op[n].detach()).abs()
+        worst = max(worst, d.max().item())
+        flipped += int((d > 1e-6).sum()); total += d.numel()
+    # Adam's first step is sign-like (+-lr whatever the gradient's size): only elements whose gradient is rounding noise around zero
+    # may land on the other side (2 lr apart); everything else must agree to float rounding
+    assert worst <= 2.0 * opt.lr * 1.01 + 1e-6 and flipped / total < 5e-3, (worst, flipped, total)
+    print(f"DDP_OK ORACLE: loss |d| {abs(hip_loss - acc[torch.float32][1]):.1e}, worst gradient tensor relL2 "
+          f"{max(r[5] for r in rows):.2e} (fp32 oracle {max(r[6] for r in rows):.2e}), parameters after Adam: max |d| {worst:.2e}, "
+          f"{flipped}/{total} elements beyond 1e-6", flush=True)
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,6 +107,8 @@ def main():
     ddp.finish()
     torch.cuda.synchronize()
     g_dn, g_pn = dn.flat_grad.clone(), pn.flat_grad.clone()       # summed over ranks, in place in the arena
+    if os.environ.get("DDP_ORACLE") is not None:
+        _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g_pn)
     opt.step()
     torch.cuda.synchronize()
     # every rank must hold identical gradients and parameters

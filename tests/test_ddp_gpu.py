@@ -59,26 +59,45 @@ def test_bench_multiprocess_path():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
 
 
+def test_two_rank_dp_matches_the_oracle_big_batch_update():
+    """SURVEY.md section 8e, "DP == big batch", on the HIP networks against the SPEC (VERDICT r3 missing 2): two ranks share the GPU
+    over gloo, fp32 mode; the all-reduced, 1/N-scaled gradient and the parameters after one Adam step are compared with the ORACLE's
+    single-process update on the mean of the per-rank losses, at the gradient bar of tests/gpu_util.grad_parity_failures."""
+    r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")], extra_env={"DDP_ORACLE": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "DDP_OK ORACLE" in r.stdout, r.stdout[-2000:]
+
+
 def test_rccl_path_with_one_rank():
     """The REAL multi-GPU code path with world_size 1: init_process_group('nccl'), GradBuckets, all-reduces issued from the
     weight-gradient side stream (bench.py --rccl-single).  The collectives are trivial but the plumbing is not: this is the
-    only way to execute it on a one-GPU box.  The step must produce the same loss as the plain run and not fall into the
+    only way to execute it on a one-GPU box.  With deterministic weight gradients (COLVO_DETERMINISTIC=1) nothing in a step depends on
+    an execution order and a one-rank fp32 all-reduce is the identity, so the run through the RCCL path must end in EXACTLY the plain
+    run's loss (a wrong grad_scale, a dropped bucket or a stale staging copy cannot hide in a tolerance).  bf16 transport rounds
+    every gradient element to bf16 (relative error <= 2^-9) before Adam: bound derived below.  And the step must not fall into the
     serialised mode (several times the plain step time) that too many active hardware queues cause."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533")
-    common = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline-cfg2", "--steps", "30", "--warmup", "5",
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29533", COLVO_DETERMINISTIC="1")
+    common = [sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-roofline-cfg2", "--no-side-measurements",
+              "--steps", "30", "--warmup", "5",
               "--graph", "off"]        # (the one-GPU default `best` runs 23 more steps before the warm-up: different final loss)
     out = {}
     for tag, extra in (("plain", []), ("rccl", ["--rccl-single"]), ("rccl_bf16", ["--rccl-single", "--grad-transport", "bf16"])):
         r = subprocess.run(common + extra, capture_output=True, text=True, env=env, timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = json.loads(r.stdout.strip().split("\n")[-1])
-    # the final loss of 35 steps on one batch varies by +-1.5e-3 (0.0234 .. 0.0257) from run to run of ONE configuration: float
-    # atomics in the weight gradients, amplified by Adam's sign-like first steps; the plumbing check only needs "the same problem"
-    assert abs(out["rccl"]["final_loss"] - out["plain"]["final_loss"]) < 5e-3
-    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) < 5e-3
+        assert out[tag]["deterministic_weight_gradients"]
+    assert out["rccl"]["final_loss"] == out["plain"]["final_loss"], (out["rccl"]["final_loss"], out["plain"]["final_loss"])
+    assert out["rccl"]["first_loss"] == out["plain"]["first_loss"] == out["rccl_bf16"]["first_loss"]
+    # bf16 transport: g' = g (1 + e), |e| <= 2^-9 per element.  Adam's update m / (sqrt(v) + eps) is homogeneous of degree 0 in a
+    # uniform scaling of g and moves by at most ~2|e| of itself under element-wise perturbations, so over the 35 steps the
+    # trajectory's total loss change D = |first_loss - final_loss| moves by O(2^-8 D) to first order; 8x that as the bar
+    # (measured: see DESIGN.md section 5) instead of round 3's 5e-3 = 20 % of the loss.
+    D = abs(out["plain"]["first_loss"] - out["plain"]["final_loss"])
+    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) <= 8 * 2.0 ** -8 * D + 1e-6, \
+        (out["rccl_bf16"]["final_loss"], out["plain"]["final_loss"], D)
     assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
     assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]

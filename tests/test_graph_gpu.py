@@ -100,23 +100,59 @@ def test_graphed_full_objective_step_is_bitwise_the_eager_one():
     assert torch.equal(dn1.flat_param, dn2.flat_param) and torch.equal(pn1.flat_param, pn2.flat_param)
 
 
-def test_graph_is_built_with_explicit_dependencies():
-    """The captured graph has ONE root (the capture is one stream) and more than one branch: under capture colvo_run_commands
-    hangs the weight-gradient chain off the main chain by dependency edits, not by a second captured stream."""
+@pytest.mark.parametrize("policy", [0, 2])
+def test_graph_is_built_with_explicit_dependencies(policy):
+    """The structure of the captured graph, read back from the runtime (colvo_graph_stats: hipGraphGetNodes / GetRootNodes /
+    GetEdges on the graph under construction): ONE root -- the capture is one stream, colvo_run_commands hangs the weight-gradient
+    chain off the main chain by dependency edits, not by a second captured stream -- and
+      policy 0: a pure chain (no fork, edges = nodes - 1, one leaf);
+      policy 2: two chains -- forks exist, no node has more than two children or two parents, the side chain is cut into segments,
+                PoseNet's open chain is carried into DepthNet's backward pass (carry mode) and nothing is left pending.
+    ADVICE r3: no k_pack_weights_multi node -- the fused update writes the operand copies, they are packed once BEFORE the capture."""
+    from coivo_amd import ops
     from coivo_amd.graph import GraphedTrainStep
     B, H, W, seed = 1, 32, 64, 62
     b = to_dev(synth.make_batch(B, H, W, seed=seed))
     dn, pn, opt = _setup(seed, torch.bfloat16)
-    step = GraphedTrainStep(dn, pn, opt, B, H, W, capture_policy=2, capture_group=4)
-    l0 = step(torch.cat([b["tgt"], b["ref"]]), b["K"]).item()
+    step = GraphedTrainStep(dn, pn, opt, B, H, W, capture_policy=policy, capture_group=4)
+    packs_under_capture = [0]
+    real_pack = ops.pack_weights_multi
+
+    def counting_pack(*a, **kw):
+        packs_under_capture[0] += int(torch.cuda.is_current_stream_capturing())
+        return real_pack(*a, **kw)
+
+    ops.pack_weights_multi = counting_pack
+    try:
+        l0 = step(torch.cat([b["tgt"], b["ref"]]), b["K"]).item()
+    finally:
+        ops.pack_weights_multi = real_pack
     l1 = step().item()
     assert 0 < l1 < 1 and l1 != l0
+    assert packs_under_capture[0] == 0, "the captured step repacks the weights although the fused update writes the operand copies"
+    st = step.stats
+    assert st is not None and "error" not in st, st
+    assert st["pending_commands"] == 0 and st["max_entry_dependencies"] <= 1, st
+    assert st["roots"] == 1, st
+    # 4 recorded passes (2 forward, 2 backward) went through the native builder; the backward passes hold the side commands
+    assert st["calls"] >= 4 and st["main_commands"] > 40, st
+    if policy == 0:
+        assert st["forks"] == 0 and st["joins"] == 0 and st["edges"] == st["nodes"] - 1 and st["leaves"] == 1, st
+        assert st["side_commands"] == 0 and st["side_segments"] == 0, st
+    else:
+        assert st["forks"] >= 3 and st["joins"] >= 3, st
+        assert st["max_out_degree"] == 2 and st["max_in_degree"] == 2, st          # two chains, never a third branch
+        assert st["side_commands"] == 28 and st["side_segments"] >= 7, st            # 20 + 1 (DepthNet + its head) + 7 (PoseNet) weight gradients
+        assert st["calls_with_carried_commands"] >= 1, st                           # PoseNet's tail rides into DepthNet's backward
+        assert st["leaves"] == 1, st
     assert dn._side is None or not torch.cuda.is_current_stream_capturing()
 
 
 def test_graphed_step_with_rccl_single_rank():
     """configs[4]'s structure on one GPU: the graph contains the bucketed all-reduces of ddp.GradBuckets (RCCL, one rank) beside the
-    native two-chain backward, and replays to the same losses as the eager data-parallel step."""
+    native two-chain backward.  Deterministic weight gradients + fp32 transport: a one-rank all-reduce is the identity, so the
+    replayed data-parallel trajectory equals the eager one BIT FOR BIT (losses, both parameter arenas); with bf16 transport the
+    gradients are rounded to bf16 on the way -- identically in both forms, so that pair is bitwise equal too."""
     import os
     import torch.distributed as dist
     from coivo_amd import nn as hnn
@@ -131,24 +167,76 @@ def test_graphed_step_with_rccl_single_rank():
         B, H, W, seed = 2, 64, 96, 63
         b = to_dev(synth.make_batch(B, H, W, seed=seed))
         frames = torch.cat([b["tgt"], b["ref"]])
-        dn1, pn1, opt1 = _setup(seed, torch.bfloat16)
-        dn2, pn2, opt2 = _setup(seed, torch.bfloat16)
-        ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=torch.bfloat16)
-        ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=torch.bfloat16)
-        step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
-        eager, graphed = [], []
-        for _ in range(3):
-            opt1.zero_grad()
-            loss = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"])[0]
-            loss.backward()
-            ddp1.finish()
-            opt1.step()
-            eager.append(loss.item())
-            graphed.append(step(frames, b["K"]).item())
-        torch.cuda.synchronize()
-        for e, g in zip(eager, graphed):
-            assert abs(e - g) < 1e-2, (eager, graphed)
-        assert graphed[-1] < graphed[0]
-        ddp1.detach(); ddp2.detach()
+        for transport in (None, torch.bfloat16):
+            dn1, pn1, opt1 = _setup(seed, torch.bfloat16)
+            dn2, pn2, opt2 = _setup(seed, torch.bfloat16)
+            for n in (dn1, pn1, dn2, pn2):
+                n.deterministic = True
+            ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport)
+            ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport)
+            step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
+            eager, graphed = [], []
+            for _ in range(3):
+                opt1.zero_grad()
+                loss = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"])[0]
+                loss.backward()
+                ddp1.finish()
+                opt1.step()
+                eager.append(loss.item())
+                graphed.append(step(frames, b["K"]).item())
+            torch.cuda.synchronize()
+            assert eager == graphed, (transport, eager, graphed)
+            assert torch.equal(dn1.flat_param, dn2.flat_param) and torch.equal(pn1.flat_param, pn2.flat_param), transport
+            assert graphed[-1] < graphed[0]
+            if transport is None:
+                # ... and the fp32-transport run is bitwise the run WITHOUT any process group (the one-rank all-reduce is the identity)
+                dn3, pn3, opt3 = _setup(seed, torch.bfloat16)
+                dn3.deterministic = pn3.deterministic = True
+                for _ in range(3):
+                    opt3.zero_grad()
+                    hnn.dcdp_forward(dn3, pn3, b["tgt"], b["ref"], b["K"])[0].backward()
+                    opt3.step()
+                torch.cuda.synchronize()
+                assert torch.equal(dn1.flat_param, dn3.flat_param) and torch.equal(pn1.flat_param, pn3.flat_param)
+            ddp1.detach(); ddp2.detach()
     finally:
         dist.destroy_process_group()
+
+
+def test_capture_and_replay_with_two_hardware_queues_in_a_fresh_process():
+    """round 2's multi-stream capture aborted the runtime under GPU_MAX_HW_QUEUES=2.  The capture has used ONE stream
+    since round 3; this runs capture + 3 replays + an eager step in a child process whose environment holds GPU_MAX_HW_QUEUES=2
+    before it touches the GPU, and checks that the child ends with rc 0 and the eager trajectory's loss."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from coivo_amd import nn as hnn, synth\n"
+        "from coivo_amd.graph import GraphedTrainStep\n"
+        "from coivo_amd.optim import FusedAdam\n"
+        "dev = torch.device('cuda:0'); B, H, W = 2, 64, 96\n"
+        "b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.make_batch(B, H, W, seed=5).items()}\n"
+        "def nets():\n"
+        "    torch.manual_seed(0)\n"
+        "    dn, pn = hnn.DepthNet(compute_dtype=torch.bfloat16), hnn.PoseNet(compute_dtype=torch.bfloat16)\n"
+        "    with torch.no_grad():\n"
+        "        for n in (dn, pn):\n"
+        "            for name, p in n.named_parameters():\n"
+        "                if name.endswith('weight'): p.copy_(torch.randn(p.shape, device=dev) * (2.0 / (p.shape[1] * 9)) ** 0.5)\n"
+        "    dn.deterministic = pn.deterministic = True\n"
+        "    return dn, pn, FusedAdam([dn, pn], lr=1e-4)\n"
+        "dn, pn, opt = nets(); torch.manual_seed(0)\n"
+        "step = GraphedTrainStep(dn, pn, opt, B, H, W)\n"
+        "frames = torch.cat([b['tgt'], b['ref']])\n"
+        "g = [step(frames, b['K']).item() for _ in range(3)]\n"
+        "dn2, pn2, opt2 = nets(); e = []\n"
+        "for _ in range(3):\n"
+        "    opt2.zero_grad(); l = hnn.dcdp_forward(dn2, pn2, b['tgt'], b['ref'], b['K'])[0]; l.backward(); opt2.step(); e.append(l.item())\n"
+        "torch.cuda.synchronize()\n"
+        "assert g == e, (g, e)\n"
+        "print('HWQ2_OK', g[-1])\n") % root
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0 and "HWQ2_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
