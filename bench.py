@@ -89,7 +89,7 @@ def parse():
     ap.add_argument("--graph-policy", type=int, choices=[0, 1, 2, 3], default=2,
                     help="how the weight-gradient chain hangs off the main chain in the graph (include/colvo.h "
                          "colvo_set_capture_policy): 0 one branch, 1 one edge per layer, 2 segments of --graph-group commands")
-    ap.add_argument("--graph-group", type=int, default=2)
+    ap.add_argument("--graph-group", type=int, default=None, help="default: 1 from 32 pairs per GPU on, else 2 (coivo_amd/graph.py)")
     return resolve_config(ap.parse_args())
 
 
@@ -698,7 +698,7 @@ def main():
                "first_loss": first_loss, "final_loss": final_loss,
                "deterministic_weight_gradients": bool(dn.deterministic and pn.deterministic),
                "hipgraph": use_graph, "hipgraph_trial": graph_trial, "hipgraph_error": graph_error,
-               "hipgraph_policy": ({"policy": args.graph_policy, "group": args.graph_group, "carry": bool(graphed.carry),
+               "hipgraph_policy": ({"policy": args.graph_policy, "group": graphed.capture_group, "carry": bool(graphed.carry),
                                     "graph": graphed.stats} if use_graph else None),
                # what the stream policy saw in this process (a first multi-GPU SCALE record should explain itself: DESIGN.md
                # section 5): the runtime's hardware-queue limit as exported before HIP initialised, queues claimed by parties other

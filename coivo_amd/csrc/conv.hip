@@ -293,7 +293,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     constexpr int NGR = 9 * NG;                    // real granules per weight row and chunk
     constexpr int STEPS = (NGR + 3) / 4;           // MFMA k-groups (4 granules each) per chunk
     constexpr int WROW = wrow_bytes(STEPS * 4);     // weight-row pitch in LDS (bytes)
-    constexpr int PIXP = pitch_bytes(NG * 16);     // patch-pixel pitch in LDS (bytes)
+    // patch-pixel pitch in LDS (bytes).  TAIL instantiations are the stride-2 layers (a stride-1 patch of <= 128 outputs never
+    // exceeds 3 x 256 granules): consecutive fragment rows are TWO patch pixels apart there, conv_common.h pitch_bytes_s2
+    constexpr int PIXP = TAIL ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
     constexpr int OUTP = BN + 4;                   // pool2 epilogue row pitch (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -683,10 +685,10 @@ struct SlabStage {
 
 // The input patch of one chunk from ONE directly stored source: patch pixel (py, px) = source pixel (y_org + py * 1, x_org + px),
 // zero outside the source; LDS rows at the padded pitch a.pwp.
-template <typename T, int NG, int PPF>
+template <typename T, int NG, int PPF, bool S2 = false>      // S2: fragment rows two patch pixels apart (conv_common.h pitch_bytes_s2)
 struct PatchStage {
     static constexpr int G = TT<T>::G, ES = TT<T>::ES, CK = NG * G;
-    static constexpr int PIXP = pitch_bytes(NG * 16);
+    static constexpr int PIXP = S2 ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
     int poff[PPF], plds[PPF];
     int ptotal;
     __amdgpu_buffer_rsrc_t rimg;
@@ -1022,6 +1024,10 @@ __global__ __launch_bounds__(NT, 2) void k_dgrad_up2(const ConvK a) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int CK = NG * G, NGR = 9 * NG, STEPS = (NGR + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4);
+    // (Round 4, measured and reverted: pitch_bytes_s2 here -- consecutive fragment rows are TWO dy pixels apart, 39-40 % of this
+    // kernel's LDS cycles are bank conflicts at the 96-byte pitch -- with the row padding the conflict model then asks for: up3 17.7
+    // -> 23.6 us at 16 frames, up4 / up3 52 -> 71 / 77 us at 64 frames.  The padded 80-byte patch crosses an LDS occupancy step at
+    // 16 frames (84.7 KB: one workgroup per CU instead of two) and is slower at equal occupancy too; not understood, not kept.)
     constexpr int PIXP = pitch_bytes(NG * 16);
     constexpr int NF = BN / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1488,7 +1494,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
 template <typename T, int BN, int NG, int DEPTH, bool TAIL, int NCH = 0, int NTH = 256>
 int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
-    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
+    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = TAIL ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
     const int S = k.g.stride;
     const int PH = (k.toh - 1) * S + 3;
     size_t lds = (size_t)BN * WROW + (size_t)PH * k.pwp * PIXP;

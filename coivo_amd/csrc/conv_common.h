@@ -113,6 +113,7 @@ struct WgradK {
     uint32_t m_pw, m_tow;     // see ConvK
     int nsplit, cot, xcd;     // 1-D grid: (co tile, chunk) fastest, pixel-range split slowest; XCD remap on/off
     int pwl;                  // LDS pitch of a patch row, in pixels (wgrad_row_pitch)
+    int det;                  // deterministic form with ONE split: plain read-modify-write instead of atomics (no slab)
     // Deterministic form (colvo_conv_wgrad_det): every pixel-range split STORES its sums into a slab of its own instead of
     // adding them to dw / db with float atomics; k_wgrad_reduce then adds the slabs in split order.  null: atomics.
     float* slabs;             // [nsplit][Cout * 9 * Ctot]
@@ -305,7 +306,8 @@ inline Tile pick_tile(int Ho, int Wo, int stride, bool even, int BM = 128, bool 
             continue;
         }
         for (int pad = 0; pad <= max_pad; ++pad) {
-            const double cf = patch_read_conflicts(toh, tow, pw + pad, stride, stride == 2 ? 5 : 6);
+            // (stride-2 forward patches, ext 3, are staged at pitch_bytes_s2 = 5 slots per pixel; k_dgrad_up2's dy patch, ext 4, keeps 6)
+            const double cf = patch_read_conflicts(toh, tow, pw + pad, stride, (stride == 2 && ext == 3) ? 5 : 6);
             const double cost = base * (1.0 + 0.2 * (cf - 1.0)) * (1.0 + 0.002 * pad);
             if (cost < best_cost) { best_cost = cost; best = Tile{toh, tow, pw + pad}; }
         }

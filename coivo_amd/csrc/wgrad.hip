@@ -52,13 +52,16 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     constexpr int NCOL = 9 * CK;                   // (tap, c) columns of this chunk
     constexpr int NFR = (NCOL + 15) / 16;          // column fragments
     constexpr int FPW = (NFR + 3) / 4;             // fragments per wave
-    constexpr int PIXP = pitch_bytes(NG * 16);
+    // patch-pixel pitch: TAIL instantiations are the stride-2 layers (a stride-1 patch of <= 128 outputs never exceeds 3 x 256
+    // granules), where consecutive K positions are TWO patch pixels apart: conv_common.h pitch_bytes_s2
+    constexpr int PIXP = TAIL ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
     constexpr int DYP = dy_pitch<T, MT>();         // dY row pitch (bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef COLVO_WTRACE
     // developer build: shader-clock stamps taken right behind barriers only (a stamp is a scalar memory read: anywhere else its
     // lgkmcnt wait would drain the LDS reads it is meant to observe)
     long long wt_start = (long long)clock64(), wt_first = 0, wt_store = 0, wt_compute = 0, wt_b1 = 0, wt_b2 = 0, wt_loop_end = 0, wt_flush = 0;
+    long long wt_issue = 0, wt_mfma = 0, wt_m0 = 0, wt_m1 = 0;        // inside `compute`: load issue (+ bias sums) | MFMA phase | the rest = barrier wait
     long long wt_wall0 = (long long)wall_clock64();
 #define WT_STAMP(x) x = (long long)clock64()
 #else
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
     const int S = a.g.stride;
     const int PH = (a.toh - 1) * S + 3, PW = (a.tow - 1) * S + 3;
     const int npix = a.toh * a.tow;
-    const int stage = (BM * DYP + PH * PW * PIXP + 15) & ~15;    // one team's staging buffers
+    const int PWL = a.pwl;                          // LDS pitch of a patch row in pixels (>= PW: conv_common.h wgrad_row_pitch)
+    const int stage = (BM * DYP + PH * PWL * PIXP + 15) & ~15;    // one team's staging buffers
     char* sDY = smem + team * stage;               // [BM][16*MT]
     char* sX = sDY + BM * DYP;                     // patch
 
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         const int ncol_addr = 16 * f + ((ES == 2) ? 4 * (lane & 3) : l15);
         int tap = min(ncol_addr / CK, 8);
         const int c = ncol_addr - (ncol_addr / CK) * CK;
-        boff[fi] = ((tap / 3) * PW + (tap % 3)) * PIXP + c * ES;
+        boff[fi] = ((tap / 3) * PWL + (tap % 3)) * PIXP + c * ES;
         const int ncol = 16 * f + l15;
         ocol[fi] = (f < NFR && ncol < NCOL) ? ((ncol / CK) * a.Ctot + (ncol % CK)) : -1;
     }
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         dy_yx[it] = (oy << 16) | ox;
         dy_lds[it] = pp_ * DYP + gch * 16;
     }
-    int p_yx[PPF], p_cg[PPF];                              // (py << 16 | px) inside the patch (py = 0x7fff: none), granule
+    int p_yx[PPF], p_cg[PPF], p_lds[PPF];                  // (py << 16 | px) inside the patch (py = 0x7fff: none), granule, LDS offset
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         const int i = it * NT + tid;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         p_cg[it] = i - pix * NG;
         const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
         p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
+        p_lds[it] = (py * PWL + px) * PIXP + p_cg[it] * 16;
     }
     // `live`: false for a team whose tile index ran past the workgroup's range (it still takes part in the barriers; its
     // loads are out of range and stage zeros)
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
+            if (i < ptotal) st16(sX + p_lds[it], pv[it]);
         }
         // patches larger than PPF*256 granules (stride-2 tiles): the rest is staged in place, 3 loads in flight
         const int base = live ? c.b * Hs * Ws * Cs * ES : 0;
@@ -209,18 +214,18 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         if constexpr (TAIL)
         for (int g0 = PPF * NT; g0 < ptotal; g0 += 3 * NT) {
             u32x4 tt[3];
+            int tl[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int i = g0 + u * NT + tid;
                 const int pix = i / NG, cg = i - pix * NG;
                 const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
                 tt[u] = bld16(rx, ((i < ptotal) ? patch_voff(c, (py << 16) | px, cg) : OOB_OFF) | dead, base);
+                tl[u] = (py * PWL + px) * PIXP + cg * 16;
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int i = g0 + u * NT + tid;
-                if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, tt[u]); }
-            }
+            for (int u = 0; u < 3; ++u)
+                if (g0 + u * NT + tid < ptotal) st16(sX + tl[u], tt[u]);
         }
     };
     // bias gradient: all 256 threads, thread = (channel, pixel phase); NPH partial sums per channel meet in the atomics
@@ -261,11 +266,21 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
             dbacc += s0 + s1;
         }
 
+#ifdef COLVO_WTRACE
+        WT_STAMP(wt_m0);
+        wt_issue += wt_m0 - wt_b2;
+#endif
         if constexpr (ES == 2) {
-            // K = 128 pixels in 4 steps of 32; fragments by hardware-transposed LDS reads
+            // K = 128 pixels in 4 steps of 32; fragments by hardware-transposed LDS reads.
+            // (Round 4, measured and not kept: ALL fragments of step ks+1 requested into a second register set before the MFMAs of
+            // step ks, pinned with scheduling barriers -- hipcc alone keeps one fragment pair of look-ahead.  The listing shows the
+            // pipeline (28 reads, wait, 10 MFMAs, 14 reads, ...), the in-kernel stamps show no gain: 0.83-0.96 us per 128-pixel tile
+            // before, 0.95-1.07 with the form held to 168 registers (3 spills), the stack's total 513 -> 508 us without that bound at
+            // 176 registers = two instead of three waves per SIMD.  The tile's 1900 cycles are not LDS latency: 640 are MFMA issue,
+            // ~500 the VALU address arithmetic between them (4 cycles an instruction), the rest barrier skew and the first k-step's
+            // round trip.  The four-class kernel below, with 16 MFMAs per step, does gain from it and keeps it.)
             const int q = l15 >> 2, pp = lane & 3;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            auto read_step = [&](int ks, s16x8 (&af)[MT], s16x8 (&bfv)[FPW]) {
                 int xo[2], yo[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -279,9 +294,8 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
                     yo[h] = p * DYP;
                     if (p >= npix) p = 0;     // its dY row is zero
                     const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-                    xo[h] = ((oy * S) * PW + ox * S) * PIXP;
+                    xo[h] = ((oy * S) * PWL + ox * S) * PIXP;
                 }
-                s16x8 af[MT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -296,12 +310,19 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
                         (__attribute__((address_space(3))) s16x4*)(sX + xo[0] + boff[fi]));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                         (__attribute__((address_space(3))) s16x4*)(sX + xo[1] + boff[fi]));
-                    const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    bfv[fi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            };
+            s16x8 af[MT], bfv[FPW];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                read_step(ks, af, bfv);
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi)
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
                         acc[mi][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf), acc[mi][fi], 0, 0, 0);
-                }
+                            __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bfv[fi]), acc[mi][fi], 0, 0, 0);
             }
         } else {
             // K = 128 pixels in 32 steps of 4 (exact f32 MFMA 16x16x4); lane k-slot = kg
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
             int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
             for (int ks = 0; ks < BM / 4; ++ks) {
                 const bool live = p < npix;
-                const int xo = live ? ((oy * S) * PW + ox * S) * PIXP : 0;
+                const int xo = live ? ((oy * S) * PWL + ox * S) * PIXP : 0;
                 float av[MT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
@@ -325,6 +346,11 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
                 while (ox >= a.tow) { ox -= a.tow; ++oy; }
             }
         }
+#ifdef COLVO_WTRACE
+        asm volatile("" ::: "memory");
+        WT_STAMP(wt_m1);
+        wt_mfma += wt_m1 - wt_m0;
+#endif
     }
 
     mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * FPW]>(acc));
@@ -357,22 +383,43 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         }
     }
     if (team == 0) {
-        // one fp32 atomic per element: D rows = co (4*kg + r), cols = (tap, c)
+        // D rows = co (4*kg + r), cols = (tap, c).  Three ways out: one fp32 atomic per element (a.det == 0); deterministic form with
+        // several splits: this split's own slab; deterministic form with ONE split = this workgroup is the only writer of its
+        // elements: plain read-modify-write, all loads in flight before the first store (40 dependent load -> store round trips
+        // otherwise) -- no slab, no second launch.  (Against the atomics the read-modify-write measured 1 us SLOWER, enc5b 25.6 ->
+        // 26.7 us: the loads miss the XCD's L2, the atomics are fire-and-forget; so it serves the deterministic form only.)
+        auto elem = [&](int mi, int fi, int r, size_t& e) -> bool {
+            const int co = co0 + 16 * mi + 4 * kg + r;
+            e = (size_t)co * 9 * a.Ctot + wc0 + ocol[fi];
+            return ocol[fi] >= 0 && co < a.Cout;
+        };
+        if (!a.slabs && a.det) {
+            float old[MT][FPW][4];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int fi = 0; fi < FPW; ++fi) {
-                if (ocol[fi] < 0) continue;
+                for (int fi = 0; fi < FPW; ++fi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + 16 * mi + 4 * kg + r;
-                    if (co < a.Cout) {
-                        const size_t e = (size_t)co * 9 * a.Ctot + wc0 + ocol[fi];
+                    for (int r = 0; r < 4; ++r) { size_t e; old[mi][fi][r] = elem(mi, fi, r, e) ? a.dw[e] : 0.0f; }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { size_t e; if (elem(mi, fi, r, e)) a.dw[e] = old[mi][fi][r] + acc[mi][fi][r]; }
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        size_t e;
+                        if (!elem(mi, fi, r, e)) continue;
                         if (a.slabs) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e] = acc[mi][fi][r];   // this split's own slab
                         else atomicAdd(a.dw + e, acc[mi][fi][r]);
                     }
-                }
-            }
+        }
     }
     if (bchunk == 0 && a.db) {                           // fold the NPH pixel phases (of every team) in LDS: one atomic per channel
         __syncthreads();
@@ -383,6 +430,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 #pragma unroll
             for (int ph = 0; ph < NPH * KS; ++ph) t += sdb[ph * 16 * MT + tid];
             if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else if (a.det) a.db[co0 + tid] += t;
             else atomicAdd(a.db + co0 + tid, t);
         }
     }
@@ -392,9 +440,10 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
         __syncthreads();
         WT_STAMP(wt_flush);
         if (threadIdx.x == 0) {
-            long long* r = a.trace + (size_t)blockIdx.x * 8;
+            long long* r = a.trace + (size_t)blockIdx.x * 16;
             r[0] = wt_start; r[1] = wt_first - wt_start; r[2] = wt_store; r[3] = wt_compute; r[4] = wt_flush - wt_loop_end;
             r[5] = wt_flush - wt_start; r[6] = (long long)wall_clock64() - wt_wall0; r[7] = (t_end - t_begin + KS - 1) / KS;
+            r[8] = wt_issue; r[9] = wt_mfma;
         }
     }
 #endif
@@ -434,27 +483,29 @@ static int g_wtrace_calls = 0;
 inline void wtrace_begin(WgradK& k, unsigned nwg, hipStream_t s) {
     k.trace = nullptr;
     if (!getenv("COLVO_WTRACE") || nwg > (1u << 14)) return;
-    if (!g_wtrace) (void)hipMalloc(&g_wtrace, (size_t)(1u << 14) * 8 * sizeof(long long));
-    (void)hipMemsetAsync(g_wtrace, 0, (size_t)nwg * 8 * sizeof(long long), s);
+    if (!g_wtrace) (void)hipMalloc(&g_wtrace, (size_t)(1u << 14) * 16 * sizeof(long long));
+    (void)hipMemsetAsync(g_wtrace, 0, (size_t)nwg * 16 * sizeof(long long), s);
     k.trace = g_wtrace;
 }
 inline void wtrace_end(const WgradK& k, unsigned nwg, int MT, int NG, bool tail, int ks, hipStream_t s) {
     if (!k.trace || (++g_wtrace_calls % atoi(getenv("COLVO_WTRACE"))) != 0) return;
     (void)hipStreamSynchronize(s);
-    std::vector<long long> h((size_t)nwg * 8);
+    std::vector<long long> h((size_t)nwg * 16);
     (void)hipMemcpy(h.data(), g_wtrace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-    double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double m[16] = {0};
     long long t0 = h[0], t1 = 0;
     for (unsigned i = 0; i < nwg; ++i) {
-        for (int j = 1; j < 8; ++j) m[j] += (double)h[(size_t)i * 8 + j] / nwg;
-        t0 = std::min(t0, h[(size_t)i * 8]); t1 = std::max(t1, h[(size_t)i * 8] + h[(size_t)i * 8 + 5]);
+        for (int j = 1; j < 16; ++j) m[j] += (double)h[(size_t)i * 16 + j] / nwg;
+        t0 = std::min(t0, h[(size_t)i * 16]); t1 = std::max(t1, h[(size_t)i * 16] + h[(size_t)i * 16 + 5]);
     }
     const double cyc_per_us = m[6] > 0 ? m[5] / (m[6] * 0.01) : 0.0;       // shader clocks per microsecond (wall clock: 100 MHz)
+    const double nt = std::max(1.0, m[7]);
     fprintf(stderr, "[wtrace] MT=%d NG=%d tail=%d KS=%d S=%d Cout=%d Ctot=%d %dx%d tile %dx%d grid=%u nsplit=%d tiles/wg %.1f | clock %.0f MHz | "
-            "span %.2f us | mean wg (us): life %.2f = setup+first-load %.2f + store %.2f + compute %.2f + flush %.2f | per tile: store %.3f compute %.3f\n",
+            "mean wg (us): life %.2f = setup+first-load %.2f + store %.2f + compute %.2f + flush %.2f | per tile: store %.3f compute %.3f = "
+            "load issue %.3f + MFMA phase %.3f + barrier wait %.3f\n",
             MT, NG, (int)tail, ks, k.g.stride, k.Cout, k.Ctot, k.Ho, k.Wo, k.toh, k.tow, nwg, k.nsplit, m[7], cyc_per_us,
-            cyc_per_us > 0 ? (t1 - t0) / cyc_per_us : 0.0, m[5] / cyc_per_us, m[1] / cyc_per_us, m[2] / cyc_per_us, m[3] / cyc_per_us,
-            m[4] / cyc_per_us, m[2] / cyc_per_us / std::max(1.0, m[7]), m[3] / cyc_per_us / std::max(1.0, m[7]));
+            m[5] / cyc_per_us, m[1] / cyc_per_us, m[2] / cyc_per_us, m[3] / cyc_per_us, m[4] / cyc_per_us, m[2] / cyc_per_us / nt,
+            m[3] / cyc_per_us / nt, m[8] / cyc_per_us / nt, m[9] / cyc_per_us / nt, (m[3] - m[8] - m[9]) / cyc_per_us / nt);
 }
 #endif
 
@@ -464,7 +515,10 @@ inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
     *err = 0;
     if (k.plan_out) { *k.plan_out = nsplit; return true; }
     k.slabs = nullptr; k.db_slabs = nullptr;
-    if (k.scratch) {
+    // deterministic form with one split: every weight element has exactly one writer, which adds to dw / db with a plain
+    // read-modify-write -- reproducible without slabs or a second launch
+    k.det = (k.scratch && nsplit == 1) ? 1 : 0;
+    if (k.scratch && nsplit > 1) {
         const long long wsize = (long long)k.Cout * 9 * k.Ctot;
         const long long need = (long long)nsplit * (wsize + k.Cout) * 4;
         if (need > k.scratch_bytes) {
@@ -492,11 +546,11 @@ inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
 template <typename T, int MT, int NG, bool TAIL, int KS>
 int launch_wgrad_teams(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G;
-    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
+    constexpr int CK = NG * G, PIXP = TAIL ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     constexpr int NFR = (9 * CK + 15) / 16, FPW = (NFR + 3) / 4;
     const int S = k.g.stride;
-    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
-    const size_t stage = ((size_t)BM * DYP + (size_t)PH * PW * PIXP + 15) & ~(size_t)15;
+    const int PH = (k.toh - 1) * S + 3;
+    const size_t stage = ((size_t)BM * DYP + (size_t)PH * k.pwl * PIXP + 15) & ~(size_t)15;
     const size_t lds = std::max(stage * KS, (size_t)MT * FPW * NT * 16 + (size_t)NT * KS * 4) + 64;   // staging | exchange slab + db
     COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad: %d teams need %zu bytes of LDS", KS, lds);
     static size_t configured = 0;
@@ -533,9 +587,9 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
 template <typename T, int MT, int NG, bool TAIL>
 int launch_wgrad_tail(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G;
-    constexpr int CK = NG * G, PIXP = pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
+    constexpr int CK = NG * G, PIXP = TAIL ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16), DYP = dy_pitch<T, MT>();
     const int S = k.g.stride;
-    const int PH = (k.toh - 1) * S + 3, PW = (k.tow - 1) * S + 3;
+    const int PH = (k.toh - 1) * S + 3, PW = k.pwl;
     {
         // Teams pay only on the two full-resolution layers (16 output channels: a one-fragment co tile, so the exchange is
         // 20 KB per team, and one or two slabs in the (co tile, channel chunk) grid, so 256 workgroups walk 40-80 tiles each).
@@ -626,9 +680,10 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
     const int co0 = bco * 16 * MT;
     const int c0 = bchunk * CK;                      // single source: channel offset = weight column offset
     const int PH = a.toh + 2, PW = a.tow + 2;        // patch of SOURCE pixels: tile + 1 each side
+    const int PWL = a.pwl;                           // its LDS row pitch in pixels (conv_common.h wgrad_row_pitch)
     const int npix = a.toh * a.tow;
     char* sDY = smem;                                // [4 classes][BM][16 MT]
-    char* sX = smem + 4 * BM * DYP;                  // [PH * PW][CK]
+    char* sX = smem + 4 * BM * DYP;                  // [PH][PWL][CK]
 
     f32x4 acc[MT][NACC];
 #pragma unroll
@@ -674,7 +729,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
         dy_yx[it] = (oy << 16) | ox;
         dy_lds[it] = (c4 * BM + pos) * DYP + gch * 16;
     }
-    int p_yx[PPF], p_cg[PPF];
+    int p_yx[PPF], p_cg[PPF], p_lds[PPF];
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         const int i = it * NT + tid;
@@ -682,6 +737,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
         p_cg[it] = i - pix * NG;
         const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
         p_yx[it] = (i < ptotal) ? ((py << 16) | px) : (0x7fff << 16);
+        p_lds[it] = (py * PWL + px) * PIXP + p_cg[it] * 16;
     }
     auto load_tile = [&](const TileC& c) {
         const int oy0 = c.ty * a.toh, ox0 = c.tx * a.tow;
@@ -716,10 +772,8 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 #pragma unroll
         for (int it = 0; it < DIT; ++it) st16(sDY + dy_lds[it], dyv[it]);
 #pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            if (i < ptotal) { const int pix = i / NG, cg = i - pix * NG; st16(sX + pix * PIXP + cg * 16, pv[it]); }
-        }
+        for (int it = 0; it < PPF; ++it)
+            if (it * NT + tid < ptotal) st16(sX + p_lds[it], pv[it]);
         __syncthreads();
         tile_next(cur);
         if (t + 1 < t_end) load_tile(cur);             // in flight during the MFMAs below
@@ -736,9 +790,9 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 
         const char* sDYc = sDY + cls * BM * DYP;
         if constexpr (ES == 2) {
+            // software pipeline over the k-steps as in k_wgrad3x3: the fragments of step ks+1 are in flight during the MFMAs of step ks
             const int q = l15 >> 2, pp = lane & 3;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            auto read_step = [&](int ks, s16x8 (&af)[MT], s16x8 (&bfv)[NACC]) {
                 int xo[2], yo[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -746,9 +800,8 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
                     yo[h] = p * DYP;
                     if (p >= npix) p = 0;                                              // its dY rows are zero
                     const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-                    xo[h] = ((oy + cpy) * PW + ox + cpx) * PIXP;                       // source tap (0, 0) of this class
+                    xo[h] = ((oy + cpy) * PWL + ox + cpx) * PIXP;                      // source tap (0, 0) of this class
                 }
-                s16x8 af[MT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -761,22 +814,32 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
                 for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
                     for (int f = 0; f < NCF; ++f) {
-                        const int bo = ((tp >> 1) * PW + (tp & 1)) * PIXP + (16 * f + 4 * pp) * 2;
+                        const int bo = ((tp >> 1) * PWL + (tp & 1)) * PIXP + (16 * f + 4 * pp) * 2;
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + bo));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + bo));
-                        const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi)
-                            acc[mi][tp * NCF + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf), acc[mi][tp * NCF + f], 0, 0, 0);
+                        bfv[tp * NCF + f] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     }
+            };
+            s16x8 af[2][MT], bfv[2][NACC];
+            read_step(0, af[0], bfv[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) read_step(ks + 1, af[(ks + 1) & 1], bfv[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int qq = 0; qq < NACC; ++qq)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        acc[mi][qq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, af[ks & 1][mi]), __builtin_bit_cast(bf16x8, bfv[ks & 1][qq]), acc[mi][qq], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             int p = kg;
             int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
             for (int ks = 0; ks < BM / 4; ++ks) {
                 const bool live = p < npix;
-                const int xo = live ? ((oy + cpy) * PW + ox + cpx) * PIXP : 0;
+                const int xo = live ? ((oy + cpy) * PWL + ox + cpx) * PIXP : 0;
                 float av[MT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) av[mi] = *reinterpret_cast<const float*>(sDYc + p * DYP + (16 * mi + l15) * 4);
@@ -784,7 +847,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
                 for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
                     for (int f = 0; f < NCF; ++f) {
-                        const float bvv = *reinterpret_cast<const float*>(sX + xo + ((tp >> 1) * PW + (tp & 1)) * PIXP + (16 * f + l15) * 4);
+                        const float bvv = *reinterpret_cast<const float*>(sX + xo + ((tp >> 1) * PWL + (tp & 1)) * PIXP + (16 * f + l15) * 4);
 #pragma unroll
                         for (int mi = 0; mi < MT; ++mi)
                             acc[mi][tp * NCF + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bvv, acc[mi][tp * NCF + f], 0, 0, 0);
@@ -796,43 +859,57 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
     }
 
     mfma_result_guard<T>(reinterpret_cast<f32x4 (&)[MT * NACC]>(acc));
-    // ---- the four classes meet: red[tap][co][c] += dW'[class][r][c'] for every tap the entry stands for, one wave at a time ----
+    // ---- the four classes meet ----
+    // Every wave stores its 16 dW' blocks [class][source tap r, c][co][ci] to LDS with plain conflict-free 16-byte stores (its
+    // accumulators as they are: lane-major), all four at once; then all 256 threads gather: dw[ky][kx][co][ci] = sum over the four
+    // classes of dW'[class][rho(py, ky)][rho(px, kx)][co][ci] -- four reads per output element, reading lane-major again.  (Round 3
+    // added each block to the taps it stands for with LDS read-modify-writes, one wave at a time behind a zero-fill pass: 144
+    // two-way-conflicting RMWs per lane, four times in a row -- a third of the kernel's LDS bank conflicts and ~3 us of a 30 us launch.)
     __syncthreads();                                   // staging buffers are free
-    float* red = reinterpret_cast<float*>(smem);       // [9][16 MT][CK]
-    constexpr int RED = 9 * 16 * MT * CK;
-    for (int i = tid; i < RED; i += NT) red[i] = 0.0f;
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-        if (cls == w) {
+    f32x4* sEx = reinterpret_cast<f32x4*>(smem);       // [class][tp][mi][f][lane]
+    {
+        f32x4* mine = sEx + (size_t)cls * 4 * MT * NCF * 64;
 #pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                const int r = tp >> 1, c = tp & 1;
-                // taps whose source offset is (r, c) for this class: rows {0} | {1, 2} for py = 0, {0, 1} | {2} for py = 1
-                const int ky_lo = cpy == 0 ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), ky_hi = cpy == 0 ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
-                const int kx_lo = cpx == 0 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kx_hi = cpx == 0 ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
-                for (int ky = ky_lo; ky <= ky_hi; ++ky)
-                    for (int kx = kx_lo; kx <= kx_hi; ++kx) {
-                        float* rt = red + (size_t)(ky * 3 + kx) * 16 * MT * CK;
+        for (int tp = 0; tp < 4; ++tp)
 #pragma unroll
-                        for (int mi = 0; mi < MT; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                            for (int f = 0; f < NCF; ++f)
-#pragma unroll
-                                for (int rr = 0; rr < 4; ++rr)
-                                    rt[(16 * mi + 4 * kg + rr) * CK + 16 * f + l15] += acc[mi][tp * NCF + f][rr];
-                    }
-            }
-        }
-        __syncthreads();
+                for (int f = 0; f < NCF; ++f) mine[((tp * MT + mi) * NCF + f) * 64 + lane] = acc[mi][tp * NCF + f];
     }
-    for (int i = tid; i < RED; i += NT) {
-        const int tap = i / (16 * MT * CK), rem = i - tap * (16 * MT * CK);
-        const int col = rem / CK, c = rem - col * CK;
-        const int co = co0 + col;
-        if (co < a.Cout) {
-            const size_t e = (size_t)co * 9 * a.Ctot + (size_t)tap * a.Ctot + c0 + c;
-            if (a.slabs) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e] = red[i];
-            else atomicAdd(a.dw + e, red[i]);
+    __syncthreads();
+    // output block (tap, mi, f): lane (l15, kg) holds rows co = 16 mi + 4 kg + r, column ci = 16 f + l15, exactly the accumulator
+    // layout; wave w takes the blocks w, w + 4, ...
+    // rho(0, k) = (0, 1, 1)[k], rho(1, k) = (0, 0, 1)[k]: the source-tap row / column that tap index k falls on for parity 0 / 1
+    constexpr int NBLK = 9 * MT * NCF;
+    for (int blk = cls; blk < NBLK; blk += 4) {
+        const int tap = blk / (MT * NCF), rem = blk - tap * (MT * NCF);
+        const int mi = rem / NCF, f = rem - mi * NCF;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int py = c4 >> 1, px = c4 & 1;
+            const int r = py == 0 ? (ky >= 1) : (ky >= 2), c = px == 0 ? (kx >= 1) : (kx >= 2);
+            sum += sEx[(((size_t)c4 * 4 + (r * 2 + c)) * MT + mi) * NCF * 64 + f * 64 + lane];
+        }
+        const size_t e0 = (size_t)(co0 + 16 * mi + 4 * kg) * 9 * a.Ctot + (size_t)tap * a.Ctot + c0 + 16 * f + l15;
+        const size_t erow = (size_t)9 * a.Ctot;
+        const int nrow = min(4, a.Cout - (co0 + 16 * mi + 4 * kg));       // rows of this lane inside the tensor (<= 0: none)
+        if (a.slabs) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (rr < nrow) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e0 + rr * erow] = sum[rr];
+        } else if (a.det) {                 // deterministic form, one split = sole writer: plain read-modify-write, loads first
+            float old[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) old[rr] = rr < nrow ? a.dw[e0 + rr * erow] : 0.0f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (rr < nrow) a.dw[e0 + rr * erow] = old[rr] + sum[rr];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (rr < nrow) atomicAdd(a.dw + e0 + rr * erow, sum[rr]);
         }
     }
     if (bchunk == 0 && a.db) {
@@ -845,6 +922,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
             if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else if (a.det) a.db[co0 + tid] += t;
             else atomicAdd(a.db + co0 + tid, t);
         }
     }
@@ -853,7 +931,8 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 template <typename T, int MT>
 int launch_wgrad_up2(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G, CK = 4 * G, PIXP = pitch_bytes(64), DYP = dy_pitch<T, MT>();
-    const size_t lds = std::max((size_t)4 * BM * DYP + (size_t)(k.toh + 2) * (k.tow + 2) * PIXP, (size_t)9 * 16 * MT * CK * 4) + 64;
+    // staging buffers | the class exchange: 4 classes x 4 source taps x MT x CK/16 accumulator blocks of 64 lanes x 16 bytes
+    const size_t lds = std::max((size_t)4 * BM * DYP + (size_t)(k.toh + 2) * k.pwl * PIXP, (size_t)16 * MT * (CK / 16) * 64 * 16) + 64;
     COLVO_CHECK_ARG(lds <= 160 * 1024, "wgrad (up-sampled source): tile needs %zu bytes of LDS", lds);
     static size_t configured = 0;
     if (lds > 48 * 1024 && lds > configured && !k.plan_out) {
@@ -996,6 +1075,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
                 k.tiles_x = (Ws + t.tow - 1) / t.tow; k.tiles_y = (Hs + t.toh - 1) / t.toh;
                 k.ntiles = d->B * k.tiles_x * k.tiles_y;
                 k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic(t.tow + 2);
+                k.pwl = wgrad_row_pitch(t.tow + 2, t.tow);
                 hipStream_t s = (hipStream_t)stream;
                 const bool wide = d->Cout >= 32;
                 if (d->dtype == COLVO_F32) return wide ? launch_wgrad_up2<float, 2>(k, s) : launch_wgrad_up2<float, 1>(k, s);
@@ -1008,6 +1088,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
     k.tiles_x = (d->Wo + t.tow - 1) / t.tow; k.tiles_y = (d->Ho + t.toh - 1) / t.toh;
     k.ntiles = d->B * k.tiles_x * k.tiles_y;
     k.m_tow = mdiv_magic(t.tow); k.m_pw = mdiv_magic((t.tow - 1) * d->stride + 3);
+    k.pwl = wgrad_row_pitch((t.tow - 1) * d->stride + 3, t.tow);
     return d->dtype == COLVO_F32 ? launch_wgrad_t<float>(k, (hipStream_t)stream)
                                  : launch_wgrad_t<bf16_t>(k, (hipStream_t)stream);
 }

@@ -38,9 +38,15 @@ class GraphedTrainStep:
     colvo_set_capture_carry); off: every pass ends joined (the round-3 form)."""
 
     def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
-                 warmup: int = 2, capture_policy: int = 2, capture_group: int = 2, full_loss: bool = False, carry: bool = True):
+                 warmup: int = 2, capture_policy: int = 2, capture_group: Optional[int] = None, full_loss: bool = False,
+                 carry: bool = True):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
+        # segments of the weight-gradient chain: one command each from 32 pairs on (the eager schedule node for node: replay 7.35
+        # vs eager 7.35 ms at 64 pairs, 7.26 vs 7.11 with segments of two), two below (1.50 vs 1.55 ms at 8 pairs) -- a cross-chain
+        # edge costs a fixed ~1-2 us, a delayed weight gradient costs in proportion to the kernels (DESIGN.md section 3.4)
+        if capture_group is None:
+            capture_group = 1 if B >= 32 else 2
         self.capture_policy, self.capture_group, self.carry = int(capture_policy), int(capture_group), bool(carry)
         self.B, self.ssim_weight, self.full_loss = B, ssim_weight, bool(full_loss)
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
@@ -86,12 +92,14 @@ class GraphedTrainStep:
         self.opt.use_device_step_counter()          # a captured host-side step number would repeat at every replay
         snap_p = [n.flat_param.clone() for n in nets]
         snap_o = [{k: v.clone() for k, v in st.items()} for st in self.opt.state]
-        side = torch.cuda.Stream(device=self.frames.device)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(self._warmup):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
+        # Warm-up ON THE CALLER'S STREAM, not on a stream made for the purpose (round 4).  The runtime deals streams onto its (default
+        # four) hardware queues in creation order: with a warm-up stream created first, the networks' weight-gradient streams and the
+        # library's auxiliary stream -- created inside the first step -- wrapped around onto the queue of the stream the caller runs
+        # eager steps on, and every eager step after a capture took 4.4 ms instead of 1.45 (tools/probe_eager_after_capture.py
+        # --capture-first).  Created from the caller's stream they land where a plain eager loop puts them:
+        # eager steps before, between and after replays run at their usual rate (tests/test_graph_gpu.py).
+        for _ in range(self._warmup):
+            self._step()
         torch.cuda.synchronize()
 
         def restore():

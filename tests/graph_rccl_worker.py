@@ -1,0 +1,79 @@
+"""Worker for tests/test_graph_gpu.py::test_graphed_step_with_rccl_single_rank: ONE process per gradient-transport dtype.
+The hipGraph-captured data-parallel step (RCCL, one rank) against the eager data-parallel step and against the step without any
+process group, in deterministic mode: bit for bit.  Its own process: the HIP runtime ends a failed stream capture with abort(), which
+must not take the test session down with it, and a process group is process-global state."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    transport = {"f32": None, "bf16": torch.bfloat16}[sys.argv[1]]
+    from coivo_amd import nn as hnn
+    from coivo_amd import synth
+    from coivo_amd.ddp import GradBuckets
+    from coivo_amd.graph import GraphedTrainStep
+    from coivo_amd.optim import FusedAdam
+    from oracle import colvo_spec as S
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+    def setup(seed):
+        dn_o, pn_o = S.make_models(seed)
+        dn, pn = hnn.DepthNet(compute_dtype=torch.bfloat16), hnn.PoseNet(compute_dtype=torch.bfloat16)
+        dn.load_state_dict(dn_o.state_dict())
+        pn.load_state_dict(pn_o.state_dict())
+        dn.deterministic = pn.deterministic = True
+        return dn, pn, FusedAdam([dn, pn], lr=1e-4)
+
+    B, H, W, seed = 2, 64, 96, 63
+    b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.make_batch(B, H, W, seed=seed).items()}
+    frames = torch.cat([b["tgt"], b["ref"]])
+    dn1, pn1, opt1 = setup(seed)
+    dn2, pn2, opt2 = setup(seed)
+    ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport)
+    ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport)
+    step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
+    eager, graphed = [], []
+    for _ in range(3):
+        opt1.zero_grad()
+        loss = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"])[0]
+        loss.backward()
+        ddp1.finish()
+        opt1.step()
+        eager.append(loss.item())
+        graphed.append(step(frames, b["K"]).item())
+    torch.cuda.synchronize()
+    assert eager == graphed, (sys.argv[1], eager, graphed)
+    assert torch.equal(dn1.flat_param, dn2.flat_param) and torch.equal(pn1.flat_param, pn2.flat_param), sys.argv[1]
+    assert graphed[-1] < graphed[0]
+    st = step.stats
+    assert st["pending_commands"] == 0 and st["side_commands"] == 28, st
+    if transport is None:
+        # ... and the fp32-transport run is bitwise the run WITHOUT any process group (a one-rank all-reduce is the identity)
+        dn3, pn3, opt3 = setup(seed)
+        for _ in range(3):
+            opt3.zero_grad()
+            hnn.dcdp_forward(dn3, pn3, b["tgt"], b["ref"], b["K"])[0].backward()
+            opt3.step()
+        torch.cuda.synchronize()
+        assert torch.equal(dn1.flat_param, dn3.flat_param) and torch.equal(pn1.flat_param, pn3.flat_param)
+    ddp1.detach()
+    ddp2.detach()
+    torch.cuda.synchronize()
+    print(f"GRAPH_RCCL_OK {sys.argv[1]} losses {graphed}", flush=True)
+    sys.stdout.flush()
+    # leave without tearing the communicator / the graph down piece by piece: the process is done
+    os._exit(0)
+
+
+if __name__ == "__main__":
+    main()

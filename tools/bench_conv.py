@@ -66,7 +66,9 @@ def main():
         gf = 2.0 * cout * cin * 9 * d.Ho * d.Wo * b / 1e9
         tf = timeit(lambda: ops.conv_fwd(d, x0, x1, wf, bias, y))
         td = 1.0 if fwdonly else timeit(lambda: ops.conv_dgrad(d, 0, dy, wb, x0, dx, False))
-        tw = 1.0 if fwdonly else timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db))
+        # CONV_BENCH_DET=1: the deterministic form (per-split slabs + the per-layer reduce launch) instead of float atomics
+        scr = ops.conv_wgrad_scratch(d, dev) if os.environ.get("CONV_BENCH_DET") else None
+        tw = 1.0 if fwdonly else timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db, scr))
         gd = gf * c0 / cin
         tot[0] += tf; tot[1] += td; tot[2] += tw
         gsum[0] += gf; gsum[1] += gd; gsum[2] += gf

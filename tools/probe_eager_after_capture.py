@@ -30,6 +30,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--mark", action="store_true")
     ap.add_argument("--carry", type=int, default=1)
+    ap.add_argument("--policy", type=int, default=2)
+    ap.add_argument("--group", type=int, default=2)
+    ap.add_argument("--capture-first", action="store_true", help="capture before ANY eager step has run in the process (bench.py --graph on)")
+    ap.add_argument("--only-eager", action="store_true", help="time eager steps in a fresh process and stop")
     args = ap.parse_args()
     from coivo_amd import build
     build.ensure()
@@ -79,8 +83,13 @@ def main():
         return ms
 
     r = {}
-    r["eager0"] = timed("eager0", eager)
-    step = GraphedTrainStep(dn, pn, opt, B, H, W, carry=bool(args.carry))
+    if not args.capture_first:
+        r["eager0"] = timed("eager0", eager)
+    if args.only_eager:
+        import json
+        print("PROBE_JSON " + json.dumps({k: round(v, 4) for k, v in r.items()}))
+        return
+    step = GraphedTrainStep(dn, pn, opt, B, H, W, carry=bool(args.carry), capture_policy=args.policy, capture_group=args.group)
     step.frames.copy_(frames)
     step.K.copy_(K)
     step.capture()
@@ -97,7 +106,8 @@ def main():
     for net in (dn, pn):
         net._side = None
     r["eager_new_side"] = timed("eager_new_side", eager)
-    print({k: round(v, 3) for k, v in r.items()})
+    import json
+    print("PROBE_JSON " + json.dumps({k: round(v, 4) for k, v in r.items()}))
 
 
 if __name__ == "__main__":
