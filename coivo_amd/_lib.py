@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -28,6 +28,13 @@ class AdamArena(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t)]
 
 
+class WgradSlabs(C.Structure):
+    """Mirror of ColvoWgradSlabs (include/colvo.h)."""
+    _fields_ = [("scratch", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nsplit", C.c_int32), ("Cout", C.c_int32),
+                ("Ctot", C.c_int32), ("pad_", C.c_int32)]
+
+
+WGRAD_GROUP_MAX = 16
 MAX_ARENAS = 4
 ADAM_PLAIN_PER_WG = 2048          # COLVO_ADAM_PLAIN_PER_WG
 
@@ -41,7 +48,7 @@ class Cmd(C.Structure):
 
 (CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
  CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN,
- CMD_DEPTH_HEAD_BWD_PARTS, CMD_CONV_DGRAD_BOTH) = range(1, 15)
+ CMD_DEPTH_HEAD_BWD_PARTS, CMD_CONV_DGRAD_BOTH, CMD_WGRAD_REDUCE_GROUP, CMD_CONV_DGRAD_PLANES, CMD_SIDE_SYNC) = range(1, 18)
 NPTR = 12      # pointer slots of a ColvoCmd
 
 SIGNATURES = {
@@ -71,9 +78,13 @@ SIGNATURES = {
     "colvo_conv_fwd": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_dgrad": (_i, [C.POINTER(ConvDesc), _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "colvo_conv_dgrad_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "colvo_conv_dgrad_planes": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _i, _vp, _i, _vp]),
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
     "colvo_conv_wgrad_scratch_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "colvo_conv_wgrad_det": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6 + [_sz, _vp]),
+    "colvo_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),
+    "colvo_conv_wgrad_slabs": (_i, [C.POINTER(ConvDesc)] + [_vp] * 4 + [_sz, _vp]),
+    "colvo_wgrad_reduce_group": (_i, [_vp, _i, _vp]),
     "colvo_depth_head_wgrad_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "colvo_depth_head_wgrad_det": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "colvo_pose_head_bwd_det": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),

@@ -114,6 +114,7 @@ struct WgradK {
     int nsplit, cot, xcd;     // 1-D grid: (co tile, chunk) fastest, pixel-range split slowest; XCD remap on/off
     int pwl;                  // LDS pitch of a patch row, in pixels (wgrad_row_pitch)
     int det;                  // deterministic form with ONE split: plain read-modify-write instead of atomics (no slab)
+    int slabs_only;           // host side: colvo_conv_wgrad_slabs -- always slabs (a single split too), no second launch
     // Deterministic form (colvo_conv_wgrad_det): every pixel-range split STORES its sums into a slab of its own instead of
     // adding them to dw / db with float atomics; k_wgrad_reduce then adds the slabs in split order.  null: atomics.
     float* slabs;             // [nsplit][Cout * 9 * Ctot]

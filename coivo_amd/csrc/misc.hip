@@ -884,6 +884,72 @@ __global__ __launch_bounds__(NT) void k_zero_multi(ZeroArenas zs) {
     for (size_t k = (size_t)(blockIdx.x - b0) * NT + threadIdx.x; k < n16; k += stride) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---- input gradient of a 3x3 conv w.r.t. a FEW input channels, as fp32 planes (colvo_conv_dgrad_planes) ----
+// PoseNet's first layer takes [tgt rgb | ref rgb | depth_t | depth_r]; of its input gradient only the two depth channels are wanted,
+// as fp32 NCHW planes for DepthNet's backward pass.  The general path computed all 8 channels of the 256x320 gradient with the MFMA
+// kernel (24 us at 8 pairs: it is a write of 10.5 MB NHWC for 0.4 GFLOP) and then unpacked two of them (+5 us), on the critical path
+// between the two networks' backward passes.  Here: one thread per input pixel, dx[c] = sum over the <= 4 (stride 2) or 9 (stride 1)
+// output pixels that see it and over Cout of w[co][tap][c] dy[co] -- 72 FMAs per pixel and channel pair at stride 2 -- weights of the
+// wanted channels in LDS as [tap][co][c], dy rows through L2 (neighbouring pixels share them), planes written coalesced.
+template <int ES, int NC>
+__global__ __launch_bounds__(NT) void k_conv_dgrad_planes(const void* __restrict__ dy, const float* __restrict__ w, int Cout, int Cin,
+                                                          int c_begin, int B, int Hi, int Wi, int Ho, int Wo, int S,
+                                                          float* __restrict__ dst, int accumulate) {
+    extern __shared__ float sw[];                       // [9][Cout][NC]
+    for (int i = threadIdx.x; i < 9 * Cout * NC; i += NT) {
+        const int c = i % NC, co = (i / NC) % Cout, tap = i / (NC * Cout);
+        sw[i] = w[((size_t)co * 9 + tap) * Cin + c_begin + c];
+    }
+    __syncthreads();
+    const size_t HW = (size_t)Hi * Wi;
+    const size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (p >= (size_t)B * HW) return;
+    const int b = (int)(p / HW);
+    const int r = (int)(p - (size_t)b * HW);
+    const int iy = r / Wi, ix = r - iy * Wi;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
+    const char* dyb = (const char*)dy + (size_t)b * Ho * Wo * Cout * ES;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;                     // S * oy
+        if (ty < 0 || (S == 2 && (ty & 1))) continue;
+        const int oy = S == 2 ? ty >> 1 : ty;
+        if (oy >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || (S == 2 && (tx & 1))) continue;
+            const int ox = S == 2 ? tx >> 1 : tx;
+            if (ox >= Wo) continue;
+            const char* row = dyb + ((size_t)oy * Wo + ox) * Cout * ES;
+            const float* wt = sw + (ky * 3 + kx) * Cout * NC;
+            for (int co = 0; co < Cout; co += 8) {
+                float v[8];
+                if constexpr (ES == 2) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(row + co * 2);
+                    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(u[j] << 16); v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+                } else {
+                    const float4 q0 = *reinterpret_cast<const float4*>(row + co * 4), q1 = *reinterpret_cast<const float4*>(row + co * 4 + 16);
+                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[c] = fmaf(wt[(co + j) * NC + c], v[j], acc[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float* d = dst + ((size_t)c * B + b) * HW + r;   // [c][B][1][Hi][Wi]: every channel a contiguous [B,1,H,W] tensor of its own
+        *d = accumulate ? *d + acc[c] : acc[c];
+    }
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + NT - 1) / NT); }
 inline bool head_dgrad_generic() { return TUNE(head_dgrad_generic) != 0; }   // A/B switch
 
@@ -955,6 +1021,31 @@ extern "C" int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H,
     DISPATCH_ES(dtype, hipLaunchKernelGGL((k_unpack_nhwc<ES, 4>), dim3(nblk((HW + 3) / 4), B), dim3(NT), 0, (hipStream_t)stream,
                                           dsrc, (int)HW, Cpad, c_begin, c_count, dst_nchw, accumulate));
     COLVO_CHECK_LAUNCH("k_unpack_nhwc");
+    return 0;
+}
+
+extern "C" int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, const float* w_master, int c_begin, int c_count,
+                                       float* dst, int accumulate, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(d && dy && w_master && dst, "colvo_conv_dgrad_planes: null pointer argument");
+    COLVO_CHECK_ARG(d->dtype == COLVO_F32 || d->dtype == COLVO_BF16, "colvo_conv_dgrad_planes: bad dtype %d", d->dtype);
+    COLVO_CHECK_ARG(d->ksize == 3 && (d->stride == 1 || d->stride == 2) && d->C1 == 0 && !d->up0,
+                    "colvo_conv_dgrad_planes: a 3x3 conv over one directly stored source, stride 1 or 2");
+    COLVO_CHECK_ARG(d->Ho == (d->Hi - 1) / d->stride + 1 && d->Wo == (d->Wi - 1) / d->stride + 1 && d->B >= 1,
+                    "colvo_conv_dgrad_planes: output %dx%d does not match input %dx%d / stride %d", d->Ho, d->Wo, d->Hi, d->Wi, d->stride);
+    COLVO_CHECK_ARG(d->Cout >= 8 && d->Cout % 8 == 0 && d->Cout <= 128 && (c_count == 1 || c_count == 2 || c_count == 4) && c_begin >= 0 &&
+                    c_begin + c_count <= d->C0,
+                    "colvo_conv_dgrad_planes: Cout a multiple of 8 up to 128, 1 / 2 / 4 channels inside [0, C0) (Cout=%d, channels %d..%d of %d)",
+                    d->Cout, c_begin, c_begin + c_count - 1, d->C0);
+    const size_t npix = (size_t)d->B * d->Hi * d->Wi;
+    const size_t lds = (size_t)9 * d->Cout * c_count * 4;
+    hipStream_t s = (hipStream_t)stream;
+#define COLVO_DGP(ES_, NC_)                                                                                                        \
+    hipLaunchKernelGGL((k_conv_dgrad_planes<ES_, NC_>), dim3(nblk(npix)), dim3(NT), lds, s, dy, w_master, d->Cout, d->C0, c_begin, d->B, \
+                       d->Hi, d->Wi, d->Ho, d->Wo, d->stride, dst, accumulate)
+    if (d->dtype == COLVO_F32) { if (c_count == 1) COLVO_DGP(4, 1); else if (c_count == 2) COLVO_DGP(4, 2); else COLVO_DGP(4, 4); }
+    else { if (c_count == 1) COLVO_DGP(2, 1); else if (c_count == 2) COLVO_DGP(2, 2); else COLVO_DGP(2, 4); }
+#undef COLVO_DGP
+    COLVO_CHECK_LAUNCH("k_conv_dgrad_planes");
     return 0;
 }
 

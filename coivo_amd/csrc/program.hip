@@ -88,6 +88,7 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
         case COLVO_CMD_CONV_DGRAD_BOTH:
             return colvo_conv_dgrad_both(&c.desc, c.p[0], c.p[1], c.p[2], c.p[3], (void*)c.p[4], (void*)c.p[5], s);
         case COLVO_CMD_CONV_WGRAD:
+            if (c.p[5] && c.i[1]) return colvo_conv_wgrad_slabs(&c.desc, c.p[0], c.p[1], c.p[2], (void*)c.p[5], (size_t)(uint32_t)c.i[0], s);
             if (c.p[5]) return colvo_conv_wgrad_det(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], (void*)c.p[5],
                                                     (size_t)(uint32_t)c.i[0], s);
             return colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
@@ -125,6 +126,12 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
             return colvo_pose_head_bwd(c.i[0], c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3],
                                        (const float*)c.p[4], (const float*)c.p[8], (const float*)c.p[9], c.i[1], c.i[2], c.i[3],
                                        c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
+        case COLVO_CMD_CONV_DGRAD_PLANES:
+            return colvo_conv_dgrad_planes(&c.desc, c.p[0], (const float*)c.p[1], c.i[0], c.i[1], (float*)c.p[2], c.i[2], s);
+        case COLVO_CMD_WGRAD_REDUCE_GROUP:
+            return colvo_wgrad_reduce_group((const ColvoWgradSlabs*)c.p[0], c.i[0], s);
+        case COLVO_CMD_SIDE_SYNC:
+            return 0;       // (the eager executor handles it before it gets here; in a captured side chain the order is the list's)
         default:
             set_error("colvo_run_commands: unknown op %d in command %d", c.op, k);
             return (int)hipErrorInvalidValue;
@@ -267,6 +274,17 @@ static int run_commands_captured(const ColvoCmd* cmds, int n, hipStream_t ms) {
             continue;
         }
         if (c.stream == 1 && policy != 0) {
+            if (c.op == COLVO_CMD_SIDE_SYNC && nchains == 2) {
+                // two side chains: what follows must see both -- flush, then let the chain the next segment lands on depend on the other
+                if (!st.pending.empty()) {
+                    if (policy >= 2 || st.fork_at.nodes.empty()) { if (int rc = st.fork_at.get(ms)) return rc; }
+                    if (int rc = capture_flush(st, st.fork_at, nchains, ms)) return rc;
+                }
+                CaptureTail all = st.sides[0];
+                all.merge(st.sides[1]);
+                st.sides[0] = all; st.sides[1] = all;
+                continue;
+            }
             st.pending.push_back(c);
             continue;
         }
@@ -382,6 +400,13 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");
                 if (naux) { side_idx = (side_idx + 1) % (naux + 1); side_cur = side_idx ? g_aux[side_idx - 1] : ss; }
                 rc = order_after(side_cur, ms, "fork");
+                break;
+            }
+            case COLVO_CMD_SIDE_SYNC: {  // the side stream in use continues after everything enqueued so far on the OTHER side streams
+                COLVO_CHECK_ARG(ss, "colvo_run_commands: SIDE_SYNC without a side stream");
+                if (side_cur != ss) rc = order_after(side_cur, ss, "side sync");       // (earlier calls hand everything back to ss)
+                for (int i = 0; rc == 0 && i < naux; ++i)
+                    if (aux_dirty[i] && g_aux[i] != side_cur) rc = order_after(side_cur, g_aux[i], "side sync");
                 break;
             }
             case COLVO_CMD_JOIN: {       // the main stream continues after everything enqueued so far on the side stream

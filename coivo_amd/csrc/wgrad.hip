@@ -476,6 +476,60 @@ __global__ __launch_bounds__(NT) void k_wgrad_reduce(const float* __restrict__ s
     else reduce_slabs(bslabs, nsplit, nb, bdst, (size_t)(blockIdx.x - wblocks) * NT + threadIdx.x, (size_t)(gridDim.x - wblocks) * NT);
 }
 
+// ---- grouped second launch (colvo_wgrad_reduce_group): dst += slabs[0] + slabs[1] + ... for up to 2 x COLVO_WGRAD_GROUP_MAX tensors ----
+// One entry per tensor (a layer's weights, a layer's bias).  An entry's work is cut into float4 columns x SP split partitions:
+// thread (s, q) of a block loads the float4 column q of the splits s, s + SP, s + 2 SP, ... (at most 8: all in flight), the SP
+// partial sums of a column meet in LDS and thread (0, q) adds them IN ORDER to dst -- a fixed tree, so the result is bitwise
+// repeatable.  SP is a power of two <= 64 chosen so that a thread has at most 8 loads (256 splits -> 32 partitions).
+struct ReduceEntry {
+    const float* slabs;
+    float* dst;
+    long long n4;             // float4 columns of the tensor
+    int nsplit, sp;
+    unsigned blk0;            // first block of this entry
+};
+struct ReduceGroup {
+    ReduceEntry e[2 * COLVO_WGRAD_GROUP_MAX];
+    int n;
+};
+__global__ __launch_bounds__(NT) void k_wgrad_reduce_group(const ReduceGroup g) {
+    __shared__ f32x4 part[NT];
+    int ei = 0;
+#pragma unroll 1
+    for (int i = 1; i < g.n; ++i)
+        if (blockIdx.x >= g.e[i].blk0) ei = i;
+    const ReduceEntry e = g.e[ei];
+    const int qpb = NT / e.sp;                                    // columns per block
+    const int s = threadIdx.x / qpb, ql = threadIdx.x - s * qpb;
+    const long long q = (long long)(blockIdx.x - e.blk0) * qpb + ql;
+    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < e.n4) {
+        const f32x4* base = reinterpret_cast<const f32x4*>(e.slabs) + q;
+        f32x4 v[8];
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sp_i = s + u * e.sp;
+            if (sp_i < e.nsplit) { v[u] = base[(long long)sp_i * e.n4]; cnt = u + 1; } else v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+        (void)cnt;
+        for (int sp_i = s + 8 * e.sp; sp_i < e.nsplit; sp_i += e.sp) t += base[(long long)sp_i * e.n4];     // (more than 8 x 64 splits)
+    }
+    if (e.sp > 1) {
+        part[threadIdx.x] = t;
+        __syncthreads();
+        if (s == 0) {
+            for (int j = 1; j < e.sp; ++j) t += part[j * qpb + ql];
+        }
+    }
+    if (s == 0 && q < e.n4) {
+        f32x4* d = reinterpret_cast<f32x4*>(e.dst) + q;
+        *d = *d + t;
+    }
+}
+
 #ifdef COLVO_WTRACE
 // developer build (tools/wtrace_wgrad.sh): per-workgroup phase stamps of k_wgrad3x3, printed as means over the workgroups
 static long long* g_wtrace = nullptr;
@@ -517,8 +571,8 @@ inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
     k.slabs = nullptr; k.db_slabs = nullptr;
     // deterministic form with one split: every weight element has exactly one writer, which adds to dw / db with a plain
     // read-modify-write -- reproducible without slabs or a second launch
-    k.det = (k.scratch && nsplit == 1) ? 1 : 0;
-    if (k.scratch && nsplit > 1) {
+    k.det = (k.scratch && nsplit == 1 && !k.slabs_only) ? 1 : 0;
+    if (k.scratch && (nsplit > 1 || k.slabs_only)) {
         const long long wsize = (long long)k.Cout * 9 * k.Ctot;
         const long long need = (long long)nsplit * (wsize + k.Cout) * 4;
         if (need > k.scratch_bytes) {
@@ -533,7 +587,7 @@ inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
 }
 
 inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
-    if (!k.slabs) return 0;
+    if (!k.slabs || k.slabs_only) return 0;          // (slabs_only: colvo_wgrad_reduce_group adds them later)
     const size_t wsize = (size_t)k.Cout * 9 * k.Ctot;
     const unsigned blocks = (unsigned)std::min<size_t>((wsize + NT - 1) / NT, 2048);
     const unsigned bblocks = k.db ? (unsigned)((k.Cout + NT - 1) / NT) : 0;
@@ -1008,7 +1062,7 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
 using namespace colvo;
 
 static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
-                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream);
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only = 0);
 
 extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
                                 float* db, colvo_stream_t stream) {
@@ -1019,6 +1073,51 @@ extern "C" int colvo_conv_wgrad_det(const ColvoConvDesc* d, const void* x0, cons
                                     float* db, void* scratch, size_t scratch_bytes, colvo_stream_t stream) {
     COLVO_CHECK_ARG(scratch, "colvo_conv_wgrad_det: null scratch");
     return wgrad_impl(d, x0, x1, dy, dw, db, scratch, scratch_bytes, nullptr, stream);
+}
+
+extern "C" int colvo_conv_wgrad_slabs(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, void* scratch,
+                                      size_t scratch_bytes, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(scratch, "colvo_conv_wgrad_slabs: null scratch");
+    static const float dummy = 0.0f;            // dw / db are not touched in this form (the kernel only needs db != NULL for the bias sums)
+    return wgrad_impl(d, x0, x1, dy, const_cast<float*>(&dummy), const_cast<float*>(&dummy), scratch, scratch_bytes, nullptr, stream, 1);
+}
+
+extern "C" int colvo_conv_wgrad_splits(const ColvoConvDesc* d) {
+    if (!d || check_desc(d, "colvo_conv_wgrad_splits")) return 0;
+    int nsplit = 0;
+    static const char dummy = 0;
+    if (wgrad_impl(d, &dummy, d->C1 ? &dummy : nullptr, &dummy, (float*)&dummy, nullptr, nullptr, 0, &nsplit, nullptr)) return 0;
+    return nsplit;
+}
+
+extern "C" int colvo_wgrad_reduce_group(const ColvoWgradSlabs* sets, int n, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(sets && n >= 1 && n <= COLVO_WGRAD_GROUP_MAX, "colvo_wgrad_reduce_group: 1..%d sets", COLVO_WGRAD_GROUP_MAX);
+    ReduceGroup g{};
+    unsigned blk = 0;
+    auto add = [&](const float* slabs, float* dst, long long n, int nsplit) {
+        ReduceEntry& e = g.e[g.n++];
+        e.slabs = slabs; e.dst = dst; e.n4 = n / 4; e.nsplit = nsplit;
+        int sp = 1;
+        while (sp < 64 && sp * 8 < nsplit) sp *= 2;
+        if (e.n4 < NT / sp) { while (sp < 64 && (long long)(NT / (sp * 2)) >= e.n4 && sp * 2 <= nsplit) sp *= 2; }   // tiny tensors: more partitions, fewer idle lanes
+        e.sp = sp;
+        e.blk0 = blk;
+        blk += (unsigned)((e.n4 + NT / sp - 1) / (NT / sp));
+    };
+    for (int i = 0; i < n; ++i) {
+        const ColvoWgradSlabs& w = sets[i];
+        COLVO_CHECK_ARG(w.scratch && w.dw && w.nsplit >= 1 && w.Cout >= 8 && w.Cout % 4 == 0 && w.Ctot >= 8 && w.Ctot % 4 == 0,
+                        "colvo_wgrad_reduce_group: bad set %d", i);
+        const long long wsize = (long long)w.Cout * 9 * w.Ctot;
+        const float* slabs = (const float*)w.scratch;
+        COLVO_CHECK_ARG(((uintptr_t)slabs % 16) == 0 && ((uintptr_t)w.dw % 16) == 0 && (!w.db || ((uintptr_t)w.db % 16) == 0),
+                        "colvo_wgrad_reduce_group: set %d is not 16-byte aligned", i);
+        add(slabs, w.dw, wsize, w.nsplit);
+        if (w.db) add(slabs + (size_t)w.nsplit * wsize, w.db, w.Cout, w.nsplit);
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(blk), dim3(NT), 0, (hipStream_t)stream, g);
+    COLVO_CHECK_LAUNCH("k_wgrad_reduce_group");
+    return 0;
 }
 
 extern "C" size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d) {
@@ -1032,7 +1131,7 @@ extern "C" size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d) {
 }
 
 static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
-                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream) {
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only) {
     if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
     COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
     // The kernel addresses dY and the sources with 32-bit buffer offsets (< 1 GiB per tensor): larger batches are
@@ -1044,6 +1143,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
         COLVO_CHECK_ARG(per_img < 0x40000000LL, "colvo_conv_wgrad: a single image of %lld bytes is not supported", per_img);
         const int bmax = (int)std::max(1LL, (0x40000000LL - 1) / per_img);
         if (d->B > bmax) {
+            COLVO_CHECK_ARG(!slabs_only, "colvo_conv_wgrad_slabs: batch %d would be sliced (tensors >= 1 GiB); use colvo_conv_wgrad_det", d->B);
             const long long e0 = (long long)(d->up0 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C0 * es;
             const long long e1 = (long long)(d->up1 ? (d->Hi / 2) * (d->Wi / 2) : d->Hi * d->Wi) * d->C1 * es;
             const long long ey = (long long)d->Ho * d->Wo * d->Cout * es;
@@ -1064,6 +1164,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
     k.Ho = d->Ho; k.Wo = d->Wo; k.B = d->B;
     k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
     k.scratch = (const char*)scratch; k.scratch_bytes = scratch ? (long long)scratch_bytes : 0; k.plan_out = plan_out;
+    k.slabs_only = slabs_only;
     {
         // single up-sampled source in whole 32-channel (bf16) / 16-channel (f32) chunks: the four-class form over source positions
         const int ck = d->dtype == COLVO_F32 ? 16 : 32;

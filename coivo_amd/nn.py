@@ -89,6 +89,21 @@ class _ArenaModule(nn.Module):
         # (include/colvo.h colvo_conv_wgrad_det): bitwise repeatable steps at the price of ~one small launch per layer.  Read when a
         # pass is RECORDED: call clear_programs() after changing it.
         self.deterministic = os.environ.get("COLVO_DETERMINISTIC") is not None
+        # group_wgrad (round 4; OFF by default): the conv layers' weight gradients leave their kernels as per-split slabs (plain
+        # stores, no float atomics) and ONE launch per group of layers adds the slabs to the gradient arena (include/colvo.h
+        # colvo_conv_wgrad_slabs / colvo_wgrad_reduce_group).  Built on the in-kernel stamps of profiles/r4_wgrad_phases.md -- the
+        # atomics are 6-7.7 us of every weight-gradient launch, the slab stores 2.3 -- and a LOSS in the step: 1.491-1.506 ms against
+        # 1.420-1.427 with the atomics at configs[1] (+5 %), 3.80-3.83 against 3.73-3.76 at the configs[3] shape (+2 %), worse with
+        # more splits (512-workgroup grids: 1.59 ms) and no better with groups of 3 / 12 / 64 MB; the per-layer deterministic form is
+        # +1.6 %.  The slabs are 180 MB a step written and read back through HBM beside kernels that are bandwidth-bound at the top
+        # of the network, and a group's launch waits for BOTH weight-gradient streams; the atomics are slow per launch but ride in
+        # L2 under the other streams' kernels.  A group closes when it holds wgrad_group_bytes of gradients (or 16 layers); its
+        # layers are reported to the gradient-ready hook then, in backward order.  Kept as an option (weight gradients are bitwise
+        # repeatable in it; `deterministic` stays the per-layer form, which is the cheaper of the two).  Read when a pass is RECORDED.
+        self.group_wgrad = _lib.dev_env("COLVO_WGRAD_GROUPED") is not None
+        self.wgrad_group_bytes = int(_lib.dev_env("COLVO_WGRAD_GROUP_MB", "6")) << 20
+        self._group: list = []
+        self._group_bytes = 0
 
     # ---- arena ------------------------------------------------------------------------------- #
     def _layers(self) -> List[ConvParams]:
@@ -322,25 +337,29 @@ class _ArenaModule(nn.Module):
 
     # ---- backward scheduling: weight gradients on a side stream, concurrent with the input gradients ------ #
     def _bwd_begin(self) -> None:
+        self._group, self._group_bytes = [], 0
         self._main = torch.cuda.current_stream()
         if self.overlap_wgrad and self._side is None:
             self._side = torch.cuda.Stream(device=self.flat_param.device, priority=_SIDE_PRIORITY)
         self._side_used = False
 
-    def _run_wgrad(self, L: ConvParams, fn, *tensors) -> None:
-        """fn() enqueues the weight-gradient kernel(s) of layer L; with overlap it runs on the side stream,
-        ordered after everything already enqueued on the main stream (its inputs), and so does the
-        gradient-ready hook (the data-parallel all-reduce of finished buckets)."""
+    def _run_wgrad(self, L, fn, *tensors) -> None:
+        """fn() enqueues weight-gradient kernel(s); with overlap it runs on the side stream, ordered after everything already
+        enqueued on the main stream (its inputs), and so does the gradient-ready hook (the data-parallel all-reduce of finished
+        buckets) of the layers that are COMPLETE once fn() has run: L = one ConvParams, a list of them, or None."""
+        layers = [] if L is None else ([L] if isinstance(L, ConvParams) else list(L))
         rec = self._rec
         if not self.overlap_wgrad:
             fn()
-            self._layer_done(L)
+            for l_ in layers:
+                self._layer_done(l_)
             return
         if rec is not None:
             rec.fork()
             rec.stream = 1
             fn()
-            self._layer_done(L)
+            for l_ in layers:
+                self._layer_done(l_)
             rec.stream = 0
             self._side_used = True
             return
@@ -349,13 +368,42 @@ class _ArenaModule(nn.Module):
         self._side.wait_event(ev)
         with torch.cuda.stream(self._side):
             fn()
-            self._layer_done(L)
+            for l_ in layers:
+                self._layer_done(l_)
         for t in tensors:
             if t is not None:
                 t.record_stream(self._side)
         self._side_used = True
 
+    def _conv_wgrad(self, L: ConvParams, desc, x0, x1, dy) -> None:
+        """Weight / bias gradient of conv layer L into the gradient arena: atomics (default), the per-layer deterministic form, or grouped slabs (see group_wgrad)."""
+        if not self.group_wgrad:
+            scr = ops.conv_wgrad_scratch(desc, dy.device) if self.deterministic else None       # (per-layer deterministic form)
+            self._run_wgrad(L, lambda: ops.conv_wgrad(desc, x0, x1, dy, L.g_master, L.g_bias, scr), x0, x1, dy)
+            return
+        scr = ops.conv_wgrad_scratch(desc, dy.device)          # (recorded passes keep it: persistent, like the activations)
+        nsplit = ops.conv_wgrad_splits(desc)
+        self._run_wgrad(None, lambda: ops.conv_wgrad_slabs(desc, x0, x1, dy, scr), x0, x1, dy, scr)
+        self._group.append((L, (scr, L.g_master, L.g_bias, nsplit, desc.Cout, desc.C0 + desc.C1)))
+        self._group_bytes += L.g_master.numel() * 4
+        if self._group_bytes >= self.wgrad_group_bytes or len(self._group) == _lib.WGRAD_GROUP_MAX:
+            self._wgrad_flush()
+
+    def _wgrad_flush(self) -> None:
+        """Close the open group: one launch adds its layers' slabs to the arena, then the layers count as done (in order)."""
+        if not self._group:
+            return
+        group, self._group, self._group_bytes = self._group, [], 0
+        sets = [g_[1] for g_ in group]
+
+        def fn():
+            if self._rec is not None:
+                self._rec.side_sync()        # the group's kernels were dealt onto both side streams: wait for all of them
+            ops.wgrad_reduce_group(sets)
+        self._run_wgrad([g_[0] for g_ in group], fn, *[t for st_ in sets for t in st_[:3]])
+
     def _bwd_end(self) -> None:
+        self._wgrad_flush()
         if self.overlap_wgrad and self._side_used:
             if self.defer_join:
                 if self._rec is not None:
@@ -578,9 +626,7 @@ class DepthNet(_ArenaModule):
             self._bwd_begin()
 
             def wgrad(name, x0, x1, dy):
-                L = getattr(self, name)
-                scr = ops.conv_wgrad_scratch(P[name], dy.device) if self.deterministic else None
-                self._run_wgrad(L, lambda: ops.conv_wgrad(P[name], x0, x1, dy, L.g_master, L.g_bias, scr), x0, x1, dy)
+                self._conv_wgrad(getattr(self, name), P[name], x0, x1, dy)
 
             def dgrad(name, src, dy, mask_like, dx=None, accumulate=False):
                 L = getattr(self, name)
@@ -757,16 +803,20 @@ class PoseNet(_ArenaModule):
             for i in range(7, 0, -1):
                 L = getattr(self, f"conv{i}")
                 src = A["in"] if i == 1 else A[i - 1]
-                scr = ops.conv_wgrad_scratch(P[i], g.device) if self.deterministic else None
-                self._run_wgrad(L, lambda L=L, i=i, src=src, g=g, scr=scr: ops.conv_wgrad(P[i], src, None, g, L.g_master, L.g_bias, scr),
-                                src, g)
-                if i > 1 or has_depth:
+                self._conv_wgrad(L, P[i], src, None, g)
+                if i > 1:
                     dx = torch.empty_like(src)
-                    ops.conv_dgrad(P[i], 0, g, L.w_bwd, src if i > 1 else None, dx, False)
+                    ops.conv_dgrad(P[i], 0, g, L.w_bwd, src, dx, False)
                     g = dx
+                elif has_depth and _lib.dev_env("COLVO_NO_DGRAD_PLANES") is None:
+                    # only the two depth channels of the 8-channel input gradient are wanted, as fp32 planes: one small kernel
+                    # instead of the full input gradient + an unpack pass (include/colvo.h colvo_conv_dgrad_planes)
+                    ops.conv_dgrad_planes(P[1], g, L.w_master, 6, 2, d_tr)
+                elif has_depth:                      # (developer A/B switch: the round-3 form)
+                    dx = torch.empty_like(src)
+                    ops.conv_dgrad(P[i], 0, g, L.w_bwd, None, dx, False)
+                    ops.unpack_nhwc_grad(dx, 6, 2, d_tr, False, by_channel=True)
             self._bwd_end()
-            if has_depth:
-                ops.unpack_nhwc_grad(g, 6, 2, d_tr, False, by_channel=True)
 
         ext = dict(grads)
         if has_depth:

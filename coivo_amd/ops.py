@@ -73,6 +73,18 @@ def conv_dgrad_both(d: ConvDesc, dy, w_bwd, relu_mask0, relu_mask1, dx0, dx1) ->
                                          _lib.ptr(dx0), _lib.ptr(dx1), _lib.stream_ptr()), "colvo_conv_dgrad_both")
 
 
+def conv_dgrad_planes(d: ConvDesc, dy, w_master, c_begin: int, c_count: int, dst, accumulate: bool = False) -> None:
+    """Input gradient w.r.t. channels [c_begin, c_begin + c_count) only, as fp32 planes dst [c_count, B, 1, Hi, Wi]
+    (include/colvo.h colvo_conv_dgrad_planes)."""
+    _need_cuda(dy, w_master, dst)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_DGRAD_PLANES, d, (dy, w_master, dst), (c_begin, c_count, int(accumulate)))
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_dgrad_planes(C.byref(d), _lib.ptr(dy), _lib.ptr(w_master), c_begin, c_count, _lib.ptr(dst),
+                                           int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad_planes")
+
+
 def conv_wgrad_scratch(d: ConvDesc, device) -> torch.Tensor:
     """Scratch for the deterministic weight gradient of one conv call (include/colvo.h colvo_conv_wgrad_det)."""
     n = _lib.load().colvo_conv_wgrad_scratch_bytes(C.byref(d))
@@ -96,6 +108,46 @@ def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db, scratch: Optional[torch.Tensor] 
         return
     _lib.check(lib.colvo_conv_wgrad(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw),
                                     _lib.ptr(db), _lib.stream_ptr()), "colvo_conv_wgrad")
+
+
+def conv_wgrad_splits(d: ConvDesc) -> int:
+    """Number of pixel-range splits (= slabs) conv_wgrad_slabs / the deterministic form will write for this layer."""
+    n = _lib.load().colvo_conv_wgrad_splits(C.byref(d))
+    if n <= 0:
+        raise RuntimeError("colvo_conv_wgrad_splits failed: " + _lib.load().colvo_last_error().decode("utf-8", "replace"))
+    return n
+
+
+def conv_wgrad_slabs(d: ConvDesc, x0, x1, dy, scratch: torch.Tensor) -> None:
+    """First half of the grouped weight gradient (include/colvo.h colvo_conv_wgrad_slabs): every split stores its sums into its
+    slab of `scratch` (conv_wgrad_scratch); nothing is added to dw / db until wgrad_reduce_group."""
+    _need_cuda(x0, x1, dy, scratch)
+    nb = scratch.numel() * scratch.element_size()
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, None, None, scratch), (nb, 1))
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_wgrad_slabs(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(scratch), nb,
+                                          _lib.stream_ptr()), "colvo_conv_wgrad_slabs")
+
+
+def wgrad_reduce_group(sets) -> None:
+    """Second half: sets = [(scratch, dw, db, nsplit, Cout, Ctot)] of up to _lib.WGRAD_GROUP_MAX conv_wgrad_slabs calls; ONE launch adds
+    every set's slabs to its dw / db in split order."""
+    n = len(sets)
+    if not 1 <= n <= _lib.WGRAD_GROUP_MAX:
+        raise ValueError(f"wgrad_reduce_group: 1..{_lib.WGRAD_GROUP_MAX} sets")
+    arr = (_lib.WgradSlabs * n)()
+    keep = []
+    for i, (scratch, dw, db, nsplit, cout, ctot) in enumerate(sets):
+        _need_cuda(scratch, dw, db)
+        arr[i].scratch, arr[i].dw, arr[i].db = scratch.data_ptr(), dw.data_ptr(), _lib.ptr(db)
+        arr[i].nsplit, arr[i].Cout, arr[i].Ctot = int(nsplit), int(cout), int(ctot)
+        keep += [scratch, dw, db]
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_WGRAD_REDUCE_GROUP, None, (), (n,), raw=[(0, C.addressof(arr), (arr, keep))])
+    _lib.check(_lib.load().colvo_wgrad_reduce_group(arr, n, _lib.stream_ptr()), "colvo_wgrad_reduce_group")
 
 
 def pack_weights(w_master: torch.Tensor, dtype: torch.dtype, w_fwd: Optional[torch.Tensor],

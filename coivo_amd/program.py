@@ -24,7 +24,7 @@ def recording() -> Optional["Program"]:
 class Program:
     def __init__(self):
         self.cmds: List[_lib.Cmd] = []
-        self.keep: List[torch.Tensor] = []
+        self.keep: List[object] = []
         self.stream = 0                      # stream selector of the commands being recorded (0 main, 1 side)
         self.marks: List[Tuple[int, object]] = []     # (number of commands recorded so far, payload) -- hook points
         self._ext: Dict[str, int] = {}       # external name -> data pointer at record time
@@ -53,11 +53,15 @@ class Program:
         return t
 
     def add(self, op: int, desc=None, p: Sequence[Optional[torch.Tensor]] = (), i: Sequence[int] = (),
-            f: Sequence[float] = ()) -> None:
+            f: Sequence[float] = (), raw: Sequence = ()) -> None:
+        """raw: [(slot, address, keepalive)] -- pointer slots that are not tensors (a host-side table the command refers to)."""
         c = _lib.Cmd()
         c.op, c.stream = op, self.stream
         if desc is not None:
             c.desc = desc
+        for slot, address, keepalive in raw:
+            c.p[slot] = address
+            self.keep.append(keepalive)
         for k, t in enumerate(p):
             if t is not None:
                 c.p[k] = t.data_ptr()
@@ -76,6 +80,10 @@ class Program:
 
     def join(self) -> None:
         self.add(_lib.CMD_JOIN)
+
+    def side_sync(self) -> None:
+        """(recorded as a side command) the side stream in use waits for every other side stream's work so far."""
+        self.add(_lib.CMD_SIDE_SYNC)
 
     def mark(self, payload) -> None:
         self.marks.append((len(self.cmds), payload))

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 7
+#define COLVO_ABI_VERSION 8
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -182,6 +182,14 @@ int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy, const void
 int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* relu_mask0,
                           const void* relu_mask1, void* dx0, void* dx1, colvo_stream_t stream);
 
+/* Input gradient of a 3x3 conv (stride 1 or 2, ONE directly stored source, no ReLU behind it: a network input) w.r.t. a few of its
+ * input channels only, as fp32 planes: dst[c][B][1][Hi][Wi] for channels c_begin .. c_begin + c_count - 1 (c_count 1, 2 or 4; every
+ * channel a contiguous [B,1,Hi,Wi] tensor of its own).  w_master: the fp32 weights [Cout][9][C0].  PoseNet's first layer: only the
+ * two depth channels of its 8-channel input gradient are wanted (DCDP coupling, README.md:7); this replaces the full input gradient +
+ * an unpack pass (29 us -> 5 us on the critical path between the two networks' backward passes).  accumulate: dst += . */
+int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, const float* w_master, int c_begin, int c_count, float* dst,
+                            int accumulate, colvo_stream_t stream);
+
 /* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
  * (the caller zeroes them once per step). */
 int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
@@ -195,6 +203,28 @@ int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, con
 size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d);
 int colvo_conv_wgrad_det(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
                          void* scratch, size_t scratch_bytes, colvo_stream_t stream);
+/* Grouped form (round 4; optional -- nn.*.group_wgrad -- and NOT the default: see the last sentence).  In-kernel stamps put the fp32
+ * atomics that end colvo_conv_wgrad at 6-7.7 us of EVERY launch -- a third of the kernel at 16 frames, whatever the number of splits --
+ * against 2.3 us for the slab stores of the _det form, whose per-layer second launch then costs ~7 us again
+ * (profiles/r4_wgrad_phases.md).  colvo_conv_wgrad_slabs is the FIRST launch of colvo_conv_wgrad_det only (every pixel-range split
+ * stores its sums into its slab of `scratch`; dw / db are not touched; a single split stores a slab too), and
+ * colvo_wgrad_reduce_group adds the slabs of up to COLVO_WGRAD_GROUP_MAX such calls to their dw / db in ONE launch, in a fixed order:
+ * four or five second launches per backward pass instead of 27, bitwise repeatable.  colvo_conv_wgrad_splits: the number of slabs the
+ * call will write (what the group entry needs).  The slabs call refuses a batch it would have to slice (a tensor >= 1 GiB: the slices
+ * would share the slabs); use _det there.  IN THE TRAINING STEP the form measured 5 % SLOWER than the atomics at 8 pairs and 2 % at 32
+ * (the per-layer _det form: 1.6 %): 180 MB of slabs a step go out to HBM and come back beside bandwidth-bound kernels, and a group's
+ * launch waits for both weight-gradient streams, while the atomics -- slow per launch -- ride in L2 under the other streams' kernels. */
+#define COLVO_WGRAD_GROUP_MAX 16
+typedef struct ColvoWgradSlabs {
+    const void* scratch;         /* what colvo_conv_wgrad_slabs wrote: [nsplit][Cout*9*Ctot] weight slabs, then [nsplit][Cout] bias slabs */
+    float* dw;                   /* [Cout][9][Ctot], added to */
+    float* db;                   /* [Cout] or NULL */
+    int32_t nsplit, Cout, Ctot, pad_;
+} ColvoWgradSlabs;
+int colvo_conv_wgrad_splits(const ColvoConvDesc* d);
+int colvo_conv_wgrad_slabs(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, void* scratch,
+                           size_t scratch_bytes, colvo_stream_t stream);
+int colvo_wgrad_reduce_group(const ColvoWgradSlabs* sets, int n, colvo_stream_t stream);
 size_t colvo_depth_head_wgrad_scratch_bytes(int B, int H, int W, int C);
 int colvo_depth_head_wgrad_det(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw, float* db,
                                void* scratch, size_t scratch_bytes, colvo_stream_t stream);
@@ -349,7 +379,8 @@ int colvo_read_npy_u8_frames(const char* const* paths, int n, int h, int w, uint
 enum {
     COLVO_CMD_CONV_FWD = 1,      /* p: x0 x1 w_fwd bias y */
     COLVO_CMD_CONV_DGRAD,        /* i: src accumulate; p: dy w_bwd relu_mask dx */
-    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db scratch; i: scratch_bytes (scratch != NULL: colvo_conv_wgrad_det) */
+    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db scratch; i: scratch_bytes slabs_only (scratch != NULL: colvo_conv_wgrad_det, or with
+                                    slabs_only colvo_conv_wgrad_slabs) */
     COLVO_CMD_PACK_NCHW,         /* i: dtype c0 c1 c2 c3 nsrc B H W Cpad; p: src0..src3 dst */
     COLVO_CMD_UNPACK_NHWC_GRAD,  /* i: dtype B H W Cpad c_begin c_count accumulate; p: dsrc dst */
     COLVO_CMD_DEPTH_HEAD_FWD,    /* i: dtype B H W C; f: min max; p: x w bias depth */
@@ -360,7 +391,11 @@ enum {
     COLVO_CMD_FORK,              /* side stream waits for the main stream's work so far */
     COLVO_CMD_JOIN,              /* main stream waits for the side stream's work so far */
     COLVO_CMD_DEPTH_HEAD_BWD_PARTS, /* i: dtype B H W C; f: min max; p: x w depth g_first g_second g_raw scale_a scale_b scratch dx g_raw_second */
-    COLVO_CMD_CONV_DGRAD_BOTH     /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
+    COLVO_CMD_CONV_DGRAD_BOTH,    /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
+    COLVO_CMD_WGRAD_REDUCE_GROUP, /* p: sets (HOST pointer to ColvoWgradSlabs[n], alive as long as the list); i: n */
+    COLVO_CMD_CONV_DGRAD_PLANES,  /* p: dy w_master dst; i: c_begin c_count accumulate */
+    COLVO_CMD_SIDE_SYNC           /* (side command) the side stream in use waits for everything enqueued so far on every other side
+                                    stream: what follows reads what several FORKed commands wrote */
 };
 
 typedef struct ColvoCmd {

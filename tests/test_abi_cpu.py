@@ -137,7 +137,8 @@ def test_tuning_table_hooks_and_no_stray_getenv(lib):
             continue
         for line in open(os.path.join(csrc, f)):
             if "getenv(" in line:
-                assert "COLVO_ABL" in line or "COLVO_TRACE" in line, f"{f}: {line.strip()}"
+                # (developer builds only: -DCOLVO_ABLATE of conv.hip, -DCOLVO_WTRACE of wgrad.hip; never the production library)
+                    assert "COLVO_ABL" in line or "COLVO_TRACE" in line or "COLVO_WTRACE" in line, f"{f}: {line.strip()}"
     # the Python side honours its developer switches only under COLVO_DEV=1
     os.environ["COLVO_TEST_SWITCH"] = "x"
     dev = os.environ.pop("COLVO_DEV", None)

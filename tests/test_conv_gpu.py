@@ -402,3 +402,72 @@ def test_dgrad_both_sources_equals_two_calls(B, H, W, C0, C1, Cout, dtype):
         b0, b1 = torch.full_like(x0, 5.0), torch.full_like(x1, 5.0)
         ops.conv_dgrad_both(desc, dy, w_bwd, masks[0], masks[1], b0, b1)
         assert torch.equal(a0, b0) and torch.equal(a1, b1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [
+    # B, Hi, Wi, C0, Cout, stride, c_begin, c_count
+    (2, 64, 96, 8, 16, 2, 6, 2),       # PoseNet conv1: the two depth channels of the 8-channel input
+    (1, 13, 21, 8, 16, 2, 6, 2),       # odd extent: ragged last output row / column
+    (2, 16, 24, 16, 32, 1, 3, 4),      # stride 1, four channels from the middle
+    (3, 9, 7, 8, 8, 2, 0, 1),          # one channel
+])
+def test_input_gradient_of_a_few_channels_as_planes(case, dtype):
+    """colvo_conv_dgrad_planes against torch autograd of F.conv2d: the input gradient w.r.t. channels [c_begin, c_begin + c_count)
+    only, as fp32 planes [c_count, B, 1, H, W]; fp32 weights in both modes, dy in the feature-map dtype; accumulate adds."""
+    from coivo_amd import ops
+    B, Hi, Wi, C0, Cout, stride, c_begin, c_count = case
+    g = torch.Generator().manual_seed(17)
+    d = ops.conv_desc(dtype, B, Hi, Wi, C0, Cout, stride=stride)
+    w = torch.randn(Cout, 9, C0, generator=g) * 0.1
+    dy = torch.randn(B, Cout, d.Ho, d.Wo, generator=g)
+    dy_q = dy.to(dtype).float()                                # what the kernel sees
+    x = torch.zeros(B, C0, Hi, Wi, requires_grad=True)
+    y = F.conv2d(x, w.view(Cout, 3, 3, C0).permute(0, 3, 1, 2), None, stride=stride, padding=1)
+    y.backward(dy_q)
+    ref = x.grad[:, c_begin:c_begin + c_count].permute(1, 0, 2, 3).unsqueeze(2).contiguous()       # [c, B, 1, H, W]
+    dst = torch.full((c_count, B, 1, Hi, Wi), 7.0, device=dev())
+    ops.conv_dgrad_planes(d, _nhwc(dy).to(dev()).to(dtype), w.to(dev()), c_begin, c_count, dst)
+    torch.cuda.synchronize()
+    scale = ref.abs().max().item()
+    assert (dst.cpu() - ref).abs().max().item() < 2e-6 * scale + 1e-6
+    ops.conv_dgrad_planes(d, _nhwc(dy).to(dev()).to(dtype), w.to(dev()), c_begin, c_count, dst, accumulate=True)
+    torch.cuda.synchronize()
+    assert (dst.cpu() - 2 * ref).abs().max().item() < 4e-6 * scale + 2e-6
+
+
+def test_grouped_weight_gradient_equals_the_per_layer_deterministic_form():
+    """colvo_conv_wgrad_slabs + colvo_wgrad_reduce_group (several layers, one second launch) against colvo_conv_wgrad_det per layer:
+    the same slabs added in the same order up to the reduction tree -- compared to fp32 round-off -- and bitwise repeatable."""
+    from coivo_amd import ops
+    g = torch.Generator().manual_seed(23)
+    layers = [(2, 16, 24, 32, 0, False, 64, 1), (2, 16, 20, 64, 0, True, 32, 1), (2, 32, 40, 64, 0, False, 128, 2),
+              (1, 8, 10, 512, 0, False, 512, 1), (2, 64, 80, 8, 0, False, 32, 2), (2, 16, 20, 32, 32, False, 32, 1)]
+    for dtype in (torch.float32, torch.bfloat16):
+        sets, refs, outs = [], [], []
+        for (B, Hi, Wi, C0, C1, up0, Cout, stride) in layers:
+            d = ops.conv_desc(dtype, B, Hi, Wi, C0, Cout, stride=stride, C1=C1, up0=up0)
+            hs, ws = (Hi // 2, Wi // 2) if up0 else (Hi, Wi)
+            x0 = torch.randn(B, hs, ws, C0, generator=g).to(dev()).to(dtype)
+            x1 = torch.randn(B, Hi, Wi, C1, generator=g).to(dev()).to(dtype) if C1 else None
+            dy = torch.randn(B, d.Ho, d.Wo, Cout, generator=g).to(dev()).to(dtype)
+            dw_ref = torch.ones(Cout, 9, C0 + C1, device=dev())
+            db_ref = torch.ones(Cout, device=dev())
+            ops.conv_wgrad(d, x0, x1, dy, dw_ref, db_ref, ops.conv_wgrad_scratch(d, dev()))
+            dw, db = torch.ones(Cout, 9, C0 + C1, device=dev()), torch.ones(Cout, device=dev())
+            scr = ops.conv_wgrad_scratch(d, dev())
+            ops.conv_wgrad_slabs(d, x0, x1, dy, scr)
+            sets.append((scr, dw, db, ops.conv_wgrad_splits(d), Cout, C0 + C1))
+            refs.append((dw_ref, db_ref)); outs.append((dw, db))
+        ops.wgrad_reduce_group(sets)
+        first = [(a.clone(), b.clone()) for a, b in outs]
+        for (a, b), (ra, rb) in zip(outs, refs):
+            assert (a - ra).abs().max().item() <= 2e-5 * ra.abs().max().item(), dtype
+            assert (b - rb).abs().max().item() <= 2e-5 * rb.abs().max().item() + 1e-6, dtype
+        # ... and adding the same slabs again gives exactly twice the increment's bits every time
+        for a, b in outs:
+            a.fill_(1.0); b.fill_(1.0)
+        ops.wgrad_reduce_group(sets)
+        torch.cuda.synchronize()
+        for (a, b), (fa, fb) in zip(outs, first):
+            assert torch.equal(a, fa) and torch.equal(b, fb), dtype

@@ -74,7 +74,7 @@ def test_rccl_path_with_one_rank():
     only way to execute it on a one-GPU box.  With deterministic weight gradients (COLVO_DETERMINISTIC=1) nothing in a step depends on
     an execution order and a one-rank fp32 all-reduce is the identity, so the run through the RCCL path must end in EXACTLY the plain
     run's loss (a wrong grad_scale, a dropped bucket or a stale staging copy cannot hide in a tolerance).  bf16 transport rounds
-    every gradient element to bf16 (relative error <= 2^-9) before Adam: bound derived below.  And the step must not fall into the
+    every gradient element to bf16 before Adam (pinned exactly by the next test; here a sanity bar).  And the step must not fall into the
     serialised mode (several times the plain step time) that too many active hardware queues cause."""
     import json
     import subprocess
@@ -92,12 +92,24 @@ def test_rccl_path_with_one_rank():
         assert out[tag]["deterministic_weight_gradients"]
     assert out["rccl"]["final_loss"] == out["plain"]["final_loss"], (out["rccl"]["final_loss"], out["plain"]["final_loss"])
     assert out["rccl"]["first_loss"] == out["plain"]["first_loss"] == out["rccl_bf16"]["first_loss"]
-    # bf16 transport: g' = g (1 + e), |e| <= 2^-9 per element.  Adam's update m / (sqrt(v) + eps) is homogeneous of degree 0 in a
-    # uniform scaling of g and moves by at most ~2|e| of itself under element-wise perturbations, so over the 35 steps the
-    # trajectory's total loss change D = |first_loss - final_loss| moves by O(2^-8 D) to first order; 8x that as the bar
-    # (measured: see DESIGN.md section 5) instead of round 3's 5e-3 = 20 % of the loss.
+    # bf16 transport rounds every gradient element to bf16 before Adam.  WHAT it does to the arena is pinned exactly by
+    # test_bf16_gradient_transport_is_exactly_a_bf16_rounding below; what that does to a 35-step trajectory is not derivable -- to
+    # first order the loss change D = |first_loss - final_loss| moves by O(2^-8 D), but ReLU / validity decisions that flip on the
+    # way amplify it (seen: 3.4e-4 and 6.4e-4 on D = 0.017) -- so here only a sanity bar: the same problem, within a tenth of D.
     D = abs(out["plain"]["first_loss"] - out["plain"]["final_loss"])
-    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) <= 8 * 2.0 ** -8 * D + 1e-6, \
+    assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) <= 0.1 * D, \
         (out["rccl_bf16"]["final_loss"], out["plain"]["final_loss"], D)
     assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
     assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
+
+
+def test_bf16_gradient_transport_is_exactly_a_bf16_rounding():
+    """One rank over RCCL: the gradient arena after GradBuckets.finish() with bf16 transport holds EXACTLY the fp32 gradients rounded
+    to bf16, and with fp32 transport exactly the gradients of the run without a process group (tests/rccl_transport_worker.py):
+    every bucket went out, came back and was copied to the right slice -- no tolerance."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29551")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_transport_worker.py")], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_TRANSPORT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

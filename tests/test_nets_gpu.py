@@ -301,3 +301,40 @@ def test_adam_with_operand_copies_in_one_pass_equals_the_two_pass_form(dtype):
     # state_dict round trip keeps the step number
     sd = opt.state_dict()
     assert int(sd["state"][0]["step"].item()) == 3 and int(sd["state"][1]["step"].item()) == 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grouped_slab_weight_gradients_equal_the_default_form(dtype):
+    """nn.*.group_wgrad (optional, round 4): conv weight gradients as per-split slabs + one reduce launch per group of layers.  Same
+    gradients as the default form to summation-order round-off, bitwise repeatable from run to run, accumulation across two backward
+    passes intact, and the gradient-ready hook still sees every layer once, in backward (reverse arena) order."""
+    from coivo_amd import nn as hnn
+    B, H, W, seed = 2, 64, 96, 91
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+
+    def run(grouped, passes=1):
+        _, _, dn, pn = _models(seed, dtype)
+        dn.group_wgrad = pn.group_wgrad = grouped
+        dn.wgrad_group_bytes = 2 << 20                     # several groups in DepthNet
+        seen = []
+        dn.grad_ready_hook = lambda m, lo, hi: seen.append((lo, hi)) or False
+        dn.zero_grad(); pn.zero_grad()
+        for _ in range(passes):
+            hnn.dcdp_forward(dn, pn, b["tgt"], b["ref"], b["K"])[0].backward()
+        dn.join_side(); pn.join_side()
+        torch.cuda.synchronize()
+        return dn.flat_grad.clone(), pn.flat_grad.clone(), seen, dn
+
+    g0 = run(False)
+    g1 = run(True)
+    g2 = run(True)
+    for a, c, r in zip(g0[:2], g1[:2], g2[:2]):
+        scale = a.abs().max().item()
+        assert (a - c).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-4) * scale
+        assert torch.equal(c, r)                           # slabs + fixed-order reduction: no run-to-run wobble
+    seen, dn = g1[2], g1[3]
+    spans = [L.span for L in dn._layers()]
+    assert sorted(seen) == sorted(spans) and seen == sorted(seen, reverse=True), seen[:4]
+    twice = run(True, passes=2)
+    for c, t in zip(g1[:2], twice[:2]):
+        assert (t - 2 * c).abs().max().item() <= 1e-5 * c.abs().max().item()
