@@ -1,0 +1,338 @@
+// bwd16.hip -- input gradient AND weight gradient of a narrow full-resolution 3x3 layer in ONE pass (round 4).
+//
+// Why: the 16-channel layers at full resolution (DepthNet iconv1: 16 -> 16 at 256x320) do 6 GFLOP on 42 MB tensors -- they are
+// HBM-bound, each kernel alone already near the bandwidth it can get (input gradient 25 us for 126 MB, weight gradient 32 us for 84 MB
+// at 16 frames) -- and the two backward kernels of the layer read the SAME two tensors: dY (with a halo for the input gradient) and the
+// layer's input x (as the ReLU mask of dx and as the second operand of dW).  Fused, a workgroup stages one dY patch and one x patch per
+// 128-pixel tile and runs both products on them: 3 tensor passes (dY, x in; dx out) instead of 5, no separate mask read.
+//
+//   dx[p][ci] = (x[p][ci] > 0) * sum_{m, co} dy[p + m - 1][co] * w_bwd[ci][m][co]        (m: flipped tap, patch offset (m/3, m%3))
+//   dw[co][t][ci] += sum_p dy[p][co] * x[p + t - 1][ci];     db[co] += sum_p dy[p][co]
+//
+// Layout per workgroup (256 threads = 4 waves, a tile = 8 rows x 16 columns):
+//   sG  dY patch  [10 x 18 pixels][16 co]  bf16, 32 B per pixel      sX  x patch  [10 x 18][16 ci]      sW  w_bwd [16 ci][10 taps][16 co]
+//   (tap 9 = zeros: K = 9 x 16 = 144 is padded to 5 k-steps of 32).  32-byte pixel pitch: conflict-free for the ds_read_b128 of the
+//   input-gradient fragments (conv_common.h: r = 2 slots) and for the transposed 8-byte reads of the weight gradient (8 consecutive
+//   pixels = 8 different 32-byte octets), because a fragment row is 16 consecutive pixels of ONE tile row (tow = 16).
+//   input gradient:  wave w owns tile rows 2w, 2w+1 (two 16-pixel fragments) x 16 ci: 5 k-steps x 2 = 10 MFMAs per tile, operands
+//                    swapped as in k_conv3x3 (accumulator = 4 consecutive channels of one pixel -> 8-byte stores, 512 B per fragment row)
+//   weight gradient: fragment f = tap f (16 columns = the 16 ci of one tap), wave w owns taps w, w+4, w+8: 4 k-steps x <= 3 MFMAs,
+//                    accumulated in registers over ALL tiles the workgroup walks, one set of fp32 atomics at the end
+//   bias gradient:   thread (co, phase) sums dY over the tile from LDS.
+// A workgroup walks `tiles_per_wg` consecutive tiles; the next tile's patches are loaded into registers before the MFMAs of the
+// current one (as k_wgrad3x3 does).  The grid is capped (tuning: bwd16_wgs) because every workgroup ends with 2304 + 16 atomics on the
+// SAME addresses.
+//
+// Built WITH -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py): the input-gradient accumulators are read every tile.
+#define COLVO_ACC_CONSTRAINT "+v"
+#include "conv_common.h"
+
+namespace colvo {
+namespace {
+
+constexpr int TOH = 8, TOW = 16, PH = TOH + 2, PW = TOW + 2, NPIX = PH * PW;   // 180 patch pixels
+constexpr int PIXB = 32;                                                    // bytes per patch pixel (16 bf16 channels)
+// bytes per ci row of sW: 10 taps x 16 co = 320, padded to 22 sixteen-byte slots -- the weight-fragment ds_read_b128 puts 8 ci rows
+// in a half group, conflict-free iff the row pitch is 2 (mod 4) slots (conv_common.h); 20 slots would take every such read twice
+constexpr int WROWB = 352;
+
+struct Bwd16K {
+    const char* dy;      // [B][H][W][16] bf16
+    const char* x;       // [B][H][W][16] bf16: the layer's input (post-ReLU)
+    const char* w_bwd;   // [16 ci][9 flipped taps][16 co] bf16
+    char* dx;            // [B][H][W][16] bf16
+    float* dw;           // [16 co][9][16 ci], added to
+    float* db;           // [16] or null
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles, tiles_per_wg;
+    int relu_mask;       // 1: dx is masked by x > 0
+    // HEAD form: `dy` is NOT the gradient but the layer's OUTPUT y (post-ReLU), and the gradient is made on the fly as the input
+    // gradient of the 3x3 16 -> 1 depth head behind the layer: dy[p][c] = (y[p][c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t]
+    const float* dpre;   // [B][H][W] fp32
+    const float* head_w; // [9][16] fp32
+};
+
+constexpr int DH = PH + 2, DW = PW + 2;                                      // d(pre) patch of the HEAD form: 12 x 20
+
+template <bool HEAD>
+__global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
+    __shared__ __attribute__((aligned(16))) char sG[NPIX * PIXB];
+    __shared__ __attribute__((aligned(16))) char sX[NPIX * PIXB];
+    __shared__ __attribute__((aligned(16))) char sW[16 * WROWB];
+    __shared__ float sdb[NT];
+    __shared__ __attribute__((aligned(16))) float sD[HEAD ? DH * DW : 4];       // d(pre) around the patch
+    __shared__ __attribute__((aligned(16))) float sWh[HEAD ? 9 * 16 : 4];       // head weights [tap][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+
+    // ---- weights: [ci][9][co] -> sW [ci][10][co], tap 9 zero ----
+    for (int i = tid; i < 16 * 10 * 2; i += NT) {                 // 16-byte granules: (ci, tap, half)
+        const int half = i & 1, tap = (i >> 1) % 10, ci = i / 20;
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (tap < 9) v = ld16(a.w_bwd + ((ci * 9 + tap) * 16 + half * 8) * 2);
+        st16(sW + ci * WROWB + tap * 32 + half * 16, v);
+    }
+
+    if constexpr (HEAD) {
+        if (tid < 9 * 16) sWh[tid] = a.head_w[tid];
+    }
+    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const long long img_bytes = (long long)a.H * a.W * 16 * 2;
+    const long long tot_bytes = img_bytes * a.B;
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)(tot_bytes < 0x7fffffffLL ? tot_bytes : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(tot_bytes < 0x7fffffffLL ? tot_bytes : 0x7fffffffLL), 0x00020000);
+
+    // ---- staging: 2 x 360 granules (patch pixel, channel half) over 256 threads: 3 per thread ----
+    constexpr int NGRAN = 2 * NPIX * 2;                            // 720
+    constexpr int PPF = (NGRAN + NT - 1) / NT;                     // 3
+    int s_which[PPF], s_py[PPF], s_px[PPF], s_lds[PPF], s_half[PPF];
+#pragma unroll
+    for (int it = 0; it < PPF; ++it) {
+        const int i = it * NT + tid;
+        const int which = i / (NPIX * 2), rem = i - which * (NPIX * 2);
+        const int pix = rem >> 1, half = rem & 1;
+        const int py = pix / PW, px = pix - py * PW;
+        s_which[it] = (i < NGRAN) ? which : 2;                    // 2: no granule
+        s_py[it] = py; s_px[it] = px; s_half[it] = half;
+        s_lds[it] = pix * PIXB + half * 16;
+    }
+    struct TileC { int b, ty, tx; };
+    auto tile_next = [&](TileC& c) {
+        if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.b; } }
+    };
+    TileC cur;
+    {
+        const int t = __builtin_amdgcn_readfirstlane(t_begin);
+        cur.b = t / tiles_per_img;
+        const int tr_ = t - cur.b * tiles_per_img;
+        cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
+    }
+    u32x4 pv[PPF];
+    float dpv = 0.0f;                                              // HEAD: this thread's element of the 12 x 20 d(pre) patch
+    const __amdgpu_buffer_rsrc_t rdp = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? a.dpre : nullptr), 0,
+                                                                          HEAD ? (int)((long long)a.B * a.H * a.W * 4) : 0, 0x00020000);
+    const int d_py = tid / DW, d_px = tid - d_py * DW;             // (tid < 240)
+    auto load_tile = [&](const TileC& c) {
+        const int oy0 = c.ty * TOH - 1, ox0 = c.tx * TOW - 1;
+        const int base = (int)((long long)c.b * img_bytes);       // (< 1 GiB per tensor: checked on the host)
+        if constexpr (HEAD) {
+            const int vy = oy0 - 1 + d_py, vx = ox0 - 1 + d_px;
+            const bool inb = tid < DH * DW && ((unsigned)vy < (unsigned)a.H) && ((unsigned)vx < (unsigned)a.W);
+            dpv = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rdp, inb ? (vy * a.W + vx) * 4 : OOB_OFF, c.b * a.H * a.W * 4, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            const int vy = oy0 + s_py[it], vx = ox0 + s_px[it];
+            const bool inb = ((unsigned)vy < (unsigned)a.H) && ((unsigned)vx < (unsigned)a.W);
+            const int off = inb ? ((vy * a.W + vx) * 16 + s_half[it] * 8) * 2 : OOB_OFF;
+            if (s_which[it] == 0) pv[it] = bld16(rdy, off, base);
+            else pv[it] = bld16(rx, s_which[it] == 1 ? off : OOB_OFF, base);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            if (s_which[it] == 0) { if constexpr (!HEAD) st16(sG + s_lds[it], pv[it]); }
+            else if (s_which[it] == 1) st16(sX + s_lds[it], pv[it]);
+        }
+        if constexpr (HEAD) {
+            if (tid < DH * DW) sD[tid] = dpv;
+        }
+    };
+    // HEAD: the gradient granules of this thread from its y granules (still in registers) and the d(pre) patch in LDS:
+    // g[c] = (y[c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t], rounded to bf16 as csrc/misc.hip k_depth_head_dgrad16 stores it
+    auto make_g = [&]() {
+#pragma unroll
+        for (int it = 0; it < PPF; ++it) {
+            if (s_which[it] != 0) continue;
+            float d[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) d[ky * 3 + kx] = sD[(s_py[it] + 2 - ky) * DW + s_px[it] + 2 - kx];
+            const unsigned yw[4] = {pv[it][0], pv[it][1], pv[it][2], pv[it][3]};
+            unsigned ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = s_half[it] * 8 + 2 * j;
+                float v0 = 0.0f, v1 = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { v0 += d[t] * sWh[t * 16 + c]; v1 += d[t] * sWh[t * 16 + c + 1]; }
+                const float y0 = bf2f((uint16_t)(yw[j] & 0xffffu)), y1 = bf2f((uint16_t)(yw[j] >> 16));
+                ow[j] = (unsigned)f2bf(y0 > 0.0f ? v0 : 0.0f) | ((unsigned)f2bf(y1 > 0.0f ? v1 : 0.0f) << 16);
+            }
+            st16(sG + s_lds[it], u32x4{ow[0], ow[1], ow[2], ow[3]});
+        }
+    };
+
+    // ---- per-lane constants of the two products ----
+    // input gradient: fragment mf = tile row 2 * wave + mf, pixel column l15
+    int g_base[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) g_base[mf] = ((2 * wave + mf) * PW + l15) * PIXB + (kg & 1) * 16;
+    const int w_base = l15 * WROWB + (kg & 1) * 16;                // + tap * 32
+    // weight gradient: K position (ks, kg, h, q) -> tile pixel p (k_wgrad3x3's order: a read group covers 8 consecutive pixels)
+    const int q = l15 >> 2, pp = lane & 3;
+    constexpr int FPW = 3;                                         // taps wave, wave + 4, wave + 8 (< 9)
+    // acc[0..1]: the input gradient of the current tile (cleared every tile); acc[2..4]: the weight gradient, carried over all tiles.
+    // ONE array so that one mfma_result_guard closes every chain at the end of a tile: hipcc rotates the carried accumulators
+    // through v_mov copies at the loop edge -- reads of MFMA results that must not come early (tools/isa_check_mfma.py)
+    f32x4 acc[2 + FPW];
+#pragma unroll
+    for (int fi = 0; fi < 2 + FPW; ++fi) acc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbacc = 0.0f;
+    const int db_co = tid & 15, db_ph = tid >> 4;                  // 16 phases x 8 pixels
+
+    if (t_begin < t_end) load_tile(cur);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if constexpr (HEAD) {
+            make_g();
+            __syncthreads();
+        }
+        const TileC here = cur;
+        tile_next(cur);
+        if (t + 1 < t_end) load_tile(cur);                         // in flight during the MFMAs below
+
+        if (a.db) {
+            float s0 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = db_ph * 8 + j;                       // tile pixel
+                s0 += bf2f(*reinterpret_cast<const uint16_t*>(sG + (((p >> 4) + 1) * PW + (p & 15) + 1) * PIXB + db_co * 2));
+            }
+            dbacc += s0;
+        }
+
+        // ---- input gradient: 5 k-steps of two taps each ----
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) {
+            const int tap = 2 * s + (kg >> 1);                     // 9: the zero tap
+            const int tp = tap > 8 ? 8 : tap;                      // its patch address: any valid one
+            const int ky = tp / 3, kx = tp - 3 * ky;
+            const u32x4 wv = ld16(sW + w_base + tap * 32);
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const u32x4 gv = ld16(sG + g_base[mf] + (ky * PW + kx) * PIXB);
+                acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, gv), acc[mf], 0, 0, 0);
+            }
+        }
+        // ---- weight gradient: 4 k-steps of 32 tile pixels, fragment = tap ----
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            int go[2], xo[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
+                const int oy = p >> 4, ox = p & 15;
+                go[h] = ((oy + 1) * PW + ox + 1) * PIXB + 4 * pp * 2;
+                xo[h] = (oy * PW + ox) * PIXB + 4 * pp * 2;
+            }
+            const s16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[0]));
+            const s16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[1]));
+            const s16x8 af = s16x8{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
+#pragma unroll
+            for (int fi = 0; fi < FPW; ++fi) {
+                const int tap = wave + 4 * fi;
+                if (tap < 9) {                                      // wave-uniform
+                    const int to = ((tap / 3) * PW + (tap % 3)) * PIXB;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + to));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + to));
+                    const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    acc[2 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[2 + fi], 0, 0, 0);
+                }
+            }
+        }
+        // ---- dx of this tile: mask by x > 0 (from the staged patch), 4 channels = 8 bytes per lane ----
+        mfma_result_guard<bf16_t>(acc);
+        {
+            const int oyt = here.ty * TOH, oxt = here.tx * TOW;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const int oy = 2 * wave + mf, ox = l15;
+                const int gy = oyt + oy, gx = oxt + ox;
+                f32x4 v = acc[mf];
+                if (a.relu_mask) {
+                    const u32x2 xm = *reinterpret_cast<const u32x2*>(sX + ((oy + 1) * PW + ox + 1) * PIXB + kg * 8);
+                    // bf16 > 0  <=>  sign bit clear and not zero
+                    const uint32_t m0 = xm[0] & 0xffffu, m1 = xm[0] >> 16, m2 = xm[1] & 0xffffu, m3 = xm[1] >> 16;
+                    v[0] = (m0 != 0 && m0 < 0x8000u) ? v[0] : 0.0f;
+                    v[1] = (m1 != 0 && m1 < 0x8000u) ? v[1] : 0.0f;
+                    v[2] = (m2 != 0 && m2 < 0x8000u) ? v[2] : 0.0f;
+                    v[3] = (m3 != 0 && m3 < 0x8000u) ? v[3] : 0.0f;
+                }
+                if (gy < a.H && gx < a.W) {
+                    u32x2 o;
+                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    *reinterpret_cast<u32x2*>(a.dx + (((long long)here.b * a.H + gy) * a.W + gx) * 32 + kg * 8) = o;
+                }
+            }
+        }
+    }
+
+    // ---- flush: dw[co][tap][ci] += accw (D rows = co 4 kg + r, cols = ci l15), db ----
+    mfma_result_guard<bf16_t>(acc);                 // (a workgroup without tiles never entered the loop)
+#pragma unroll
+    for (int fi = 0; fi < FPW; ++fi) {
+        const int tap = wave + 4 * fi;
+        if (tap < 9) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(a.dw + ((4 * kg + r) * 9 + tap) * 16 + l15, acc[2 + fi][r]);
+        }
+    }
+    if (a.db) {
+        __syncthreads();
+        sdb[tid] = dbacc;
+        __syncthreads();
+        if (tid < 16) {
+            float s = 0.0f;
+#pragma unroll
+            for (int ph = 0; ph < 16; ++ph) s += sdb[ph * 16 + tid];
+            atomicAdd(a.db + tid, s);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace colvo
+
+using namespace colvo;
+
+extern "C" int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d) {
+    if (!d) return 0;
+    const long long bytes = (long long)d->B * d->Hi * d->Wi * 16 * 2;
+    return d->dtype == COLVO_BF16 && d->ksize == 3 && d->stride == 1 && d->C0 == 16 && d->C1 == 0 && d->Cout == 16 && !d->up0 &&
+           d->Ho == d->Hi && d->Wo == d->Wi && bytes < 0x40000000LL && TUNE(bwd16) != 0;
+}
+
+extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* x, int relu_mask, void* dx,
+                                    float* dw, float* db, const float* head_dpre, const float* head_w, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(d && dy && w_bwd && x && dx && dw && ((head_dpre == nullptr) == (head_w == nullptr)),
+                    "colvo_conv_bwd_fused: null pointer argument");
+    COLVO_CHECK_ARG(colvo_conv_bwd_fused_ok(d), "colvo_conv_bwd_fused: only bf16 16 -> 16 stride-1 layers over one directly stored source "
+                                                "below 1 GiB per tensor (colvo_conv_bwd_fused_ok)");
+    Bwd16K k{};
+    k.dy = (const char*)dy; k.x = (const char*)x; k.w_bwd = (const char*)w_bwd; k.dx = (char*)dx; k.dw = dw; k.db = db;
+    k.B = d->B; k.H = d->Hi; k.W = d->Wi; k.relu_mask = relu_mask;
+    k.tiles_x = (k.W + TOW - 1) / TOW; k.tiles_y = (k.H + TOH - 1) / TOH;
+    k.ntiles = k.B * k.tiles_x * k.tiles_y;
+    // grid: bwd16_wgs workgroups (2 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
+    // 3.64 against 3.67 ms per step with 512), at most four times as many -- every workgroup ends with 2320 atomics on the same addresses
+    int wgs = (int)TUNE(bwd16_wgs);
+    wgs = std::max(wgs, std::min(4 * wgs, k.ntiles / 40));
+    if (wgs > k.ntiles) wgs = k.ntiles;
+    k.tiles_per_wg = (k.ntiles + wgs - 1) / wgs;
+    wgs = (k.ntiles + k.tiles_per_wg - 1) / k.tiles_per_wg;
+    k.dpre = head_dpre; k.head_w = head_w;
+    if (head_dpre) hipLaunchKernelGGL(k_bwd16<true>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(k_bwd16<false>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    COLVO_CHECK_LAUNCH("k_bwd16");
+    return 0;
+}

@@ -1112,7 +1112,7 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
                                           const float* scale_a, const float* scale_b, int B, int H, int W, int C,
                                           float min_depth, float max_depth, float* scratch, void* dx, float* dw, float* db,
                                           colvo_stream_t stream) {
-    COLVO_CHECK_ARG(x && w && depth && scratch && dx && ((dw == nullptr) == (db == nullptr)),
+    COLVO_CHECK_ARG(x && w && depth && scratch && ((dw == nullptr) == (db == nullptr)),
                     "colvo_depth_head_bwd_parts: null pointer argument");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_depth_head_bwd_parts: bad dtype");
     COLVO_CHECK_ARG(B >= 2 && B % 2 == 0 && B <= 65534 && H >= 1 && W >= 1 && C >= 1 && C <= 1024 && min_depth > 0 &&
@@ -1127,6 +1127,7 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
     if (dw) {
         if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
     }
+    if (!dx) return 0;          // d(pre) only: the input gradient is made by colvo_conv_bwd_fused's HEAD form from `scratch`
     if (C == 16 && ((uintptr_t)x | (uintptr_t)dx) % 16 == 0 && !head_dgrad_generic()) {
         DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
     } else {

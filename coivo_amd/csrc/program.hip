@@ -128,6 +128,9 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
                                        c.f[0], c.f[1], (void*)c.p[5], (float*)c.p[6], (float*)c.p[7], s);
         case COLVO_CMD_CONV_DGRAD_PLANES:
             return colvo_conv_dgrad_planes(&c.desc, c.p[0], (const float*)c.p[1], c.i[0], c.i[1], (float*)c.p[2], c.i[2], s);
+        case COLVO_CMD_CONV_BWD_FUSED:
+            return colvo_conv_bwd_fused(&c.desc, c.p[0], c.p[1], c.p[2], c.i[0], (void*)c.p[3], (float*)c.p[4], (float*)c.p[5],
+                                        (const float*)c.p[6], (const float*)c.p[7], s);
         case COLVO_CMD_WGRAD_REDUCE_GROUP:
             return colvo_wgrad_reduce_group((const ColvoWgradSlabs*)c.p[0], c.i[0], s);
         case COLVO_CMD_SIDE_SYNC:

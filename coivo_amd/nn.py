@@ -636,8 +636,14 @@ class DepthNet(_ArenaModule):
                 return dx
 
             x1 = A["iconv1"]
-            g = torch.empty_like(x1)
             scratch = torch.empty(B * H * W, device=dev, dtype=torch.float32)
+            # The narrow full-resolution layer (iconv1) takes its input gradient and weight gradient in ONE pass over its input and
+            # output (include/colvo.h colvo_conv_bwd_fused); in the training step's form of this call (gradient in parts) the head's
+            # input gradient is made inside that pass as well (HEAD form) and never touches memory.
+            fuse1 = (not self.deterministic and not self.group_wgrad and ops.conv_bwd_fused_ok(P["iconv1"]) and
+                     _lib.dev_env("COLVO_NO_BWD16") is None)
+            fuse_head = fuse1 and parts is not None and _lib.dev_env("COLVO_NO_BWD16_HEAD") is None
+            g = None if fuse_head else torch.empty_like(x1)
             # head: d(pre) + input gradient on the main stream, its weight gradient beside it like every other layer's
             if parts is None:
                 ops.depth_head_bwd(x1, self.head.w_master, depth, d_depth, scratch, g, None, None)
@@ -650,6 +656,20 @@ class DepthNet(_ArenaModule):
             for i in range(1, 6):                       # decoder, output side first
                 u = A[f"up{i}"]
                 skip = A[f"enc{i - 1}b"] if i >= 2 else None
+                Pi = P[f"iconv{i}"]
+                if i == 1 and fuse1:
+                    # on the main stream: d_u is the next layer's dy
+                    L = getattr(self, f"iconv{i}")
+                    d_u = torch.empty_like(u)
+                    if fuse_head:
+                        ops.conv_bwd_fused(Pi, x1, L.w_bwd, u, True, d_u, L.g_master, L.g_bias, scratch, self.head.w_master)
+                    else:
+                        ops.conv_bwd_fused(Pi, g, L.w_bwd, u, True, d_u, L.g_master, L.g_bias)
+                    self._layer_done(L)
+                    below = A[f"iconv{i + 1}"] if i < 5 else A["enc5b"]
+                    wgrad(f"up{i}", below, None, d_u)
+                    g = dgrad(f"up{i}", 0, d_u, below)
+                    continue
                 wgrad(f"iconv{i}", u, skip, g)
                 if skip is not None:                    # both sources' input gradients in one launch
                     L = getattr(self, f"iconv{i}")

@@ -85,6 +85,24 @@ def conv_dgrad_planes(d: ConvDesc, dy, w_master, c_begin: int, c_count: int, dst
                                            int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad_planes")
 
 
+def conv_bwd_fused_ok(d: ConvDesc) -> bool:
+    return bool(_lib.load().colvo_conv_bwd_fused_ok(C.byref(d)))
+
+
+def conv_bwd_fused(d: ConvDesc, dy, w_bwd, x, relu_mask: bool, dx, dw, db, head_dpre=None, head_w=None) -> None:
+    """Input gradient (written to dx, masked by x > 0 when relu_mask) and weight / bias gradient (added to dw / db) of a qualifying
+    narrow layer in one pass (include/colvo.h colvo_conv_bwd_fused).  head_dpre / head_w: the HEAD form -- `dy` is the layer's
+    OUTPUT and the gradient is made on the fly from the depth head's d(pre) plane and weights."""
+    _need_cuda(dy, w_bwd, x, dx, dw, db, head_dpre, head_w)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_BWD_FUSED, d, (dy, w_bwd, x, dx, dw, db, head_dpre, head_w), (int(relu_mask),))
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_bwd_fused(C.byref(d), _lib.ptr(dy), _lib.ptr(w_bwd), _lib.ptr(x), int(relu_mask), _lib.ptr(dx),
+                                        _lib.ptr(dw), _lib.ptr(db), _lib.ptr(head_dpre), _lib.ptr(head_w), _lib.stream_ptr()),
+               "colvo_conv_bwd_fused")
+
+
 def conv_wgrad_scratch(d: ConvDesc, device) -> torch.Tensor:
     """Scratch for the deterministic weight gradient of one conv call (include/colvo.h colvo_conv_wgrad_det)."""
     n = _lib.load().colvo_conv_wgrad_scratch_bytes(C.byref(d))

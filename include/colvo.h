@@ -190,6 +190,19 @@ int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_
 int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, const float* w_master, int c_begin, int c_count, float* dst,
                             int accumulate, colvo_stream_t stream);
 
+/* Input gradient AND weight / bias gradient of a narrow full-resolution layer in ONE pass (csrc/bwd16.hip): bf16, 16 -> 16 channels,
+ * stride 1, one directly stored source -- DepthNet's iconv1.  Both backward kernels of such a layer are HBM-bound and read the same
+ * two tensors (dy with a halo; the layer's input x as ReLU mask of dx and as second operand of dw): fused, the layer's backward is 3
+ * tensor passes instead of 5.  dx = (relu_mask ? x > 0 : 1) * (dy (*) w_bwd), written (not added); dw / db are ADDED to (fp32
+ * atomics: use the separate calls where bitwise repeatability is wanted).  colvo_conv_bwd_fused_ok: 1 when the layer qualifies. */
+int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d);
+/* head_dpre / head_w (both or neither): the HEAD form for the layer in front of the 3x3 16 -> 1 depth head.  `dy` is then NOT the
+ * gradient but the layer's OUTPUT y (post-ReLU) and the gradient is made on the fly from the head's d(pre) plane [B][H][W] (what
+ * colvo_depth_head_bwd / _bwd_parts leave in `scratch`; call them with dx = NULL) and its fp32 weights [9][16]:
+ * dy[p][c] = (y[p][c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t] -- the head's input gradient is never written or read back. */
+int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* x, int relu_mask, void* dx, float* dw,
+                         float* db, const float* head_dpre, const float* head_w, colvo_stream_t stream);
+
 /* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
  * (the caller zeroes them once per step). */
 int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
@@ -272,7 +285,8 @@ int colvo_depth_head_wgrad(int dtype, const void* x, const float* dpre, int B, i
  * frames first): with s = scale_a[0]*scale_b[0], d_depth[b] = g_first[b] + s*g_raw[b] for b < Bh,
  * g_second[b-Bh] + s*g_raw_second[b-Bh] for b >= Bh.  g_first, g_second, g_raw, g_raw_second: [Bh,1,H,W] each, any of them
  * may be NULL (= zero); scale_a, scale_b: device scalars, NULL = 1 (the fused loss hands over d_depth_raw with grad_loss and
- * loss_state + 1; the widened objective hands over finished gradients for both halves).  No concatenated / summed copy is made. */
+ * loss_state + 1; the widened objective hands over finished gradients for both halves).  No concatenated / summed copy is made.
+ * dx = NULL: d(pre) only (into `scratch`) -- the input gradient is then made by colvo_conv_bwd_fused's HEAD form. */
 int colvo_depth_head_bwd_parts(int dtype, const void* x, const float* w, const float* depth, const float* g_first,
                                const float* g_second, const float* g_raw, const float* g_raw_second, const float* scale_a,
                                const float* scale_b, int B, int H, int W, int C, float min_depth, float max_depth,
@@ -394,6 +408,7 @@ enum {
     COLVO_CMD_CONV_DGRAD_BOTH,    /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
     COLVO_CMD_WGRAD_REDUCE_GROUP, /* p: sets (HOST pointer to ColvoWgradSlabs[n], alive as long as the list); i: n */
     COLVO_CMD_CONV_DGRAD_PLANES,  /* p: dy w_master dst; i: c_begin c_count accumulate */
+    COLVO_CMD_CONV_BWD_FUSED,     /* p: dy w_bwd x dx dw db head_dpre head_w; i: relu_mask */
     COLVO_CMD_SIDE_SYNC           /* (side command) the side stream in use waits for everything enqueued so far on every other side
                                     stream: what follows reads what several FORKed commands wrote */
 };

@@ -471,3 +471,85 @@ def test_grouped_weight_gradient_equals_the_per_layer_deterministic_form():
         torch.cuda.synchronize()
         for (a, b), (fa, fb) in zip(outs, first):
             assert torch.equal(a, fa) and torch.equal(b, fb), dtype
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (3, 8, 16), (2, 256, 320)])
+@pytest.mark.parametrize("relu_mask", [True, False])
+def test_fused_backward_of_the_narrow_layer_equals_the_two_kernels(shape, relu_mask):
+    """colvo_conv_bwd_fused (bf16, 16 -> 16, stride 1): dx and dw / db against the separate input-gradient and weight-gradient
+    kernels on the same operands -- fp32 accumulation in both, so dx agrees to a bf16 rounding of the last bit and dw / db to the
+    summation order -- and against torch autograd on the bf16-rounded operands; ragged shapes (tiles are 8 x 16) included."""
+    from coivo_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(31)
+    dt = torch.bfloat16
+    d = ops.conv_desc(dt, B, H, W, 16, 16)
+    assert ops.conv_bwd_fused_ok(d)
+    x = torch.randn(B, H, W, 16, generator=g).relu().to(dev()).to(dt)           # post-ReLU input: ~half zeros
+    dy = torch.randn(B, H, W, 16, generator=g).to(dev()).to(dt)
+    w = torch.randn(16, 9, 16, generator=g) * 0.1                               # [Cout][9][Cin]
+    w_bwd = w.view(16, 9, 16).flip(1).permute(2, 1, 0).contiguous().to(dev()).to(dt)     # [Cin][9 flipped][Cout]
+    # reference: the two kernels
+    dx_ref = torch.empty_like(x)
+    ops.conv_dgrad(d, 0, dy, w_bwd, x if relu_mask else None, dx_ref, False)
+    dw_ref, db_ref = torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_wgrad(d, x, None, dy, dw_ref, db_ref)
+    dx = torch.full_like(x, 3.0)
+    dw, db = torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_bwd_fused(d, dy, w_bwd, x, relu_mask, dx, dw, db)
+    torch.cuda.synchronize()
+    sx = dx_ref.float().abs().max().item()
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= 2.0 ** -7 * sx       # one bf16 ulp of the largest element
+    assert ((dx.float() - dx_ref.float()).abs() > 1e-3 * sx).float().mean().item() < 1e-3
+    assert (dw - dw_ref).abs().max().item() <= 1e-4 * dw_ref.abs().max().item()
+    assert (db - db_ref).abs().max().item() <= 1e-4 * db_ref.abs().max().item() + 1e-4
+    # torch autograd on the same bf16-rounded operands
+    xt = x.float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = w.to(dt).float().view(16, 3, 3, 16).permute(0, 3, 1, 2).requires_grad_(True)
+    bt = torch.zeros(16, requires_grad=True)
+    y = F.conv2d(xt, wt, bt, padding=1)
+    y.backward(dy.float().cpu().permute(0, 3, 1, 2))
+    gx = xt.grad.permute(0, 2, 3, 1)
+    if relu_mask:
+        gx = gx * (x.float().cpu() > 0)
+    assert (dx.float().cpu() - gx).abs().max().item() <= 2.0 ** -6 * gx.abs().max().item()
+    gw = wt.grad.permute(0, 2, 3, 1).reshape(16, 9, 16)
+    assert (dw.cpu() - gw).abs().max().item() <= 2e-4 * gw.abs().max().item()
+    assert (db.cpu() - bt.grad).abs().max().item() <= 2e-4 * bt.grad.abs().max().item() + 1e-4
+    # accumulation into dw / db
+    ops.conv_bwd_fused(d, dy, w_bwd, x, relu_mask, dx, dw, db)
+    torch.cuda.synchronize()
+    assert (dw - 2 * dw_ref).abs().max().item() <= 2e-4 * dw_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (2, 256, 320)])
+def test_fused_backward_with_the_depth_head_gradient_made_on_the_fly(shape):
+    """colvo_conv_bwd_fused, HEAD form: `dy` is the layer's OUTPUT y and the gradient g = (y > 0) * (dpre (*) head_w) is made inside the
+    kernel from the depth head's d(pre) plane -- against the same call fed with g computed by torch (conv of dpre with the flipped head
+    weights, masked, rounded to bf16 as the head's own input-gradient kernel stores it)."""
+    from coivo_amd import ops
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(37)
+    dt = torch.bfloat16
+    d = ops.conv_desc(dt, B, H, W, 16, 16)
+    x = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(dt)
+    y = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(dt)                 # the layer's output (post-ReLU)
+    dpre = torch.randn(B, H, W, generator=gen).to(dev())
+    wh = (torch.randn(1, 9, 16, generator=gen) * 0.2).to(dev())                          # head weights [1][9][16]
+    w = torch.randn(16, 9, 16, generator=gen) * 0.1
+    w_bwd = w.flip(1).permute(2, 1, 0).contiguous().to(dev()).to(dt)
+    # g[b, p, c] = sum_t wh[t][c] * dpre[p + 1 - t]  ==  conv2d(dpre, kernel[c][0][ky][kx] = wh[(2 - ky) * 3 + (2 - kx)][c], padding 1)
+    k = wh[0].view(3, 3, 16).flip(0, 1).permute(2, 0, 1).unsqueeze(1).contiguous()       # [16, 1, 3, 3]
+    g = F.conv2d(dpre.unsqueeze(1), k, padding=1).permute(0, 2, 3, 1)                      # [B, H, W, 16] fp32
+    g = (g * (y.float() > 0)).to(dt).contiguous()
+    dx_ref, dw_ref, db_ref = torch.empty_like(x), torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_bwd_fused(d, g, w_bwd, x, True, dx_ref, dw_ref, db_ref)
+    dx, dw, db = torch.full_like(x, 5.0), torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_bwd_fused(d, y, w_bwd, x, True, dx, dw, db, dpre, wh)
+    torch.cuda.synchronize()
+    sx = dx_ref.float().abs().max().item()
+    # g itself may differ in the last bf16 bit where the two summation orders round differently: a few elements, one ulp each
+    assert (dx.float() - dx_ref.float()).abs().max().item() <= 2.0 ** -6 * sx
+    assert ((dx.float() - dx_ref.float()).abs() > 2e-3 * sx).float().mean().item() < 2e-3
+    assert (dw - dw_ref).abs().max().item() <= 2e-3 * dw_ref.abs().max().item()
+    assert (db - db_ref).abs().max().item() <= 2e-3 * db_ref.abs().max().item() + 1e-3
