@@ -50,18 +50,27 @@ struct Bwd16K {
     // gradient of the 3x3 16 -> 1 depth head behind the layer: dy[p][c] = (y[p][c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t]
     const float* dpre;   // [B][H][W] fp32
     const float* head_w; // [9][16] fp32
+    // HEAD form, optional: the head's own weight / bias gradient as well -- dWh[t][c] = sum_p dpre[p] y[p + t - 1][c], db_h = sum_p dpre[p]
+    // -- as one partial row of 9 * 16 + 1 floats per WAVE (4 rows per workgroup) for the table reduction of csrc/misc.hip
+    float* head_partials;
 };
 
 constexpr int DH = PH + 2, DW = PW + 2;                                      // d(pre) patch of the HEAD form: 12 x 20
 
-template <bool HEAD>
+// MODE 0: dy given.  1: HEAD form (dy made from the layer's output and the depth head's d(pre)).  2: HEAD form + the head's own weight
+// gradient.  Compile-time, not a kernel argument: a run-time branch around an MFMA makes hipcc merge the carried accumulators
+// through v_mov copies at the join -- reads of MFMA results in front of the guard (tools/isa_check_mfma.py).
+template <int MODE>
 __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
+    constexpr bool HEAD = MODE >= 1, headw = MODE == 2;
     __shared__ __attribute__((aligned(16))) char sG[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sX[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sW[16 * WROWB];
     __shared__ float sdb[NT];
     __shared__ __attribute__((aligned(16))) float sD[HEAD ? DH * DW : 4];       // d(pre) around the patch
     __shared__ __attribute__((aligned(16))) float sWh[HEAD ? 9 * 16 : 4];       // head weights [tap][c]
+    __shared__ __attribute__((aligned(16))) char sY[MODE == 2 ? NPIX * PIXB : 16];   // the layer's output patch (head weight gradient)
+    float hb = 0.0f;                                                            // (dWh itself: acc[5], rows c = 4 kg + r, column t = l15)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
 
@@ -134,7 +143,10 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
-            if (s_which[it] == 0) { if constexpr (!HEAD) st16(sG + s_lds[it], pv[it]); }
+            if (s_which[it] == 0) {
+                if constexpr (!HEAD) st16(sG + s_lds[it], pv[it]);
+                else if constexpr (headw) st16(sY + s_lds[it], pv[it]);
+            }
             else if (s_which[it] == 1) st16(sX + s_lds[it], pv[it]);
         }
         if constexpr (HEAD) {
@@ -179,9 +191,9 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
     // acc[0..1]: the input gradient of the current tile (cleared every tile); acc[2..4]: the weight gradient, carried over all tiles.
     // ONE array so that one mfma_result_guard closes every chain at the end of a tile: hipcc rotates the carried accumulators
     // through v_mov copies at the loop edge -- reads of MFMA results that must not come early (tools/isa_check_mfma.py)
-    f32x4 acc[2 + FPW];
+    f32x4 acc[2 + FPW + 1];                                        // (+ 1: the HEAD form's head weight gradient, see `acch`)
 #pragma unroll
-    for (int fi = 0; fi < 2 + FPW; ++fi) acc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int fi = 0; fi < 2 + FPW + 1; ++fi) acc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc = 0.0f;
     const int db_co = tid & 15, db_ph = tid >> 4;                  // 16 phases x 8 pixels
 
@@ -208,6 +220,39 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
             dbacc += s0;
         }
 
+        if constexpr (headw) {
+            {
+                // head weight gradient: wave w takes the 32 tile pixels of k-step w.  A = y^T by transposed reads (as the weight
+                // gradient below), B[q][t] = dpre[q + 1 - t] built from the fp32 d(pre) patch (bf16: like y), columns t >= 9 zero
+                int yo[2], p0[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 32 * wave + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1);        // + q: this lane's run of 4 K positions
+                    p0[h] = p;
+                    const int pq = p + q;
+                    yo[h] = (((pq >> 4) + 1) * PW + (pq & 15) + 1) * PIXB + 4 * pp * 2;
+                }
+                const s16x4 ylo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sY + yo[0]));
+                const s16x4 yhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sY + yo[1]));
+                const s16x8 ay = s16x8{ylo[0], ylo[1], ylo[2], ylo[3], yhi[0], yhi[1], yhi[2], yhi[3]};
+                const int t = l15 > 8 ? 8 : l15, ky = t / 3, kx = t - 3 * ky;
+                unsigned bw[4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // pixels p0[h] .. p0[h] + 3 lie in one tile row (runs of 4 never cross a multiple of 16)
+                    const float* dr = sD + ((p0[h] >> 4) + 3 - ky) * DW + (p0[h] & 15) + 3 - kx;    // sD(py + 2 - ky, px + 2 - kx), patch = tile + 1
+                    const float d0 = l15 < 9 ? dr[0] : 0.0f, d1 = l15 < 9 ? dr[1] : 0.0f, d2 = l15 < 9 ? dr[2] : 0.0f, d3 = l15 < 9 ? dr[3] : 0.0f;
+                    bw[2 * h] = (unsigned)f2bf(d0) | ((unsigned)f2bf(d1) << 16);
+                    bw[2 * h + 1] = (unsigned)f2bf(d2) | ((unsigned)f2bf(d3) << 16);
+                }
+                const u32x4 bd = u32x4{bw[0], bw[1], bw[2], bw[3]};
+                acc[2 + FPW] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[2 + FPW], 0, 0, 0);
+                if (lane < 32) {                                      // bias: this wave's 32 pixels
+                    const int p = 32 * wave + lane;
+                    hb += sD[((p >> 4) + 2) * DW + (p & 15) + 2];
+                }
+            }
+        }
         // ---- input gradient: 5 k-steps of two taps each ----
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -287,6 +332,17 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
             for (int r = 0; r < 4; ++r) atomicAdd(a.dw + ((4 * kg + r) * 9 + tap) * 16 + l15, acc[2 + fi][r]);
         }
     }
+    if constexpr (headw) {
+        {
+            float* row = a.head_partials + ((size_t)blockIdx.x * 4 + wave) * (9 * 16 + 1);
+            if (l15 < 9) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) row[l15 * 16 + 4 * kg + r] = acc[2 + FPW][r];
+            }
+            const float hbs = wave_sum(hb);
+            if (lane == 0) row[9 * 16] = hbs;
+        }
+    }
     if (a.db) {
         __syncthreads();
         sdb[tid] = dbacc;
@@ -312,9 +368,27 @@ extern "C" int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d) {
            d->Ho == d->Hi && d->Wo == d->Wi && bytes < 0x40000000LL && TUNE(bwd16) != 0;
 }
 
+static int bwd16_grid(const ColvoConvDesc* d, int* tiles_per_wg) {
+    const int ntiles = d->B * ((d->Wi + TOW - 1) / TOW) * ((d->Hi + TOH - 1) / TOH);
+    // grid: bwd16_wgs workgroups (2 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
+    // 3.64 against 3.67 ms per step with 512), at most four times as many -- every workgroup ends with 2320 atomics on the same addresses
+    int wgs = (int)TUNE(bwd16_wgs);
+    wgs = std::max(wgs, std::min(4 * wgs, ntiles / 40));
+    if (wgs > ntiles) wgs = ntiles;
+    const int tpw = (ntiles + wgs - 1) / wgs;
+    if (tiles_per_wg) *tiles_per_wg = tpw;
+    return (ntiles + tpw - 1) / tpw;
+}
+
+extern "C" int colvo_conv_bwd_fused_head_rows(const ColvoConvDesc* d) {
+    if (!colvo_conv_bwd_fused_ok(d)) return 0;
+    return 4 * bwd16_grid(d, nullptr);
+}
+
 extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* x, int relu_mask, void* dx,
-                                    float* dw, float* db, const float* head_dpre, const float* head_w, colvo_stream_t stream) {
-    COLVO_CHECK_ARG(d && dy && w_bwd && x && dx && dw && ((head_dpre == nullptr) == (head_w == nullptr)),
+                                    float* dw, float* db, const float* head_dpre, const float* head_w, float* head_partials,
+                                    colvo_stream_t stream) {
+    COLVO_CHECK_ARG(d && dy && w_bwd && x && dx && dw && ((head_dpre == nullptr) == (head_w == nullptr)) && (!head_partials || head_dpre),
                     "colvo_conv_bwd_fused: null pointer argument");
     COLVO_CHECK_ARG(colvo_conv_bwd_fused_ok(d), "colvo_conv_bwd_fused: only bf16 16 -> 16 stride-1 layers over one directly stored source "
                                                 "below 1 GiB per tensor (colvo_conv_bwd_fused_ok)");
@@ -323,16 +397,11 @@ extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, cons
     k.B = d->B; k.H = d->Hi; k.W = d->Wi; k.relu_mask = relu_mask;
     k.tiles_x = (k.W + TOW - 1) / TOW; k.tiles_y = (k.H + TOH - 1) / TOH;
     k.ntiles = k.B * k.tiles_x * k.tiles_y;
-    // grid: bwd16_wgs workgroups (2 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
-    // 3.64 against 3.67 ms per step with 512), at most four times as many -- every workgroup ends with 2320 atomics on the same addresses
-    int wgs = (int)TUNE(bwd16_wgs);
-    wgs = std::max(wgs, std::min(4 * wgs, k.ntiles / 40));
-    if (wgs > k.ntiles) wgs = k.ntiles;
-    k.tiles_per_wg = (k.ntiles + wgs - 1) / wgs;
-    wgs = (k.ntiles + k.tiles_per_wg - 1) / k.tiles_per_wg;
-    k.dpre = head_dpre; k.head_w = head_w;
-    if (head_dpre) hipLaunchKernelGGL(k_bwd16<true>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL(k_bwd16<false>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    const int wgs = bwd16_grid(d, &k.tiles_per_wg);
+    k.dpre = head_dpre; k.head_w = head_w; k.head_partials = head_partials;
+    if (head_partials) hipLaunchKernelGGL(k_bwd16<2>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    else if (head_dpre) hipLaunchKernelGGL(k_bwd16<1>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    else hipLaunchKernelGGL(k_bwd16<0>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
     COLVO_CHECK_LAUNCH("k_bwd16");
     return 0;
 }

@@ -1169,6 +1169,13 @@ extern "C" int colvo_depth_head_wgrad_det(int dtype, const void* x, const float*
     return depth_head_wgrad_impl(dtype, x, dpre, B, H, W, C, dw, db, (float*)scratch, scratch_bytes, stream);
 }
 
+extern "C" int colvo_depth_head_wgrad_reduce(const float* partials, int rows, float* dw, float* db, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(partials && dw && db && rows >= 1, "colvo_depth_head_wgrad_reduce: bad arguments");
+    hipLaunchKernelGGL(k_head_wgrad_reduce, dim3(9 * 16 + 1), dim3(NT), 0, (hipStream_t)stream, partials, rows, 9 * 16 + 1, dw, db);
+    COLVO_CHECK_LAUNCH("k_head_wgrad_reduce");
+    return 0;
+}
+
 static int depth_head_wgrad_impl(int dtype, const void* x, const float* dpre, int B, int H, int W, int C, float* dw, float* db,
                                  float* partials, size_t partial_bytes, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && dpre && dw && db, "colvo_depth_head_wgrad: null pointer argument");

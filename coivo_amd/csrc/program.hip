@@ -130,7 +130,12 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
             return colvo_conv_dgrad_planes(&c.desc, c.p[0], (const float*)c.p[1], c.i[0], c.i[1], (float*)c.p[2], c.i[2], s);
         case COLVO_CMD_CONV_BWD_FUSED:
             return colvo_conv_bwd_fused(&c.desc, c.p[0], c.p[1], c.p[2], c.i[0], (void*)c.p[3], (float*)c.p[4], (float*)c.p[5],
-                                        (const float*)c.p[6], (const float*)c.p[7], s);
+                                        (const float*)c.p[6], (const float*)c.p[7], (float*)c.p[8], s);
+        case COLVO_CMD_CONV_HEAD_FUSED:
+            return colvo_conv_head_fused(&c.desc, c.p[0], c.p[1], (const float*)c.p[2], (const float*)c.p[3], (const float*)c.p[4], c.f[0],
+                                         c.f[1], (void*)c.p[5], (float*)c.p[6], s);
+        case COLVO_CMD_HEAD_WGRAD_REDUCE:
+            return colvo_depth_head_wgrad_reduce((const float*)c.p[0], c.i[0], (float*)c.p[1], (float*)c.p[2], s);
         case COLVO_CMD_WGRAD_REDUCE_GROUP:
             return colvo_wgrad_reduce_group((const ColvoWgradSlabs*)c.p[0], c.i[0], s);
         case COLVO_CMD_SIDE_SYNC:

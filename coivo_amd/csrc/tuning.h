@@ -58,6 +58,8 @@ namespace tune {
     X(wgrad_team_wgs, 256, "... grid size of the team form")                                                                        \
     X(bwd16, 1, "input + weight gradient of the 16 -> 16 full-resolution layer in one pass (k_bwd16, csrc/bwd16.hip)")                \
     X(bwd16_wgs, 512, "... its grid: every workgroup ends with 2320 atomics on the same addresses")                                  \
+    X(fwd16, 1, "the 16 -> 16 full-resolution layer and the depth head behind it in one pass (k_fwd16_head, csrc/fwd16.hip)")          \
+    X(fwd16_wgs, 1024, "... its grid (at least; one workgroup per 8 tiles beyond that)")                                              \
     /* ---- heads, fused loss, streams ---- */                                                                                      \
     X(head_wgrad_rows, 1, "tap rows per thread of the depth-head weight gradient (1: three workgroups per pixel range)")            \
     X(head_fwd_lds, 1, "depth-head forward stages its tile in LDS (24.7 -> 18.5 us)")                                               \

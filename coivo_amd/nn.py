@@ -594,8 +594,16 @@ class DepthNet(_ArenaModule):
             for i in range(1, 6):
                 x = _conv(x, getattr(self, f"enc{i}a"), P[f"enc{i}a"]); A[f"enc{i}a"] = x
                 x = _conv(x, getattr(self, f"enc{i}b"), P[f"enc{i}b"]); A[f"enc{i}b"] = x
+            fuse_top = ops.conv_head_fused_ok(P["iconv1"]) and _lib.dev_env("COLVO_NO_FWD16") is None
             for i in range(5, 0, -1):
                 x = _conv(x, getattr(self, f"up{i}"), P[f"up{i}"]); A[f"up{i}"] = x
+                if i == 1 and fuse_top:
+                    # the narrow full-resolution layer and the depth head in one pass: its 42 MB output is written, not read back
+                    L = self.iconv1
+                    y = torch.empty(P["iconv1"].B, P["iconv1"].Ho, P["iconv1"].Wo, 16, device=x.device, dtype=x.dtype)
+                    ops.conv_head_fused(P["iconv1"], x, L.w_fwd, L.bias.data, self.head.w_master, self.head.bias.data, y, depth)
+                    A["iconv1"] = x = y
+                    return A
                 x = _conv(x, getattr(self, f"iconv{i}"), P[f"iconv{i}"], A[f"enc{i - 1}b"] if i >= 2 else None)
                 A[f"iconv{i}"] = x
             ops.depth_head_fwd(x, self.head.w_master, self.head.bias.data, depth)
@@ -650,8 +658,13 @@ class DepthNet(_ArenaModule):
             else:
                 ops.depth_head_bwd_parts(x1, self.head.w_master, depth, *parts[:5], scratch, g,
                                          parts[5] if len(parts) > 5 else None)
-            self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
-                                                                    self.deterministic), x1, scratch)
+            # (the head's OWN weight gradient can ride along too -- colvo_conv_bwd_fused's head_partials -- and measured no gain: it
+            # leaves the side streams, where it overlapped, for the main chain: 1.464 against 1.455 ms at configs[1], 3.729 against
+            # 3.732 at the configs[3] shape; developer switch COLVO_BWD16_HEADW=1)
+            fuse_headw = fuse_head and _lib.dev_env("COLVO_BWD16_HEADW") is not None
+            if not fuse_headw:
+                self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
+                                                                        self.deterministic), x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
             for i in range(1, 6):                       # decoder, output side first
                 u = A[f"up{i}"]
@@ -661,7 +674,12 @@ class DepthNet(_ArenaModule):
                     # on the main stream: d_u is the next layer's dy
                     L = getattr(self, f"iconv{i}")
                     d_u = torch.empty_like(u)
-                    if fuse_head:
+                    if fuse_headw:
+                        rows = ops.conv_bwd_fused_head_rows(Pi)
+                        hp = torch.empty(rows * 145, device=dev, dtype=torch.float32)
+                        ops.conv_bwd_fused(Pi, x1, L.w_bwd, u, True, d_u, L.g_master, L.g_bias, scratch, self.head.w_master, hp)
+                        self._run_wgrad(self.head, lambda: ops.depth_head_wgrad_reduce(hp, rows, self.head.g_master, self.head.g_bias), hp)
+                    elif fuse_head:
                         ops.conv_bwd_fused(Pi, x1, L.w_bwd, u, True, d_u, L.g_master, L.g_bias, scratch, self.head.w_master)
                     else:
                         ops.conv_bwd_fused(Pi, g, L.w_bwd, u, True, d_u, L.g_master, L.g_bias)

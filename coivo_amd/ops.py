@@ -85,22 +85,53 @@ def conv_dgrad_planes(d: ConvDesc, dy, w_master, c_begin: int, c_count: int, dst
                                            int(accumulate), _lib.stream_ptr()), "colvo_conv_dgrad_planes")
 
 
+def conv_head_fused_ok(d: ConvDesc) -> bool:
+    return bool(_lib.load().colvo_conv_head_fused_ok(C.byref(d)))
+
+
+def conv_head_fused(d: ConvDesc, x, w_fwd, bias, head_w, head_b, y, depth) -> None:
+    """The narrow full-resolution layer and the depth head behind it in one pass (include/colvo.h colvo_conv_head_fused): writes the
+    layer's output y (NHWC bf16) and depth [B,1,H,W] fp32."""
+    _need_cuda(x, w_fwd, bias, head_w, head_b, y, depth)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_CONV_HEAD_FUSED, d, (x, w_fwd, bias, head_w, head_b, y, depth), (), (MIN_DEPTH, MAX_DEPTH))
+    lib = _lib.load()
+    _lib.check(lib.colvo_conv_head_fused(C.byref(d), _lib.ptr(x), _lib.ptr(w_fwd), _lib.ptr(bias), _lib.ptr(head_w), _lib.ptr(head_b),
+                                         MIN_DEPTH, MAX_DEPTH, _lib.ptr(y), _lib.ptr(depth), _lib.stream_ptr()), "colvo_conv_head_fused")
+
+
 def conv_bwd_fused_ok(d: ConvDesc) -> bool:
     return bool(_lib.load().colvo_conv_bwd_fused_ok(C.byref(d)))
 
 
-def conv_bwd_fused(d: ConvDesc, dy, w_bwd, x, relu_mask: bool, dx, dw, db, head_dpre=None, head_w=None) -> None:
+def conv_bwd_fused(d: ConvDesc, dy, w_bwd, x, relu_mask: bool, dx, dw, db, head_dpre=None, head_w=None, head_partials=None) -> None:
     """Input gradient (written to dx, masked by x > 0 when relu_mask) and weight / bias gradient (added to dw / db) of a qualifying
     narrow layer in one pass (include/colvo.h colvo_conv_bwd_fused).  head_dpre / head_w: the HEAD form -- `dy` is the layer's
-    OUTPUT and the gradient is made on the fly from the depth head's d(pre) plane and weights."""
-    _need_cuda(dy, w_bwd, x, dx, dw, db, head_dpre, head_w)
+    OUTPUT and the gradient is made on the fly from the depth head's d(pre) plane and weights; head_partials
+    ([conv_bwd_fused_head_rows(d), 145] floats): the head's own weight gradient as partial rows for depth_head_wgrad_reduce."""
+    _need_cuda(dy, w_bwd, x, dx, dw, db, head_dpre, head_w, head_partials)
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_CONV_BWD_FUSED, d, (dy, w_bwd, x, dx, dw, db, head_dpre, head_w), (int(relu_mask),))
+        return rec.add(_lib.CMD_CONV_BWD_FUSED, d, (dy, w_bwd, x, dx, dw, db, head_dpre, head_w, head_partials), (int(relu_mask),))
     lib = _lib.load()
     _lib.check(lib.colvo_conv_bwd_fused(C.byref(d), _lib.ptr(dy), _lib.ptr(w_bwd), _lib.ptr(x), int(relu_mask), _lib.ptr(dx),
-                                        _lib.ptr(dw), _lib.ptr(db), _lib.ptr(head_dpre), _lib.ptr(head_w), _lib.stream_ptr()),
-               "colvo_conv_bwd_fused")
+                                        _lib.ptr(dw), _lib.ptr(db), _lib.ptr(head_dpre), _lib.ptr(head_w), _lib.ptr(head_partials),
+                                        _lib.stream_ptr()), "colvo_conv_bwd_fused")
+
+
+def conv_bwd_fused_head_rows(d: ConvDesc) -> int:
+    return int(_lib.load().colvo_conv_bwd_fused_head_rows(C.byref(d)))
+
+
+def depth_head_wgrad_reduce(partials, rows: int, dw, db) -> None:
+    """dw [9][16] / db [1] += the column sums of partials [rows][145] (fixed order)."""
+    _need_cuda(partials, dw, db)
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_HEAD_WGRAD_REDUCE, None, (partials, dw, db), (int(rows),))
+    _lib.check(_lib.load().colvo_depth_head_wgrad_reduce(_lib.ptr(partials), int(rows), _lib.ptr(dw), _lib.ptr(db), _lib.stream_ptr()),
+               "colvo_depth_head_wgrad_reduce")
 
 
 def conv_wgrad_scratch(d: ConvDesc, device) -> torch.Tensor:

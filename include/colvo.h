@@ -190,6 +190,15 @@ int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, const void* w_
 int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, const float* w_master, int c_begin, int c_count, float* dst,
                             int accumulate, colvo_stream_t stream);
 
+/* The narrow full-resolution layer (bf16, 16 -> 16, stride 1, ReLU, one directly stored source: DepthNet's iconv1) AND the 3x3
+ * 16 -> 1 depth head behind it in ONE pass (csrc/fwd16.hip): y = relu(conv(x, w_fwd) + bias) is written (the backward pass needs it)
+ * and the head is evaluated on it from LDS -- depth = 1 / (1/max + (1/min - 1/max) sigmoid(conv(y, head_w) + head_b)), [B,1,H,W] fp32 --
+ * so the 42 MB tensor is not read back (colvo_conv_fwd + colvo_depth_head_fwd: 21 + 18 us at 16 frames of 256x320).
+ * colvo_conv_head_fused_ok: 1 when the layer qualifies. */
+int colvo_conv_head_fused_ok(const ColvoConvDesc* d);
+int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, const void* w_fwd, const float* bias, const float* head_w,
+                          const float* head_b, float min_depth, float max_depth, void* y, float* depth, colvo_stream_t stream);
+
 /* Input gradient AND weight / bias gradient of a narrow full-resolution layer in ONE pass (csrc/bwd16.hip): bf16, 16 -> 16 channels,
  * stride 1, one directly stored source -- DepthNet's iconv1.  Both backward kernels of such a layer are HBM-bound and read the same
  * two tensors (dy with a halo; the layer's input x as ReLU mask of dx and as second operand of dw): fused, the layer's backward is 3
@@ -200,8 +209,14 @@ int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d);
  * gradient but the layer's OUTPUT y (post-ReLU) and the gradient is made on the fly from the head's d(pre) plane [B][H][W] (what
  * colvo_depth_head_bwd / _bwd_parts leave in `scratch`; call them with dx = NULL) and its fp32 weights [9][16]:
  * dy[p][c] = (y[p][c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t] -- the head's input gradient is never written or read back. */
+/* head_partials (HEAD form only, optional): the depth head's OWN weight / bias gradient rides along as well -- the kernel has y and
+ * d(pre) staged anyway -- as colvo_conv_bwd_fused_head_rows(d) partial rows of 9 * 16 + 1 floats (one per wave, plain stores), which
+ * colvo_depth_head_wgrad_reduce then adds to the head's dw [9][16] / db [1] in a fixed order: the 42 MB pass of colvo_depth_head_wgrad
+ * over y disappears. */
 int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* x, int relu_mask, void* dx, float* dw,
-                         float* db, const float* head_dpre, const float* head_w, colvo_stream_t stream);
+                         float* db, const float* head_dpre, const float* head_w, float* head_partials, colvo_stream_t stream);
+int colvo_conv_bwd_fused_head_rows(const ColvoConvDesc* d);
+int colvo_depth_head_wgrad_reduce(const float* partials, int rows, float* dw, float* db, colvo_stream_t stream);
 
 /* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
  * (the caller zeroes them once per step). */
@@ -408,7 +423,9 @@ enum {
     COLVO_CMD_CONV_DGRAD_BOTH,    /* p: dy w_bwd relu_mask0 relu_mask1 dx0 dx1 */
     COLVO_CMD_WGRAD_REDUCE_GROUP, /* p: sets (HOST pointer to ColvoWgradSlabs[n], alive as long as the list); i: n */
     COLVO_CMD_CONV_DGRAD_PLANES,  /* p: dy w_master dst; i: c_begin c_count accumulate */
-    COLVO_CMD_CONV_BWD_FUSED,     /* p: dy w_bwd x dx dw db head_dpre head_w; i: relu_mask */
+    COLVO_CMD_CONV_BWD_FUSED,     /* p: dy w_bwd x dx dw db head_dpre head_w head_partials; i: relu_mask */
+    COLVO_CMD_HEAD_WGRAD_REDUCE,  /* p: partials dw db; i: rows */
+    COLVO_CMD_CONV_HEAD_FUSED,    /* p: x w_fwd bias head_w head_b y depth; f: min_depth max_depth */
     COLVO_CMD_SIDE_SYNC           /* (side command) the side stream in use waits for everything enqueued so far on every other side
                                     stream: what follows reads what several FORKed commands wrote */
 };

@@ -553,3 +553,70 @@ def test_fused_backward_with_the_depth_head_gradient_made_on_the_fly(shape):
     assert ((dx.float() - dx_ref.float()).abs() > 2e-3 * sx).float().mean().item() < 2e-3
     assert (dw - dw_ref).abs().max().item() <= 2e-3 * dw_ref.abs().max().item()
     assert (db - db_ref).abs().max().item() <= 2e-3 * db_ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (2, 256, 320)])
+def test_fused_backward_carries_the_depth_heads_weight_gradient(shape):
+    """colvo_conv_bwd_fused with head_partials: the head's dw [9][16] / db [1] from the partial rows (colvo_depth_head_wgrad_reduce)
+    against colvo_depth_head_wgrad on the same y and d(pre) (the fold rounds d(pre) to bf16 for its MFMA: 2^-9 per term), and dx / dw
+    of the layer unchanged by the extra output (bitwise dx)."""
+    from coivo_amd import _lib, ops
+    import ctypes as C
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(41)
+    dt = torch.bfloat16
+    d = ops.conv_desc(dt, B, H, W, 16, 16)
+    x = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(dt)
+    y = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(dt)
+    dpre = torch.randn(B, H, W, generator=gen).to(dev())
+    wh = (torch.randn(1, 9, 16, generator=gen) * 0.2).to(dev())
+    w_bwd = (torch.randn(16, 9, 16, generator=gen) * 0.1).to(dev()).to(dt)
+    dx0, dw0, db0 = torch.empty_like(x), torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_bwd_fused(d, y, w_bwd, x, True, dx0, dw0, db0, dpre, wh)
+    rows = ops.conv_bwd_fused_head_rows(d)
+    assert rows >= 4 and rows % 4 == 0
+    hp = torch.full((rows * 145,), float("nan"), device=dev())
+    dx1, dw1, db1 = torch.empty_like(x), torch.zeros(16, 9, 16, device=dev()), torch.zeros(16, device=dev())
+    ops.conv_bwd_fused(d, y, w_bwd, x, True, dx1, dw1, db1, dpre, wh, hp)
+    hdw, hdb = torch.zeros(1, 9, 16, device=dev()), torch.zeros(1, device=dev())
+    ops.depth_head_wgrad_reduce(hp, rows, hdw, hdb)
+    rdw, rdb = torch.zeros(1, 9, 16, device=dev()), torch.zeros(1, device=dev())
+    ops.depth_head_wgrad(y, dpre, rdw, rdb)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    assert (dw0 - dw1).abs().max().item() <= 1e-4 * dw0.abs().max().item()
+    assert torch.isfinite(hp).all()
+    assert (hdw - rdw).abs().max().item() <= 4e-3 * rdw.abs().max().item(), ((hdw - rdw).abs().max().item(), rdw.abs().max().item())
+    assert abs(hdb.item() - rdb.item()) <= 1e-4 * max(1.0, abs(rdb.item())) + 1e-3 * dpre.abs().sum().item() * 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (3, 8, 16), (2, 256, 320)])
+def test_fused_layer_and_depth_head_forward_equals_the_two_kernels(shape):
+    """colvo_conv_head_fused (bf16, 16 -> 16 + the 3x3 16 -> 1 depth head): y against colvo_conv_fwd (same fp32 accumulation up to the
+    summation order: a bf16 rounding of the last bit on a few elements), depth against colvo_depth_head_fwd on that y."""
+    from coivo_amd import ops
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(43)
+    dt = torch.bfloat16
+    d = ops.conv_desc(dt, B, H, W, 16, 16)
+    assert ops.conv_head_fused_ok(d)
+    x = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(dt)
+    w = (torch.randn(16, 9, 16, generator=gen) * 0.15).to(dev()).to(dt)                  # [Cout][9][Cin]
+    bias = (torch.randn(16, generator=gen) * 0.1).to(dev())
+    wh = (torch.randn(1, 9, 16, generator=gen) * 0.2).to(dev())
+    bh = torch.tensor([0.3], device=dev())
+    y_ref = torch.empty(B, H, W, 16, device=dev(), dtype=dt)
+    ops.conv_fwd(d, x, None, w, bias, y_ref)
+    depth_ref = torch.empty(B, 1, H, W, device=dev())
+    ops.depth_head_fwd(y_ref, wh, bh, depth_ref)
+    y = torch.full_like(y_ref, 9.0)
+    depth = torch.full_like(depth_ref, -1.0)
+    ops.conv_head_fused(d, x, w, bias, wh, bh, y, depth)
+    torch.cuda.synchronize()
+    sy = y_ref.float().abs().max().item()
+    assert (y.float() - y_ref.float()).abs().max().item() <= 2.0 ** -7 * sy
+    assert ((y.float() - y_ref.float()).abs() > 0).float().mean().item() < 2e-3
+    # depth in (0.1, 10): compare 1 / depth (the sigmoid's scale); the few y elements that differ by one bf16 ulp move it by ~1e-3 relative
+    inv, inv_ref = 1.0 / depth, 1.0 / depth_ref
+    assert (depth > 0.0999).all() and (depth < 10.001).all()
+    assert (inv - inv_ref).abs().max().item() <= 2e-2 and ((inv - inv_ref).abs() > 1e-4).float().mean().item() < 5e-3

@@ -337,4 +337,4 @@ def test_grouped_slab_weight_gradients_equal_the_default_form(dtype):
     assert sorted(seen) == sorted(spans) and seen == sorted(seen, reverse=True), seen[:4]
     twice = run(True, passes=2)
     for c, t in zip(g1[:2], twice[:2]):
-        assert (t - 2 * c).abs().max().item() <= 1e-5 * c.abs().max().item()
+        assert (t - 2 * c).abs().max().item() <= 1e-4 * c.abs().max().item()       # (the two heads' gradients still end in float atomics)
