@@ -153,6 +153,15 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
             if (tid < DH * DW) sD[tid] = dpv;
         }
     };
+    // (this thread's granules all have channel half tid & 1: its 9 x 8 head weights live in registers -- from LDS they were 72 more
+    // LDS reads per granule in a kernel that is VALU / LDS-issue bound)
+    float whr[9][8];
+    if constexpr (HEAD) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) whr[t][j] = a.head_w[t * 16 + (tid & 1) * 8 + j];
+    }
     // HEAD: the gradient granules of this thread from its y granules (still in registers) and the d(pre) patch in LDS:
     // g[c] = (y[c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t], rounded to bf16 as csrc/misc.hip k_depth_head_dgrad16 stores it
     auto make_g = [&]() {
@@ -168,10 +177,13 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
             unsigned ow[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int c = s_half[it] * 8 + 2 * j;
                 float v0 = 0.0f, v1 = 0.0f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) { v0 += d[t] * sWh[t * 16 + c]; v1 += d[t] * sWh[t * 16 + c + 1]; }
+#ifdef COLVO_BWD16_LDS_WH           // developer A/B build only: head weights from LDS instead of registers
+                for (int t = 0; t < 9; ++t) { v0 += d[t] * sWh[t * 16 + s_half[it] * 8 + 2 * j]; v1 += d[t] * sWh[t * 16 + s_half[it] * 8 + 2 * j + 1]; }
+#else
+                for (int t = 0; t < 9; ++t) { v0 += d[t] * whr[t][2 * j]; v1 += d[t] * whr[t][2 * j + 1]; }
+#endif
                 const float y0 = bf2f((uint16_t)(yw[j] & 0xffffu)), y1 = bf2f((uint16_t)(yw[j] >> 16));
                 ow[j] = (unsigned)f2bf(y0 > 0.0f ? v0 : 0.0f) | ((unsigned)f2bf(y1 > 0.0f ? v1 : 0.0f) << 16);
             }
@@ -356,10 +368,137 @@ __global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
     }
 }
 
+// ---- the depth head's weight / bias gradient by MFMA (colvo_depth_head_wgrad_mfma) ----
+// dWh[t][c] = sum_p dpre[p] y[p + t - 1][c] = sum_q y[q][c] dpre[q + 1 - t], db = sum_p dpre[p]: a [16 c] x [9 t] product over the pixels.
+// The VALU kernel of csrc/misc.hip (thread = strided pixels, 48 accumulators, nine scattered d(pre) loads per pixel) runs at 26 + 5 us
+// for a 47 MB read at 16 frames -- on the weight-gradient streams, which are what ends the backward pass at 8 pairs.  Here a workgroup
+// walks 8 x 16 tiles: y tile (256 granules, one per thread) and the 10 x 18 d(pre) patch in LDS, wave w takes the 32 pixels of k-step
+// w: A = y^T by transposed reads, B[q][t] = dpre[q + 1 - t] rounded to bf16 (as y is), ONE MFMA per wave and tile; partial rows per
+// wave for the table reduction (k_head_wgrad_reduce).
+struct HeadWgradK {
+    const char* y;          // [B][H][W][16] bf16
+    const float* dpre;      // [B][H][W]
+    float* partials;        // [4 * grid][145]
+    int B, H, W;
+    int tiles_x, tiles_y, ntiles, tiles_per_wg;
+};
+
+__global__ __launch_bounds__(NT, 4) void k_head_wgrad_mfma(const HeadWgradK a) {
+    __shared__ __attribute__((aligned(16))) char sY[TOH * TOW * PIXB];          // tile pixels only
+    __shared__ __attribute__((aligned(16))) float sD[PH * PW];                   // d(pre) on tile + 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4, q = l15 >> 2, pp = lane & 3;
+    const int t_begin = blockIdx.x * a.tiles_per_wg;
+    const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const long long img_bytes = (long long)a.H * a.W * 16 * 2;
+    const long long tot_bytes = img_bytes * a.B;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)(tot_bytes < 0x7fffffffLL ? tot_bytes : 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dpre, 0, (int)((long long)a.B * a.H * a.W * 4), 0x00020000);
+    const int g_pix = tid >> 1, g_half = tid & 1;                 // this thread's y granule: tile pixel, channel half
+    const int g_oy = g_pix >> 4, g_ox = g_pix & 15;
+    const int d_py = tid / PW, d_px = tid - d_py * PW;             // (tid < 180) its d(pre) patch element
+    struct TileC { int b, ty, tx; };
+    auto tile_next = [&](TileC& c) {
+        if (++c.tx == a.tiles_x) { c.tx = 0; if (++c.ty == a.tiles_y) { c.ty = 0; ++c.b; } }
+    };
+    TileC cur;
+    {
+        const int t = __builtin_amdgcn_readfirstlane(t_begin);
+        cur.b = t / tiles_per_img;
+        const int tr_ = t - cur.b * tiles_per_img;
+        cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
+    }
+    u32x4 yv = u32x4{0u, 0u, 0u, 0u};
+    float dv = 0.0f;
+    auto load_tile = [&](const TileC& c) {
+        const int oy0 = c.ty * TOH, ox0 = c.tx * TOW;
+        {
+            const int vy = oy0 + g_oy, vx = ox0 + g_ox;
+            const bool inb = vy < a.H && vx < a.W;
+            yv = bld16(ry, inb ? ((vy * a.W + vx) * 16 + g_half * 8) * 2 : OOB_OFF, (int)((long long)c.b * img_bytes));
+        }
+        {
+            const int vy = oy0 - 1 + d_py, vx = ox0 - 1 + d_px;
+            const bool inb = tid < PH * PW && ((unsigned)vy < (unsigned)a.H) && ((unsigned)vx < (unsigned)a.W);
+            dv = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rd, inb ? (vy * a.W + vx) * 4 : OOB_OFF, c.b * a.H * a.W * 4, 0));
+        }
+    };
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    float hb = 0.0f;
+    // this lane's K positions of k-step `wave`: two runs of 4 consecutive tile pixels (k_wgrad3x3's order)
+    int yo[2], p0[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        p0[h] = 32 * wave + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1);
+        yo[h] = (p0[h] + q) * PIXB + 4 * pp * 2;
+    }
+    const int t9 = l15 > 8 ? 8 : l15, ky = t9 / 3, kx = t9 - 3 * ky;
+    if (t_begin < t_end) load_tile(cur);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        st16(sY + g_pix * PIXB + g_half * 16, yv);
+        if (tid < PH * PW) sD[tid] = dv;
+        __syncthreads();
+        tile_next(cur);
+        if (t + 1 < t_end) load_tile(cur);
+        const s16x4 ylo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sY + yo[0]));
+        const s16x4 yhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sY + yo[1]));
+        const s16x8 ay = s16x8{ylo[0], ylo[1], ylo[2], ylo[3], yhi[0], yhi[1], yhi[2], yhi[3]};
+        unsigned bw[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // dpre[q + 1 - t] for the run's 4 pixels: patch coordinates (oy + 1 + 1 - ky, ox + 1 + 1 - kx)
+            const float* dr = sD + ((p0[h] >> 4) + 2 - ky) * PW + (p0[h] & 15) + 2 - kx;
+            const float d0 = l15 < 9 ? dr[0] : 0.0f, d1 = l15 < 9 ? dr[1] : 0.0f, d2 = l15 < 9 ? dr[2] : 0.0f, d3 = l15 < 9 ? dr[3] : 0.0f;
+            bw[2 * h] = (unsigned)f2bf(d0) | ((unsigned)f2bf(d1) << 16);
+            bw[2 * h + 1] = (unsigned)f2bf(d2) | ((unsigned)f2bf(d3) << 16);
+        }
+        const u32x4 bd = u32x4{bw[0], bw[1], bw[2], bw[3]};
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[0], 0, 0, 0);
+        if (lane < 32) {
+            const int p = 32 * wave + lane;
+            hb += sD[((p >> 4) + 1) * PW + (p & 15) + 1];
+        }
+        mfma_result_guard<bf16_t>(acc);                 // (carried across the loop: closed every tile, see k_bwd16)
+    }
+    float* row = a.partials + ((size_t)blockIdx.x * 4 + wave) * (9 * 16 + 1);
+    if (l15 < 9) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[l15 * 16 + 4 * kg + r] = acc[0][r];
+    }
+    const float hbs = wave_sum(hb);
+    if (lane == 0) row[9 * 16] = hbs;
+}
+
 }  // namespace
 }  // namespace colvo
 
 using namespace colvo;
+
+static int head_wgrad_mfma_grid(int B, int H, int W, int* tiles_per_wg) {
+    const int ntiles = B * ((W + TOW - 1) / TOW) * ((H + TOH - 1) / TOH);
+    int wgs = std::min(ntiles, 1024);
+    const int tpw = (ntiles + wgs - 1) / wgs;
+    if (tiles_per_wg) *tiles_per_wg = tpw;
+    return (ntiles + tpw - 1) / tpw;
+}
+
+extern "C" int colvo_depth_head_wgrad_mfma_rows(int B, int H, int W) {
+    if (B < 1 || H < 1 || W < 1 || (long long)B * H * W * 32 >= 0x40000000LL) return 0;
+    return 4 * head_wgrad_mfma_grid(B, H, W, nullptr);
+}
+
+extern "C" int colvo_depth_head_wgrad_mfma(const void* y, const float* dpre, int B, int H, int W, float* partials, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(y && dpre && partials && colvo_depth_head_wgrad_mfma_rows(B, H, W) > 0, "colvo_depth_head_wgrad_mfma: bad arguments");
+    HeadWgradK k{};
+    k.y = (const char*)y; k.dpre = dpre; k.partials = partials; k.B = B; k.H = H; k.W = W;
+    k.tiles_x = (W + TOW - 1) / TOW; k.tiles_y = (H + TOH - 1) / TOH; k.ntiles = B * k.tiles_x * k.tiles_y;
+    const int wgs = head_wgrad_mfma_grid(B, H, W, &k.tiles_per_wg);
+    hipLaunchKernelGGL(k_head_wgrad_mfma, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    COLVO_CHECK_LAUNCH("k_head_wgrad_mfma");
+    return 0;
+}
 
 extern "C" int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d) {
     if (!d) return 0;

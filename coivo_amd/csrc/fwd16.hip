@@ -15,7 +15,10 @@
 //   sY  y on [10 x 18 positions][16 co] bf16
 //   layer:  position fragments of 16 consecutive patch positions (12 fragments cover 192 >= 180), wave w owns fragments 3w .. 3w + 2;
 //           5 k-steps of two taps; operands swapped as in k_conv3x3 (accumulator = 4 consecutive channels of one position)
-//   head:   two threads per centre pixel (8 channels each, 9 x 16-byte LDS reads), halves joined by a DPP quad swap.
+//   head:   an MFMA of the same shape (16 pixels x K = 9 taps x 16 channels) against a weight operand whose row 0 is the bf16 rounding
+//           of the fp32 head weights and row 1 what that rounding left over: hi + lo sums = the fp32-weight product to 2^-17.  (The
+//           first version evaluated the head on the VALU, two threads per pixel: 280 of the kernel's ~480 issue slots per wave and
+//           tile -- the kernel was issue-bound at 33.6 us in the step for 89 MB of traffic.)
 // A workgroup walks `tiles_per_wg` consecutive tiles with the next tile's patch in flight during the MFMAs.
 #define COLVO_ACC_CONSTRAINT "+v"
 #include "conv_common.h"
@@ -45,7 +48,10 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
     __shared__ __attribute__((aligned(16))) char sU[NU * PIXB];
     __shared__ __attribute__((aligned(16))) char sY[(NY + 12) * PIXB];        // (+ 12: the dummy positions 180 .. 191 of the last fragment)
     __shared__ __attribute__((aligned(16))) char sW[16 * WROWB];
-    __shared__ __attribute__((aligned(16))) float sWh[9 * 16];
+    // head weights as an MFMA operand: [16 rows][10 taps][16 c] bf16 like sW; row 0 = the bf16 rounding of the fp32 weights, row 1 = the
+    // bf16 rounding of what that left over (hi + lo carries 16 mantissa bits: the sum of the two rows' products is the fp32-weight
+    // product to 2^-17), rows 2..15 zero
+    __shared__ __attribute__((aligned(16))) char sWh[16 * WROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
 
@@ -55,7 +61,16 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
         if (tap < 9) v = ld16(a.w + ((co * 9 + tap) * 16 + half * 8) * 2);
         st16(sW + co * WROWB + tap * 32 + half * 16, v);
     }
-    if (tid < 9 * 16) sWh[tid] = a.head_w[tid];
+    for (int i = tid; i < 16 * WROWB / 4; i += NT) reinterpret_cast<uint32_t*>(sWh)[i] = 0u;
+    __syncthreads();
+    if (tid < 9 * 16) {
+        const int tq = tid >> 4, c = tid & 15;
+        const float wv = a.head_w[tid];
+        const uint16_t hi = f2bf(wv);
+        const uint16_t lo = f2bf(wv - bf2f(hi));
+        *reinterpret_cast<uint16_t*>(sWh + 0 * WROWB + tq * 32 + c * 2) = hi;
+        *reinterpret_cast<uint16_t*>(sWh + 1 * WROWB + tq * 32 + c * 2) = lo;
+    }
     const float hb = a.head_b[0];
     // bias of this lane's 4 output channels (4 kg .. 4 kg + 3)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 4 * kg);
@@ -115,9 +130,10 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
         u_base[j] = (py * UW + px) * PIXB + (kg & 1) * 16;        // input patch pixel of tap (0, 0)
     }
     const int w_base = l15 * WROWB + (kg & 1) * 16;
-    // head: thread pair per centre pixel
-    const int hp = tid >> 1, hh = tid & 1;
-    const int h_oy = hp >> 4, h_ox = hp & 15;
+    // head: an MFMA like the layer's -- fragment mf = tile row 2 wave + mf, 16 pixels; D rows 0 / 1 (lanes kg == 0) = hi / lo sums
+    int hy_base[2];
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) hy_base[mf] = ((2 * wave + mf) * YW + l15) * PIXB + (kg & 1) * 16;
 
     if (t_begin < t_end) load_tile(cur);
     for (int t = t_begin; t < t_end; ++t) {
@@ -161,27 +177,32 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
             if (centre && inimg) *reinterpret_cast<u32x2*>(a.y + (((long long)here.b * a.H + gy) * a.W + gx) * 32 + kg * 8) = o;
         }
         __syncthreads();
-        // ---- head on the 128 centre pixels ----
+        // ---- head on the 128 centre pixels: 5 k-steps of two taps, 2 MFMAs each ----
         {
-            float s0 = 0.0f;
+            f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int tq = 0; tq < 9; ++tq) {
-                const int ky = tq / 3, kx = tq - 3 * ky;
-                const u32x4 yv = ld16(sY + ((h_oy + ky) * YW + h_ox + kx) * PIXB + hh * 16);
-                const float* wt = sWh + tq * 16 + hh * 8;
+            for (int s = 0; s < 5; ++s) {
+                const int tap = 2 * s + (kg >> 1);
+                const int tp = tap > 8 ? 8 : tap;
+                const int ky = tp / 3, kx = tp - 3 * ky;
+                const u32x4 wv = ld16(sWh + w_base + tap * 32);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    s0 = fmaf(__uint_as_float(yv[k] << 16), wt[2 * k], s0);
-                    s0 = fmaf(__uint_as_float(yv[k] & 0xffff0000u), wt[2 * k + 1], s0);
+                for (int mf = 0; mf < 2; ++mf) {
+                    const u32x4 yv = ld16(sY + hy_base[mf] + (ky * YW + kx) * PIXB);
+                    hacc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, yv), hacc[mf], 0, 0, 0);
                 }
             }
-            // the pair's other half: lanes 2i and 2i + 1 swap (DPP quad_perm [1, 0, 3, 2])
-            const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s0), 0xB1, 0xf, 0xf, false));
-            const float pre = hb + (s0 + other);
-            const int gy = oyt + h_oy, gx = oxt + h_ox;
-            if (hh == 0 && gy < a.H && gx < a.W) {
-                const float sig = 1.0f / (1.0f + expf(-pre));
-                a.depth[((long long)here.b * a.H + gy) * a.W + gx] = 1.0f / (a.lo + (a.hi - a.lo) * sig);
+            mfma_result_guard<bf16_t>(hacc);
+            if (kg == 0) {
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf) {
+                    const float pre = hb + (hacc[mf][0] + hacc[mf][1]);
+                    const int gy = oyt + 2 * wave + mf, gx = oxt + l15;
+                    if (gy < a.H && gx < a.W) {
+                        const float sig = 1.0f / (1.0f + expf(-pre));
+                        a.depth[((long long)here.b * a.H + gy) * a.W + gx] = 1.0f / (a.lo + (a.hi - a.lo) * sig);
+                    }
+                }
             }
         }
     }

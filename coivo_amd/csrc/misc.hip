@@ -888,9 +888,24 @@ __global__ __launch_bounds__(NT) void k_zero_multi(ZeroArenas zs) {
 // PoseNet's first layer takes [tgt rgb | ref rgb | depth_t | depth_r]; of its input gradient only the two depth channels are wanted,
 // as fp32 NCHW planes for DepthNet's backward pass.  The general path computed all 8 channels of the 256x320 gradient with the MFMA
 // kernel (24 us at 8 pairs: it is a write of 10.5 MB NHWC for 0.4 GFLOP) and then unpacked two of them (+5 us), on the critical path
-// between the two networks' backward passes.  Here: one thread per input pixel, dx[c] = sum over the <= 4 (stride 2) or 9 (stride 1)
-// output pixels that see it and over Cout of w[co][tap][c] dy[co] -- 72 FMAs per pixel and channel pair at stride 2 -- weights of the
-// wanted channels in LDS as [tap][co][c], dy rows through L2 (neighbouring pixels share them), planes written coalesced.
+// between the two networks' backward passes.  Here: dx[c] = sum over the output pixels that see the input pixel and over Cout of
+// w[co][tap][c] dy[co], weights of the wanted channels in LDS as [tap][co][c], dy rows through L2, planes written coalesced.
+// Stride 2: a thread takes a PAIR of horizontally adjacent input pixels (2m, 2m + 1) -- the even one sees the middle tap column of
+// output column m, the odd one the right column of m and the left column of m + 1 -- so every lane of a wave runs the same taps (with a
+// thread per pixel the lanes alternated between the two parity classes: every tap body ran under half an EXEC mask, 21 us in the step).
+template <int ES>
+__device__ __forceinline__ void load_row16(const char* row, int co, float (&v)[8]) {
+    if constexpr (ES == 2) {
+        const uint4 q = *reinterpret_cast<const uint4*>(row + co * 2);
+        const uint32_t u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(u[j] << 16); v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
+    } else {
+        const float4 q0 = *reinterpret_cast<const float4*>(row + co * 4), q1 = *reinterpret_cast<const float4*>(row + co * 4 + 16);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    }
+}
+
 template <int ES, int NC>
 __global__ __launch_bounds__(NT) void k_conv_dgrad_planes(const void* __restrict__ dy, const float* __restrict__ w, int Cout, int Cin,
                                                           int c_begin, int B, int Hi, int Wi, int Ho, int Wo, int S,
@@ -902,6 +917,53 @@ __global__ __launch_bounds__(NT) void k_conv_dgrad_planes(const void* __restrict
     }
     __syncthreads();
     const size_t HW = (size_t)Hi * Wi;
+    if (S == 2) {
+        const int Wp = (Wi + 1) >> 1;                   // pixel pairs per row
+        const size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
+        if (p >= (size_t)B * Hi * Wp) return;
+        const int b = (int)(p / ((size_t)Hi * Wp));
+        const int r = (int)(p - (size_t)b * Hi * Wp);
+        const int iy = r / Wp, m = r - iy * Wp;
+        float a0[NC], a1[NC];                           // pixel 2m, pixel 2m + 1
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { a0[c] = 0.0f; a1[c] = 0.0f; }
+        const char* dyb = (const char*)dy + (size_t)b * Ho * Wo * Cout * ES;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;                 // 2 oy
+            if (ty < 0 || (ty & 1)) continue;           // (wave-uniform: a wave holds pixels of one row or two)
+            const int oy = ty >> 1;
+            if (oy >= Ho) continue;
+            const char* r0 = dyb + ((size_t)oy * Wo + m) * Cout * ES;            // output column m
+            const bool has1 = m + 1 < Wo;                                        // output column m + 1 (left tap of the odd pixel)
+            const float* w0 = sw + (ky * 3 + 0) * Cout * NC, *w1 = sw + (ky * 3 + 1) * Cout * NC, *w2 = sw + (ky * 3 + 2) * Cout * NC;
+            for (int co = 0; co < Cout; co += 8) {
+                float v[8], u[8];
+                load_row16<ES>(r0, co, v);
+                if (has1) load_row16<ES>(r0 + Cout * ES, co, u);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) u[j] = 0.0f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        a0[c] = fmaf(w1[(co + j) * NC + c], v[j], a0[c]);                       // 2m     + 1 - 1 = 2 m
+                        a1[c] = fmaf(w2[(co + j) * NC + c], v[j], a1[c]);                       // 2m + 1 + 1 - 2 = 2 m
+                        a1[c] = fmaf(w0[(co + j) * NC + c], u[j], a1[c]);                       // 2m + 1 + 1 - 0 = 2 (m + 1)
+                    }
+            }
+        }
+        const int ix = 2 * m;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float* d = dst + ((size_t)c * B + b) * HW + (size_t)iy * Wi + ix;   // [c][B][1][Hi][Wi]
+            d[0] = accumulate ? d[0] + a0[c] : a0[c];
+            if (ix + 1 < Wi) d[1] = accumulate ? d[1] + a1[c] : a1[c];
+        }
+        return;
+    }
     const size_t p = (size_t)blockIdx.x * NT + threadIdx.x;
     if (p >= (size_t)B * HW) return;
     const int b = (int)(p / HW);
@@ -913,29 +975,17 @@ __global__ __launch_bounds__(NT) void k_conv_dgrad_planes(const void* __restrict
     const char* dyb = (const char*)dy + (size_t)b * Ho * Wo * Cout * ES;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int ty = iy + 1 - ky;                     // S * oy
-        if (ty < 0 || (S == 2 && (ty & 1))) continue;
-        const int oy = S == 2 ? ty >> 1 : ty;
-        if (oy >= Ho) continue;
+        const int oy = iy + 1 - ky;
+        if (oy < 0 || oy >= Ho) continue;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int tx = ix + 1 - kx;
-            if (tx < 0 || (S == 2 && (tx & 1))) continue;
-            const int ox = S == 2 ? tx >> 1 : tx;
-            if (ox >= Wo) continue;
+            const int ox = ix + 1 - kx;
+            if (ox < 0 || ox >= Wo) continue;
             const char* row = dyb + ((size_t)oy * Wo + ox) * Cout * ES;
             const float* wt = sw + (ky * 3 + kx) * Cout * NC;
             for (int co = 0; co < Cout; co += 8) {
                 float v[8];
-                if constexpr (ES == 2) {
-                    const uint4 q = *reinterpret_cast<const uint4*>(row + co * 2);
-                    const uint32_t u[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(u[j] << 16); v[2 * j + 1] = __uint_as_float(u[j] & 0xffff0000u); }
-                } else {
-                    const float4 q0 = *reinterpret_cast<const float4*>(row + co * 4), q1 = *reinterpret_cast<const float4*>(row + co * 4 + 16);
-                    v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w; v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
-                }
+                load_row16<ES>(row, co, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -1036,7 +1086,7 @@ extern "C" int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, c
                     c_begin + c_count <= d->C0,
                     "colvo_conv_dgrad_planes: Cout a multiple of 8 up to 128, 1 / 2 / 4 channels inside [0, C0) (Cout=%d, channels %d..%d of %d)",
                     d->Cout, c_begin, c_begin + c_count - 1, d->C0);
-    const size_t npix = (size_t)d->B * d->Hi * d->Wi;
+    const size_t npix = d->stride == 2 ? (size_t)d->B * d->Hi * ((d->Wi + 1) / 2) : (size_t)d->B * d->Hi * d->Wi;   // threads
     const size_t lds = (size_t)9 * d->Cout * c_count * 4;
     hipStream_t s = (hipStream_t)stream;
 #define COLVO_DGP(ES_, NC_)                                                                                                        \

@@ -134,6 +134,8 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
         case COLVO_CMD_CONV_HEAD_FUSED:
             return colvo_conv_head_fused(&c.desc, c.p[0], c.p[1], (const float*)c.p[2], (const float*)c.p[3], (const float*)c.p[4], c.f[0],
                                          c.f[1], (void*)c.p[5], (float*)c.p[6], s);
+        case COLVO_CMD_HEAD_WGRAD_MFMA:
+            return colvo_depth_head_wgrad_mfma(c.p[0], (const float*)c.p[1], c.i[0], c.i[1], c.i[2], (float*)c.p[2], s);
         case COLVO_CMD_HEAD_WGRAD_REDUCE:
             return colvo_depth_head_wgrad_reduce((const float*)c.p[0], c.i[0], (float*)c.p[1], (float*)c.p[2], s);
         case COLVO_CMD_WGRAD_REDUCE_GROUP:

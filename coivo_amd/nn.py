@@ -663,8 +663,13 @@ class DepthNet(_ArenaModule):
             # 3.732 at the configs[3] shape; developer switch COLVO_BWD16_HEADW=1)
             fuse_headw = fuse_head and _lib.dev_env("COLVO_BWD16_HEADW") is not None
             if not fuse_headw:
-                self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
-                                                                        self.deterministic), x1, scratch)
+                if self.compute_dtype == torch.bfloat16 and _lib.dev_env("COLVO_NO_HEAD_WGRAD_MFMA") is None:
+                    # the head's weight gradient by MFMA (partial rows + table reduction: reproducible in every mode)
+                    self._run_wgrad(self.head, lambda: ops.depth_head_wgrad_mfma(x1, scratch, self.head.g_master, self.head.g_bias),
+                                    x1, scratch)
+                else:
+                    self._run_wgrad(self.head, lambda: ops.depth_head_wgrad(x1, scratch, self.head.g_master, self.head.g_bias,
+                                                                            self.deterministic), x1, scratch)
             d_skip: Dict[int, torch.Tensor] = {}
             for i in range(1, 6):                       # decoder, output side first
                 u = A[f"up{i}"]

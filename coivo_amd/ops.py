@@ -124,6 +124,27 @@ def conv_bwd_fused_head_rows(d: ConvDesc) -> int:
     return int(_lib.load().colvo_conv_bwd_fused_head_rows(C.byref(d)))
 
 
+def depth_head_wgrad_mfma(y, dpre, dw, db) -> None:
+    """The 16-channel bf16 depth head's weight / bias gradient by MFMA: partial rows + the table reduction (two launches on the current
+    stream; include/colvo.h colvo_depth_head_wgrad_mfma)."""
+    _need_cuda(y, dpre, dw, db)
+    B, H, W, Cc = y.shape
+    if Cc != 16 or y.dtype != torch.bfloat16:
+        raise ValueError("depth_head_wgrad_mfma: the 16-channel bf16 head only")
+    lib = _lib.load()
+    rows = lib.colvo_depth_head_wgrad_mfma_rows(B, H, W)
+    if rows <= 0:
+        raise RuntimeError("colvo_depth_head_wgrad_mfma_rows failed")
+    hp = torch.empty(rows * 145, device=y.device, dtype=torch.float32)
+    rec = program.recording()
+    if rec is not None:
+        rec.add(_lib.CMD_HEAD_WGRAD_MFMA, None, (y, dpre, hp), (B, H, W))
+        return rec.add(_lib.CMD_HEAD_WGRAD_REDUCE, None, (hp, dw, db), (int(rows),))
+    _lib.check(lib.colvo_depth_head_wgrad_mfma(_lib.ptr(y), _lib.ptr(dpre), B, H, W, _lib.ptr(hp), _lib.stream_ptr()), "colvo_depth_head_wgrad_mfma")
+    _lib.check(lib.colvo_depth_head_wgrad_reduce(_lib.ptr(hp), int(rows), _lib.ptr(dw), _lib.ptr(db), _lib.stream_ptr()),
+               "colvo_depth_head_wgrad_reduce")
+
+
 def depth_head_wgrad_reduce(partials, rows: int, dw, db) -> None:
     """dw [9][16] / db [1] += the column sums of partials [rows][145] (fixed order)."""
     _need_cuda(partials, dw, db)

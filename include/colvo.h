@@ -217,6 +217,11 @@ int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_b
                          float* db, const float* head_dpre, const float* head_w, float* head_partials, colvo_stream_t stream);
 int colvo_conv_bwd_fused_head_rows(const ColvoConvDesc* d);
 int colvo_depth_head_wgrad_reduce(const float* partials, int rows, float* dw, float* db, colvo_stream_t stream);
+/* The 16-channel depth head's weight / bias gradient by MFMA (bf16 feature maps): partial rows ([colvo_depth_head_wgrad_mfma_rows(B, H,
+ * W)][9 * 16 + 1] floats, plain stores) from y [B][H][W][16] and the d(pre) plane, then colvo_depth_head_wgrad_reduce.  d(pre) enters
+ * the product rounded to bf16 (as y is); fixed order: bitwise repeatable.  colvo_depth_head_wgrad (VALU) stays the fp32 / generic form. */
+int colvo_depth_head_wgrad_mfma_rows(int B, int H, int W);
+int colvo_depth_head_wgrad_mfma(const void* y, const float* dpre, int B, int H, int W, float* partials, colvo_stream_t stream);
 
 /* Weight + bias gradient, fp32, ADDED into dw[Cout][ksize*ksize][C0+C1] and db[Cout]
  * (the caller zeroes them once per step). */
@@ -426,6 +431,7 @@ enum {
     COLVO_CMD_CONV_BWD_FUSED,     /* p: dy w_bwd x dx dw db head_dpre head_w head_partials; i: relu_mask */
     COLVO_CMD_HEAD_WGRAD_REDUCE,  /* p: partials dw db; i: rows */
     COLVO_CMD_CONV_HEAD_FUSED,    /* p: x w_fwd bias head_w head_b y depth; f: min_depth max_depth */
+    COLVO_CMD_HEAD_WGRAD_MFMA,    /* p: y dpre partials; i: B H W */
     COLVO_CMD_SIDE_SYNC           /* (side command) the side stream in use waits for everything enqueued so far on every other side
                                     stream: what follows reads what several FORKed commands wrote */
 };

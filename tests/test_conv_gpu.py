@@ -620,3 +620,27 @@ def test_fused_layer_and_depth_head_forward_equals_the_two_kernels(shape):
     inv, inv_ref = 1.0 / depth, 1.0 / depth_ref
     assert (depth > 0.0999).all() and (depth < 10.001).all()
     assert (inv - inv_ref).abs().max().item() <= 2e-2 and ((inv - inv_ref).abs() > 1e-4).float().mean().item() < 5e-3
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (2, 256, 320)])
+def test_depth_head_weight_gradient_by_mfma(shape):
+    """colvo_depth_head_wgrad_mfma (+ the table reduction) against the VALU kernel colvo_depth_head_wgrad on the same y and d(pre):
+    the MFMA form rounds d(pre) to bf16 (2^-9 per term); added to dw / db, bitwise repeatable."""
+    from coivo_amd import ops
+    B, H, W = shape
+    gen = torch.Generator().manual_seed(47)
+    y = torch.randn(B, H, W, 16, generator=gen).relu().to(dev()).to(torch.bfloat16)
+    dpre = torch.randn(B, H, W, generator=gen).to(dev())
+    rdw, rdb = torch.ones(1, 9, 16, device=dev()), torch.ones(1, device=dev())
+    ops.depth_head_wgrad(y, dpre, rdw, rdb)
+    outs = []
+    for _ in range(2):
+        dw, db = torch.ones(1, 9, 16, device=dev()), torch.ones(1, device=dev())
+        ops.depth_head_wgrad_mfma(y, dpre, dw, db)
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    dw, db = outs[0]
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    scale = (rdw - 1).abs().max().item()
+    assert (dw - rdw).abs().max().item() <= 4e-3 * scale, ((dw - rdw).abs().max().item(), scale)
+    assert abs(db.item() - rdb.item()) <= 1e-4 * abs(rdb.item() - 1) + 2e-3

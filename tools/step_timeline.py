@@ -21,9 +21,11 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"]))
     rows.sort()
+    # step boundaries: the fused update k_adam_pack (one launch per step, round 3 on) -- or, in traces of older builds, every second
+    # k_adam launch (one per arena)
+    pack_ends = [e for s, e, q, n in rows if "k_adam_pack" in n]
     adam_ends = [e for s, e, q, n in rows if "k_adam" in n]
-    # two k_adam launches per step (one per arena): step boundaries = every second one
-    bounds = adam_ends[1::2]
+    bounds = pack_ends if pack_ends else adam_ends[1::2]
     t0, t1 = bounds[-back - 1], bounds[-back]
     step = [r for r in rows if r[0] >= t0 and r[1] <= t1 + 1]
     print(f"step window {1e-3 * (t1 - t0):.1f} us, {len(step)} kernels")
