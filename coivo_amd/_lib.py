@@ -49,7 +49,7 @@ class Cmd(C.Structure):
 (CMD_CONV_FWD, CMD_CONV_DGRAD, CMD_CONV_WGRAD, CMD_PACK_NCHW, CMD_UNPACK_NHWC_GRAD, CMD_DEPTH_HEAD_FWD,
  CMD_DEPTH_HEAD_BWD, CMD_DEPTH_HEAD_WGRAD, CMD_POSE_HEAD_FWD, CMD_POSE_HEAD_BWD, CMD_FORK, CMD_JOIN,
  CMD_DEPTH_HEAD_BWD_PARTS, CMD_CONV_DGRAD_BOTH, CMD_WGRAD_REDUCE_GROUP, CMD_CONV_DGRAD_PLANES, CMD_CONV_BWD_FUSED,
- CMD_HEAD_WGRAD_REDUCE, CMD_CONV_HEAD_FUSED, CMD_HEAD_WGRAD_MFMA, CMD_SIDE_SYNC) = range(1, 22)
+ CMD_HEAD_WGRAD_REDUCE, CMD_CONV_HEAD_FUSED, CMD_PACK_STEM_POSE, CMD_HEAD_WGRAD_MFMA, CMD_SIDE_SYNC) = range(1, 23)
 NPTR = 12      # pointer slots of a ColvoCmd
 
 SIGNATURES = {
@@ -81,7 +81,8 @@ SIGNATURES = {
     "colvo_conv_dgrad_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "colvo_conv_dgrad_planes": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _i, _vp, _i, _vp]),
     "colvo_conv_head_fused_ok": (_i, [C.POINTER(ConvDesc)]),
-    "colvo_conv_head_fused": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "colvo_conv_head_fused": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp]),
+    "colvo_pack_stem_pose": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "colvo_conv_bwd_fused_ok": (_i, [C.POINTER(ConvDesc)]),
     "colvo_conv_bwd_fused": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "colvo_conv_bwd_fused_head_rows": (_i, [C.POINTER(ConvDesc)]),

@@ -39,6 +39,7 @@ struct Fwd16K {
     const float* head_b;  // [1]
     char* y;              // [B][H][W][16] bf16
     float* depth;         // [B][1][H][W] fp32
+    char* pose_in;        // optional: PoseNet's input [B / 2][H][W][8] bf16 -- depth of image b goes to channel 6 (b < B/2) or 7 of pair b mod B/2
     float lo, hi;         // 1 / max_depth, 1 / min_depth
     int B, H, W;
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
@@ -200,7 +201,12 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
                     const int gy = oyt + 2 * wave + mf, gx = oxt + l15;
                     if (gy < a.H && gx < a.W) {
                         const float sig = 1.0f / (1.0f + expf(-pre));
-                        a.depth[((long long)here.b * a.H + gy) * a.W + gx] = 1.0f / (a.lo + (a.hi - a.lo) * sig);
+                        const float dep = 1.0f / (a.lo + (a.hi - a.lo) * sig);
+                        a.depth[((long long)here.b * a.H + gy) * a.W + gx] = dep;
+                        if (a.pose_in) {
+                            const int Bh = a.B >> 1, pair = here.b < Bh ? here.b : here.b - Bh;
+                            *reinterpret_cast<uint16_t*>(a.pose_in + ((((long long)pair * a.H + gy) * a.W + gx) * 8 + 6 + (here.b >= Bh)) * 2) = f2bf(dep);
+                        }
                     }
                 }
             }
@@ -221,14 +227,16 @@ extern "C" int colvo_conv_head_fused_ok(const ColvoConvDesc* d) {
 }
 
 extern "C" int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, const void* w_fwd, const float* bias, const float* head_w,
-                                     const float* head_b, float min_depth, float max_depth, void* y, float* depth,
+                                     const float* head_b, float min_depth, float max_depth, void* y, float* depth, void* pose_in,
                                      colvo_stream_t stream) {
     COLVO_CHECK_ARG(d && x && w_fwd && bias && head_w && head_b && y && depth, "colvo_conv_head_fused: null pointer argument");
+    COLVO_CHECK_ARG(!pose_in || d->B % 2 == 0, "colvo_conv_head_fused: pose_in needs a pair batch (B = 2 * pairs)");
     COLVO_CHECK_ARG(colvo_conv_head_fused_ok(d), "colvo_conv_head_fused: only bf16 16 -> 16 stride-1 ReLU layers over one directly stored "
                                                  "source below 1 GiB per tensor (colvo_conv_head_fused_ok)");
     COLVO_CHECK_ARG(min_depth > 0 && max_depth > min_depth, "colvo_conv_head_fused: bad depth range");
     Fwd16K k{};
     k.x = (const char*)x; k.w = (const char*)w_fwd; k.bias = bias; k.head_w = head_w; k.head_b = head_b; k.y = (char*)y; k.depth = depth;
+    k.pose_in = (char*)pose_in;
     k.lo = 1.0f / max_depth; k.hi = 1.0f / min_depth;
     k.B = d->B; k.H = d->Hi; k.W = d->Wi;
     k.tiles_x = (k.W + TOW - 1) / TOW; k.tiles_y = (k.H + TOH - 1) / TOH;

@@ -148,6 +148,31 @@ __global__ __launch_bounds__(NT) void k_pack_nchw8(Planes src, int HW, void* __r
     }
 }
 
+// DepthNet's stem pack for the DCDP pair batch [target frames | reference frames] (bf16), which ALSO writes the six rgb channels of
+// PoseNet's 8-channel input [tgt rgb | ref rgb | depth_t | depth_r]: image i fills channels 0..2 (i < Bh) or 3..5 of pair i mod Bh.
+// The two depth channels are written by the depth head's kernel (csrc/fwd16.hip): PoseNet's own packing pass -- a read of the same
+// frames plus both depth maps, 13 us at 8 pairs on the forward chain -- disappears.
+// A thread takes one pixel of one PAIR (six plane reads in flight), so PoseNet's pixel is one full 16-byte store: its depth channels are
+// zero until the head's kernel -- later in the same pass -- writes them.
+__global__ __launch_bounds__(NT) void k_pack_stem_pose(const float* __restrict__ frames, int HW, int Bh, void* __restrict__ stem,
+                                                        void* __restrict__ pose_in) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const int p = blockIdx.y;
+    const size_t pix = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (pix >= (size_t)HW) return;
+    const float* t = frames + (size_t)p * 3 * HW + pix;
+    const float* r = frames + (size_t)(p + Bh) * 3 * HW + pix;
+    const float t0 = t[0], t1 = t[(size_t)HW], t2 = t[2 * (size_t)HW], r0 = r[0], r1 = r[(size_t)HW], r2 = r[2 * (size_t)HW];
+    const unsigned a0 = f2bf(t0), a1 = f2bf(t1), a2 = f2bf(t2), b0 = f2bf(r0), b1 = f2bf(r1), b2 = f2bf(r2);
+    u4 w;
+    w[0] = a0 | (a1 << 16); w[1] = a2; w[2] = 0u; w[3] = 0u;
+    *reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(stem) + ((size_t)p * HW + pix) * 8) = w;
+    w[0] = b0 | (b1 << 16); w[1] = b2;
+    *reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(stem) + ((size_t)(p + Bh) * HW + pix) * 8) = w;
+    w[0] = a0 | (a1 << 16); w[1] = a2 | (b0 << 16); w[2] = b1 | (b2 << 16); w[3] = 0u;
+    *reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(pose_in) + ((size_t)p * HW + pix) * 8) = w;
+}
+
 // PX pixels per thread: the reads are 2 / 4 useful bytes per 16 / 32-byte pixel, so a thread needs several in flight
 template <int ES, int PX = 4>
 __global__ __launch_bounds__(NT) void k_unpack_nhwc(const void* __restrict__ src, int HW, int Cpad, int c_begin,
@@ -1059,6 +1084,15 @@ extern "C" int colvo_pack_nchw(int dtype, const float* const* src, const int32_t
                                               (int)HW, Cpad, dst));
     }
     COLVO_CHECK_LAUNCH("k_pack_nchw");
+    return 0;
+}
+
+extern "C" int colvo_pack_stem_pose(const float* frames, int B2, int H, int W, void* stem, void* pose_in, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(frames && stem && pose_in && B2 >= 2 && B2 % 2 == 0 && B2 <= 65534 && H >= 1 && W >= 1,
+                    "colvo_pack_stem_pose: bad arguments (B2 = 2 * pairs images)");
+    const size_t HW = (size_t)H * W;
+    hipLaunchKernelGGL(k_pack_stem_pose, dim3(nblk(HW), B2 / 2), dim3(NT), 0, (hipStream_t)stream, frames, (int)HW, B2 / 2, stem, pose_in);
+    COLVO_CHECK_LAUNCH("k_pack_stem_pose");
     return 0;
 }
 

@@ -133,7 +133,9 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
                                         (const float*)c.p[6], (const float*)c.p[7], (float*)c.p[8], s);
         case COLVO_CMD_CONV_HEAD_FUSED:
             return colvo_conv_head_fused(&c.desc, c.p[0], c.p[1], (const float*)c.p[2], (const float*)c.p[3], (const float*)c.p[4], c.f[0],
-                                         c.f[1], (void*)c.p[5], (float*)c.p[6], s);
+                                         c.f[1], (void*)c.p[5], (float*)c.p[6], (void*)c.p[7], s);
+        case COLVO_CMD_PACK_STEM_POSE:
+            return colvo_pack_stem_pose((const float*)c.p[0], c.i[0], c.i[1], c.i[2], (void*)c.p[1], (void*)c.p[2], s);
         case COLVO_CMD_HEAD_WGRAD_MFMA:
             return colvo_depth_head_wgrad_mfma(c.p[0], (const float*)c.p[1], c.i[0], c.i[1], c.i[2], (float*)c.p[2], s);
         case COLVO_CMD_HEAD_WGRAD_REDUCE:

@@ -526,7 +526,7 @@ class DepthNet(_ArenaModule):
         small launches on the critical path between the PoseNet and the DepthNet backward)."""
         if frames.dim() != 4 or frames.shape[0] % 2:
             raise ValueError("forward_pair: expected [2B,3,H,W]")
-        return _DepthNetPairFn.apply(self, frames, self._trigger(), None)[:2]
+        return self._tag_pose_in(_DepthNetPairFn.apply(self, frames, self._trigger(), None)[:2])
 
     def forward_pair_split(self, frames: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """forward_pair with a third output: the target-frame depth AGAIN, as the tensor to hand to photometric_loss (and
@@ -540,6 +540,7 @@ class DepthNet(_ArenaModule):
         hand = GradHandover()
         d_t, d_r, d_l = _DepthNetPairFn.apply(self, frames, self._trigger(), hand)
         d_l._colvo_handover = hand
+        self._tag_pose_in((d_t, d_r))
         return d_t, d_r, d_l
 
     def forward_pair_full(self, frames: torch.Tensor):
@@ -549,7 +550,13 @@ class DepthNet(_ArenaModule):
         while it reads them: no autograd accumulation, zero-fill or concatenation kernels."""
         if frames.dim() != 4 or frames.shape[0] % 2:
             raise ValueError("forward_pair_full: expected [2B,3,H,W]")
-        return _DepthNetPairFn.apply(self, frames, self._trigger(), None, True)
+        return self._tag_pose_in(_DepthNetPairFn.apply(self, frames, self._trigger(), None, True))
+
+    def _tag_pose_in(self, outs):
+        """The target-frame depth carries the PoseNet input this pass filled (see _forward_impl) to PoseNet.forward."""
+        outs[0]._colvo_pose_in = getattr(self, "_pose_in", None)
+        self._pose_in = None
+        return outs
 
     # ---- whole-network forward / backward ---------------------------------------------------- #
     def _plan(self, B, H, W):
@@ -573,7 +580,11 @@ class DepthNet(_ArenaModule):
             cin = d
         return P
 
-    def _forward_impl(self, img: torch.Tensor):
+    def _forward_impl(self, img: torch.Tensor, pair: bool = False):
+        """pair: img is the DCDP pair batch [target frames | reference frames]; where the top of the network runs fused
+        (colvo_conv_head_fused) the pass then also fills PoseNet's 8-channel input -- rgb from the stem's packing kernel, the two
+        depth channels from the head -- and leaves it in self._pose_in for PoseNet.forward (which checks that it is handed these
+        very frames and depths, and packs for itself otherwise)."""
         if img.dim() != 4 or img.shape[1] != 3:
             raise ValueError(f"DepthNet: expected [B,3,H,W], got {tuple(img.shape)}")
         B, _, H, W = img.shape
@@ -585,23 +596,31 @@ class DepthNet(_ArenaModule):
         P = self._plan(B, H, W)
         img = img.contiguous()
         depth = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
-        inst = self._acquire((B, H, W, self.compute_dtype))
+        fuse_top = ops.conv_head_fused_ok(P["iconv1"]) and _lib.dev_env("COLVO_NO_FWD16") is None
+        pose_fill = pair and fuse_top and B % 2 == 0 and _lib.dev_env("COLVO_NO_POSE_FILL") is None
+        inst = self._acquire((B, H, W, self.compute_dtype, pose_fill))
 
         def body():
             A: Dict[str, torch.Tensor] = {}
-            x = ops.pack_nchw([img], 8, self.compute_dtype)
+            if pose_fill:
+                x = torch.empty(B, H, W, 8, device=img.device, dtype=self.compute_dtype)
+                # (the two depth channels of every pixel are written by the head below, the six rgb channels here)
+                A["pose_in"] = torch.empty(B // 2, H, W, 8, device=img.device, dtype=self.compute_dtype)
+                ops.pack_stem_pose(img, x, A["pose_in"])
+            else:
+                x = ops.pack_nchw([img], 8, self.compute_dtype)
             A["in"] = x
             for i in range(1, 6):
                 x = _conv(x, getattr(self, f"enc{i}a"), P[f"enc{i}a"]); A[f"enc{i}a"] = x
                 x = _conv(x, getattr(self, f"enc{i}b"), P[f"enc{i}b"]); A[f"enc{i}b"] = x
-            fuse_top = ops.conv_head_fused_ok(P["iconv1"]) and _lib.dev_env("COLVO_NO_FWD16") is None
             for i in range(5, 0, -1):
                 x = _conv(x, getattr(self, f"up{i}"), P[f"up{i}"]); A[f"up{i}"] = x
                 if i == 1 and fuse_top:
                     # the narrow full-resolution layer and the depth head in one pass: its 42 MB output is written, not read back
                     L = self.iconv1
                     y = torch.empty(P["iconv1"].B, P["iconv1"].Ho, P["iconv1"].Wo, 16, device=x.device, dtype=x.dtype)
-                    ops.conv_head_fused(P["iconv1"], x, L.w_fwd, L.bias.data, self.head.w_master, self.head.bias.data, y, depth)
+                    ops.conv_head_fused(P["iconv1"], x, L.w_fwd, L.bias.data, self.head.w_master, self.head.bias.data, y, depth,
+                                        A.get("pose_in"))
                     A["iconv1"] = x = y
                     return A
                 x = _conv(x, getattr(self, f"iconv{i}"), P[f"iconv{i}"], A[f"enc{i - 1}b"] if i >= 2 else None)
@@ -610,6 +629,7 @@ class DepthNet(_ArenaModule):
             return A
 
         A = self._run_pass(inst, "fwd", {"img": img, "depth": depth}, body)
+        self._pose_in = (A["pose_in"], img.data_ptr(), depth.data_ptr(), depth._version) if pose_fill else None
         return depth, (A, P, inst)
 
     def _backward_impl(self, saved, depth: torch.Tensor, d_depth: Optional[torch.Tensor], parts=None) -> None:
@@ -741,7 +761,7 @@ class _DepthNetPairFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net: DepthNet, frames, trigger, handover, both=False):
-        depth, saved = net._forward_impl(frames)
+        depth, saved = net._forward_impl(frames, pair=True)
         ctx.net, ctx.saved, ctx.handover = net, saved, handover
         ctx.lease = _Lease(saved[2])
         ctx.save_for_backward(depth)
@@ -799,7 +819,21 @@ class PoseNet(_ArenaModule):
         self._prepare_weights()
         dt = self.compute_dtype
         has_depth = d_t is not None
-        srcs = _dealias([tgt.contiguous(), ref.contiguous()] + ([d_t.contiguous(), d_r.contiguous()] if has_depth else []))
+        # DepthNet's pair pass may have assembled this very input already (DepthNet._forward_impl): taken only when tgt, ref, d_t
+        # and d_r are, untouched, the frames that pass read and the depths it wrote
+        filled = getattr(d_t, "_colvo_pose_in", None) if has_depth else None
+        if filled is not None:
+            buf, frames_ptr, depth_ptr, version = filled
+            ok = (tuple(buf.shape) == (B, H, W, 8) and buf.dtype == dt and tgt.is_contiguous() and ref.is_contiguous()
+                  and d_t.is_contiguous() and d_r.is_contiguous() and tgt.data_ptr() == frames_ptr
+                  and ref.data_ptr() == frames_ptr + 12 * B * H * W and d_t.data_ptr() == depth_ptr
+                  and d_r.data_ptr() == depth_ptr + 4 * B * H * W and d_t._version == version and d_r._version == version)
+            filled = buf if ok else None
+        if filled is not None:
+            has_depth = "filled"
+            srcs = []
+        else:
+            srcs = _dealias([tgt.contiguous(), ref.contiguous()] + ([d_t.contiguous(), d_r.contiguous()] if has_depth else []))
         key = (B, H, W, dt)
         P = self._plans.get(key)
         if P is None:
@@ -812,7 +846,7 @@ class PoseNet(_ArenaModule):
         inst = self._acquire((B, H, W, dt, has_depth))
 
         def body():
-            x = ops.pack_nchw(srcs, 8, dt)
+            x = filled if filled is not None else ops.pack_nchw(srcs, 8, dt)
             A = {"in": x}
             for i in range(1, 8):
                 x = _conv(x, getattr(self, f"conv{i}"), P[i])
@@ -822,11 +856,13 @@ class PoseNet(_ArenaModule):
 
         ext = {f"src{k}": t for k, t in enumerate(srcs)}
         ext["out"] = out
+        if filled is not None:
+            ext["in"] = filled             # belongs to DepthNet's pass instance: may be another buffer at the next step
         A = self._run_pass(inst, "fwd", ext, body)
-        return out, (A, P, (B, H, W), has_depth, inst)
+        return out, (A, P, (B, H, W), has_depth, inst, filled)
 
     def _backward_impl(self, saved, d_pose, d_a, d_b, scale_a=None, scale_b=None):
-        A, P, (B, H, W), has_depth, inst = saved
+        A, P, (B, H, W), has_depth, inst, filled = saved
         self.attach_grads()
         dev = self.flat_param.device
         grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}
@@ -845,7 +881,7 @@ class PoseNet(_ArenaModule):
             self._layer_done(self.pred)
             for i in range(7, 0, -1):
                 L = getattr(self, f"conv{i}")
-                src = A["in"] if i == 1 else A[i - 1]
+                src = (filled if filled is not None else A["in"]) if i == 1 else A[i - 1]
                 self._conv_wgrad(L, P[i], src, None, g)
                 if i > 1:
                     dx = torch.empty_like(src)
@@ -864,6 +900,8 @@ class PoseNet(_ArenaModule):
         ext = dict(grads)
         if has_depth:
             ext["d_tr"] = d_tr
+        if filled is not None:
+            ext["in"] = filled
         which = "bwd:" + ",".join(sorted(grads))       # a missing (None) gradient changes the recorded commands
         self._run_pass(inst, which, ext, body)
         return d_t, d_r
@@ -901,6 +939,8 @@ def dcdp_forward(depth_net: DepthNet, pose_net: PoseNet, tgt, ref, K, *, ssim_we
         tgt, ref = frames[:frames.shape[0] // 2], frames[frames.shape[0] // 2:]
     else:
         frames = torch.cat([tgt, ref], dim=0)
+        if not (tgt.requires_grad or ref.requires_grad):
+            tgt, ref = frames[:tgt.shape[0]], frames[tgt.shape[0]:]     # the same values; PoseNet then recognises the pair batch
     if full_loss:
         # the objective is one native call that returns finished gradients (no hand-over of scale factors); the depth of both
         # frames reaches it through outputs of their own, so no gradient is accumulated by autograd

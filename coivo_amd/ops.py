@@ -89,16 +89,28 @@ def conv_head_fused_ok(d: ConvDesc) -> bool:
     return bool(_lib.load().colvo_conv_head_fused_ok(C.byref(d)))
 
 
-def conv_head_fused(d: ConvDesc, x, w_fwd, bias, head_w, head_b, y, depth) -> None:
+def conv_head_fused(d: ConvDesc, x, w_fwd, bias, head_w, head_b, y, depth, pose_in=None) -> None:
     """The narrow full-resolution layer and the depth head behind it in one pass (include/colvo.h colvo_conv_head_fused): writes the
-    layer's output y (NHWC bf16) and depth [B,1,H,W] fp32."""
-    _need_cuda(x, w_fwd, bias, head_w, head_b, y, depth)
+    layer's output y (NHWC bf16), depth [B,1,H,W] fp32 and -- with pose_in -- the two depth channels of PoseNet's input."""
+    _need_cuda(x, w_fwd, bias, head_w, head_b, y, depth, pose_in)
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_CONV_HEAD_FUSED, d, (x, w_fwd, bias, head_w, head_b, y, depth), (), (MIN_DEPTH, MAX_DEPTH))
+        return rec.add(_lib.CMD_CONV_HEAD_FUSED, d, (x, w_fwd, bias, head_w, head_b, y, depth, pose_in), (), (MIN_DEPTH, MAX_DEPTH))
     lib = _lib.load()
     _lib.check(lib.colvo_conv_head_fused(C.byref(d), _lib.ptr(x), _lib.ptr(w_fwd), _lib.ptr(bias), _lib.ptr(head_w), _lib.ptr(head_b),
-                                         MIN_DEPTH, MAX_DEPTH, _lib.ptr(y), _lib.ptr(depth), _lib.stream_ptr()), "colvo_conv_head_fused")
+                                         MIN_DEPTH, MAX_DEPTH, _lib.ptr(y), _lib.ptr(depth), _lib.ptr(pose_in), _lib.stream_ptr()),
+               "colvo_conv_head_fused")
+
+
+def pack_stem_pose(frames, stem, pose_in) -> None:
+    """frames [2B,3,H,W] fp32 -> stem [2B,H,W,8] bf16 and the rgb channels of pose_in [B,H,W,8] bf16 (colvo_pack_stem_pose)."""
+    _need_cuda(frames, stem, pose_in)
+    B2, _, H, W = frames.shape
+    rec = program.recording()
+    if rec is not None:
+        return rec.add(_lib.CMD_PACK_STEM_POSE, None, (frames, stem, pose_in), (B2, H, W))
+    _lib.check(_lib.load().colvo_pack_stem_pose(_lib.ptr(frames), B2, H, W, _lib.ptr(stem), _lib.ptr(pose_in), _lib.stream_ptr()),
+               "colvo_pack_stem_pose")
 
 
 def conv_bwd_fused_ok(d: ConvDesc) -> bool:

@@ -196,8 +196,16 @@ int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, const float*
  * so the 42 MB tensor is not read back (colvo_conv_fwd + colvo_depth_head_fwd: 21 + 18 us at 16 frames of 256x320).
  * colvo_conv_head_fused_ok: 1 when the layer qualifies. */
 int colvo_conv_head_fused_ok(const ColvoConvDesc* d);
+/* pose_in (optional; B = 2 * pairs, target frames first): PoseNet's 8-channel bf16 input [pairs][H][W][8] = [tgt rgb | ref rgb |
+ * depth_t | depth_r] -- the depth of image b is ALSO written, rounded to bf16, into channel 6 (b < pairs) or 7 of pair b mod pairs;
+ * colvo_pack_stem_pose fills the six rgb channels while it packs DepthNet's own input: PoseNet's packing pass disappears. */
 int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, const void* w_fwd, const float* bias, const float* head_w,
-                          const float* head_b, float min_depth, float max_depth, void* y, float* depth, colvo_stream_t stream);
+                          const float* head_b, float min_depth, float max_depth, void* y, float* depth, void* pose_in,
+                          colvo_stream_t stream);
+/* frames [B2][3][H][W] fp32 (B2 = 2 * pairs: target frames, then reference frames) -> stem [B2][H][W][8] bf16 (rgb + 5 zero channels,
+ * what colvo_pack_nchw writes) AND pose_in [pairs][H][W][8] bf16: rgb channels 0..2 / 3..5, channels 6 / 7 zeroed (the head's pass
+ * writes them afterwards). */
+int colvo_pack_stem_pose(const float* frames, int B2, int H, int W, void* stem, void* pose_in, colvo_stream_t stream);
 
 /* Input gradient AND weight / bias gradient of a narrow full-resolution layer in ONE pass (csrc/bwd16.hip): bf16, 16 -> 16 channels,
  * stride 1, one directly stored source -- DepthNet's iconv1.  Both backward kernels of such a layer are HBM-bound and read the same
@@ -430,7 +438,8 @@ enum {
     COLVO_CMD_CONV_DGRAD_PLANES,  /* p: dy w_master dst; i: c_begin c_count accumulate */
     COLVO_CMD_CONV_BWD_FUSED,     /* p: dy w_bwd x dx dw db head_dpre head_w head_partials; i: relu_mask */
     COLVO_CMD_HEAD_WGRAD_REDUCE,  /* p: partials dw db; i: rows */
-    COLVO_CMD_CONV_HEAD_FUSED,    /* p: x w_fwd bias head_w head_b y depth; f: min_depth max_depth */
+    COLVO_CMD_CONV_HEAD_FUSED,    /* p: x w_fwd bias head_w head_b y depth pose_in; f: min_depth max_depth */
+    COLVO_CMD_PACK_STEM_POSE,     /* p: frames stem pose_in; i: B2 H W */
     COLVO_CMD_HEAD_WGRAD_MFMA,    /* p: y dpre partials; i: B H W */
     COLVO_CMD_SIDE_SYNC           /* (side command) the side stream in use waits for everything enqueued so far on every other side
                                     stream: what follows reads what several FORKed commands wrote */

@@ -622,6 +622,38 @@ def test_fused_layer_and_depth_head_forward_equals_the_two_kernels(shape):
     assert (inv - inv_ref).abs().max().item() <= 2e-2 and ((inv - inv_ref).abs() > 1e-4).float().mean().item() < 5e-3
 
 
+@pytest.mark.parametrize("shape", [(1, 64, 96), (3, 8, 16), (2, 13, 37)])
+def test_pose_input_filled_by_stem_pack_and_depth_head_is_bit_identical(shape):
+    """colvo_pack_stem_pose + the pose_in argument of colvo_conv_head_fused assemble PoseNet's input [tgt rgb | ref rgb | depth_t |
+    depth_r] (bf16): bit for bit what colvo_pack_nchw makes from the frames and the depth this pass wrote; the stem input too."""
+    from coivo_amd import ops
+    Bp, H, W = shape                                     # pairs
+    gen = torch.Generator().manual_seed(53)
+    dt = torch.bfloat16
+    frames = torch.rand(2 * Bp, 3, H, W, generator=gen).to(dev())
+    stem = torch.full((2 * Bp, H, W, 8), 7.0, device=dev(), dtype=dt)
+    pose_in = torch.full((Bp, H, W, 8), 5.0, device=dev(), dtype=dt)
+    ops.pack_stem_pose(frames, stem, pose_in)
+    assert torch.equal(stem, ops.pack_nchw([frames], 8, dt))
+    d = ops.conv_desc(dt, 2 * Bp, H, W, 16, 16)
+    x = torch.randn(2 * Bp, H, W, 16, generator=gen).relu().to(dev()).to(dt)
+    w = (torch.randn(16, 9, 16, generator=gen) * 0.15).to(dev()).to(dt)
+    bias = (torch.randn(16, generator=gen) * 0.1).to(dev())
+    wh = (torch.randn(1, 9, 16, generator=gen) * 0.2).to(dev())
+    bh = torch.tensor([0.3], device=dev())
+    y, depth = torch.empty_like(x), torch.empty(2 * Bp, 1, H, W, device=dev())
+    y0, depth0 = torch.empty_like(x), torch.empty_like(depth)
+    ops.conv_head_fused(d, x, w, bias, wh, bh, y0, depth0)
+    ops.conv_head_fused(d, x, w, bias, wh, bh, y, depth, pose_in)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0) and torch.equal(depth, depth0)
+    want = ops.pack_nchw([frames[:Bp].contiguous(), frames[Bp:].contiguous(), depth[:Bp].contiguous(), depth[Bp:].contiguous()], 8, dt)
+    assert torch.equal(pose_in.view(torch.int16), want.view(torch.int16))
+    with pytest.raises(RuntimeError):                    # an odd image count is not a pair batch
+        d3 = ops.conv_desc(dt, 3, H, W, 16, 16)
+        ops.conv_head_fused(d3, x[:3].contiguous(), w, bias, wh, bh, y[:3].contiguous(), depth[:3].contiguous(), pose_in)
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 13, 37), (2, 256, 320)])
 def test_depth_head_weight_gradient_by_mfma(shape):
     """colvo_depth_head_wgrad_mfma (+ the table reduction) against the VALU kernel colvo_depth_head_wgrad on the same y and d(pre):

@@ -338,3 +338,53 @@ def test_grouped_slab_weight_gradients_equal_the_default_form(dtype):
     twice = run(True, passes=2)
     for c, t in zip(g1[:2], twice[:2]):
         assert (t - 2 * c).abs().max().item() <= 1e-4 * c.abs().max().item()       # (the two heads' gradients still end in float atomics)
+
+
+def test_pose_input_filled_by_depthnet_gives_the_same_step_bitwise(monkeypatch):
+    """bf16: DepthNet's pair pass fills PoseNet's input (rgb from the stem pack, depth from the head) and PoseNet skips its own packing
+    pass.  Same loss and pose bit for bit as with PoseNet packing for itself (COLVO_NO_POSE_FILL), gradients to atomics' round-off;
+    a PoseNet call on OTHER tensors after a pair pass packs for itself (the hand-over is bound to the very frames and depths)."""
+    from coivo_amd import _lib, nn as hnn
+    B, H, W, seed = 2, 64, 96, 17
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+    frames = torch.cat([b["tgt"], b["ref"]], dim=0)
+
+    def run(fill):
+        monkeypatch.setenv("COLVO_DEV", "1")
+        if fill:
+            monkeypatch.delenv("COLVO_NO_POSE_FILL", raising=False)
+        else:
+            monkeypatch.setenv("COLVO_NO_POSE_FILL", "1")
+        _, _, dn, pn = _models(seed, torch.bfloat16)
+        dn.zero_grad(); pn.zero_grad()
+        outs = []
+        for _ in range(2):                                 # recorded, then replayed
+            loss, d_t, d_r, pose, a, bb = hnn.dcdp_forward(dn, pn, None, None, b["K"], frames=frames)
+            loss.backward()
+            outs.append((loss.detach().clone(), pose.detach().clone(), a.detach().clone()))
+        dn.join_side(); pn.join_side()
+        torch.cuda.synchronize()
+        used = any(k[-1] == "filled" for k in pn._insts)
+        return outs, dn.flat_grad.clone(), pn.flat_grad.clone(), used, (dn, pn)
+
+    o1, gd1, gp1, used1, (dn, pn) = run(True)
+    o0, gd0, gp0, used0, _ = run(False)
+    assert used1 and not used0
+    for (l1, p1, a1), (l0, p0, a0) in zip(o1, o0):
+        assert torch.equal(l1, l0) and torch.equal(p1, p0) and torch.equal(a1, a0)
+    for g1, g0 in ((gd1, gd0), (gp1, gp0)):
+        assert (g1 - g0).abs().max().item() <= 1e-4 * g0.abs().max().item()
+    # other tensors: no hand-over
+    monkeypatch.delenv("COLVO_NO_POSE_FILL", raising=False)
+    with torch.no_grad():
+        d_t, d_r = dn.forward_pair(frames)
+        want = pn(b["tgt"], b["ref"], d_t.clone(), d_r.clone())[0]
+        n_before = sum(1 for k in pn._insts if k[-1] == "filled")
+        d_t2, d_r2 = dn.forward_pair(frames)
+        got_other = pn(b["ref"], b["tgt"], d_t2, d_r2)[0]          # frames swapped: must not take the filled buffer
+        swapped = pn(b["ref"], b["tgt"], d_t2.clone(), d_r2.clone())[0]
+        d_t3, d_r3 = dn.forward_pair(frames)
+        got = pn(frames[:B], frames[B:], d_t3, d_r3)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(got_other, swapped)
+    assert torch.equal(got, want)
