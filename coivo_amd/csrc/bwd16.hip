@@ -495,7 +495,7 @@ extern "C" int colvo_depth_head_wgrad_mfma(const void* y, const float* dpre, int
     k.y = (const char*)y; k.dpre = dpre; k.partials = partials; k.B = B; k.H = H; k.W = W;
     k.tiles_x = (W + TOW - 1) / TOW; k.tiles_y = (H + TOH - 1) / TOH; k.ntiles = B * k.tiles_x * k.tiles_y;
     const int wgs = head_wgrad_mfma_grid(B, H, W, &k.tiles_per_wg);
-    hipLaunchKernelGGL(k_head_wgrad_mfma, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    colvo::launch(k_head_wgrad_mfma, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
     COLVO_CHECK_LAUNCH("k_head_wgrad_mfma");
     return 0;
 }
@@ -538,9 +538,9 @@ extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, cons
     k.ntiles = k.B * k.tiles_x * k.tiles_y;
     const int wgs = bwd16_grid(d, &k.tiles_per_wg);
     k.dpre = head_dpre; k.head_w = head_w; k.head_partials = head_partials;
-    if (head_partials) hipLaunchKernelGGL(k_bwd16<2>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
-    else if (head_dpre) hipLaunchKernelGGL(k_bwd16<1>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
-    else hipLaunchKernelGGL(k_bwd16<0>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    if (head_partials) colvo::launch(k_bwd16<2>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    else if (head_dpre) colvo::launch(k_bwd16<1>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    else colvo::launch(k_bwd16<0>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
     COLVO_CHECK_LAUNCH("k_bwd16");
     return 0;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -27,6 +28,30 @@ void set_error(const char* fmt, ...);
             return (int)e_;                                                         \
         }                                                                           \
     } while (0)
+
+// Every kernel launch of the library goes through launch(): a launch can then CARRY an event.  hipEventRecord puts a marker packet
+// behind the kernel on its queue, and the next kernel of that queue waits for it: 2.8 us per record on the producing chain, 5.3 us
+// when another queue already waits on the event -- the backward pass forks a weight-gradient kernel off every layer of its
+// input-gradient chain (tools/ubench/fork_cost.hip: chain of 40 kernels of 18 us: 18.0 us per kernel alone, 20.8 with a record after
+// each, 23.3 with record + waiter; 19.4 with the event as hipExtLaunchKernel's stopEvent, which rides on the kernel's own completion
+// signal: no packet on the producer's queue).  colvo_run_commands arms the tap around a command that a FORK follows.
+struct LaunchTap {
+    hipEvent_t stop = nullptr;     // event to attach to launches on `stream` (nullptr: plain launches)
+    hipStream_t stream = nullptr;
+    int used = 0;                  // launches that carried it
+};
+extern thread_local LaunchTap g_launch_tap;      // program.hip (commands run on the thread that armed it)
+
+template <typename... P, typename... A>
+inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned lds, hipStream_t s, A&&... a) {
+    LaunchTap& t = g_launch_tap;
+    if (t.stop != nullptr && t.stream == s) {
+        ++t.used;
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, t.stop, 0u, static_cast<P>(a)...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, lds, s, static_cast<P>(a)...);
+    }
+}
 
 __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));

@@ -1528,7 +1528,7 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
         hipMemsetAsync(tbuf, 0, nwg * 8 * sizeof(long long), s);
         ka.trace = tbuf;
     }
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, ka);
+    colvo::launch((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, ka);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     if (tracing && (++tcount % atoi(getenv("COLVO_TRACE"))) == 0) {     // every n-th launch: print the phase statistics
         hipStreamSynchronize(s);
@@ -1552,7 +1552,7 @@ int launch_conv_tail(const ConvK& k, int B, hipStream_t s) {
     }
     return 0;
 #endif
-    hipLaunchKernelGGL((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, kk);
+    colvo::launch((k_conv3x3<T, BN, NG, DEPTH, TAIL, NCH, NTH>), grid, dim3(NTH), lds, s, kk);
     COLVO_CHECK_LAUNCH("k_conv3x3");
     return 0;
 }
@@ -1586,7 +1586,7 @@ int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     int gx = 256 * res_wg_per_cu;               // workgroups per CU, each walking ntiles / gx tiles
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
-    hipLaunchKernelGGL((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
+    colvo::launch((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
                        mdiv_magic(k.tiles_x));
     COLVO_CHECK_LAUNCH("k_conv3x3_res");
     return 0;
@@ -1735,8 +1735,8 @@ int try_launch_conv_q(const ConvK& k0, int B, hipStream_t s) {
         configured[bn == 32] = true;
     }
     const dim3 grid((unsigned)(tiles * k.ntn));
-    if (bn == 32) hipLaunchKernelGGL((k_conv_q<T, 32>), grid, dim3(NT), lds, s, k);
-    else hipLaunchKernelGGL((k_conv_q<T, 16>), grid, dim3(NT), lds, s, k);
+    if (bn == 32) colvo::launch((k_conv_q<T, 32>), grid, dim3(NT), lds, s, k);
+    else colvo::launch((k_conv_q<T, 16>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv_q");
     return 0;
 }
@@ -1751,7 +1751,7 @@ int launch_conv_up2_inst(ConvK k, int B, hipStream_t s) {
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
     COLVO_CHECK_ARG(nwg < (1ll << 30) && lds <= 48 * 1024, "conv (up-sampled source): bad launch geometry");
-    hipLaunchKernelGGL((k_conv_up2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    colvo::launch((k_conv_up2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv_up2");
     return 0;
 }
@@ -1782,7 +1782,7 @@ int launch_dgrad_up2_inst(ConvK k, int B, hipStream_t s) {
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
     COLVO_CHECK_ARG(nwg < (1ll << 30), "dgrad (up-sampled source): too many workgroups");
-    hipLaunchKernelGGL((k_dgrad_up2<T, BN, DEPTH, NCH, NG>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    colvo::launch((k_dgrad_up2<T, BN, DEPTH, NCH, NG>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_dgrad_up2");
     return 0;
 }
@@ -1806,7 +1806,7 @@ int launch_dgrad_s2_inst(ConvK k, int B, hipStream_t s) {
     k.xcd = xcd_on;
     const long long nwg = (long long)k.tiles_x * k.tiles_y * k.ntn * B;
     COLVO_CHECK_ARG(nwg < (1ll << 30) && lds <= 48 * 1024, "dgrad (stride 2): bad launch geometry");
-    hipLaunchKernelGGL((k_dgrad_s2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
+    colvo::launch((k_dgrad_s2<T, BN, DEPTH, NCH>), dim3((unsigned)nwg), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_dgrad_s2");
     return 0;
 }

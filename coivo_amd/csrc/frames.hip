@@ -62,7 +62,7 @@ extern "C" int colvo_frames_u8_to_f32(const uint8_t* frames, int B, int h, int w
                         (long long)H * W < (1ll << 28) && (H + 3) / 4 <= 65535,
                     "colvo_frames_u8_to_f32: bad shape B=%d %dx%d -> %dx%d", B, h, w, H, W);
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    hipLaunchKernelGGL(k_frames_u8_to_f32, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, frames,
+    colvo::launch(k_frames_u8_to_f32, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, frames,
                        h, w, H, W, sy, sx, out);
     COLVO_CHECK_LAUNCH("k_frames_u8_to_f32");
     return 0;

@@ -246,7 +246,7 @@ extern "C" int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, cons
     if (wgs > k.ntiles) wgs = k.ntiles;
     k.tiles_per_wg = (k.ntiles + wgs - 1) / wgs;
     wgs = (k.ntiles + k.tiles_per_wg - 1) / k.tiles_per_wg;
-    hipLaunchKernelGGL(k_fwd16_head, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
+    colvo::launch(k_fwd16_head, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
     COLVO_CHECK_LAUNCH("k_fwd16_head");
     return 0;
 }

@@ -1045,7 +1045,7 @@ extern "C" int colvo_pack_weights(int dtype, const float* w_master, int Cout, in
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pack_weights: bad dtype");
     COLVO_CHECK_ARG(Cout > 0 && kk > 0 && Cin > 0, "colvo_pack_weights: bad shape");
     const size_t n = (size_t)Cout * kk * Cin;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_weights<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream,
+    DISPATCH_ES(dtype, colvo::launch((k_pack_weights<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream,
                                           w_master, Cout, kk, Cin, w_fwd, w_bwd));
     COLVO_CHECK_LAUNCH("k_pack_weights");
     return 0;
@@ -1055,7 +1055,7 @@ extern "C" int colvo_pack_weights_multi(int dtype, const float* master, const vo
                                         void* fwd, void* bwd, colvo_stream_t stream) {
     COLVO_CHECK_ARG(master && table && bwd && nlayers >= 1 && nblocks >= 1, "colvo_pack_weights_multi: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pack_weights_multi: bad dtype");
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_weights_multi<ES>), dim3(nblocks), dim3(NT), 0, (hipStream_t)stream, master,
+    DISPATCH_ES(dtype, colvo::launch((k_pack_weights_multi<ES>), dim3(nblocks), dim3(NT), 0, (hipStream_t)stream, master,
                                           (const PackEntry*)table, nlayers, fwd, bwd));
     COLVO_CHECK_LAUNCH("k_pack_weights_multi");
     return 0;
@@ -1077,10 +1077,10 @@ extern "C" int colvo_pack_nchw(int dtype, const float* const* src, const int32_t
     bool narrow = Cpad == 8;
     for (int i = 0; i < nsrc; ++i) narrow = narrow && src_channels[i] <= 4;
     if (narrow) {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_nchw8<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, pl,
+        DISPATCH_ES(dtype, colvo::launch((k_pack_nchw8<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, pl,
                                               (int)HW, dst));
     } else {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pack_nchw<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, pl,
+        DISPATCH_ES(dtype, colvo::launch((k_pack_nchw<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, pl,
                                               (int)HW, Cpad, dst));
     }
     COLVO_CHECK_LAUNCH("k_pack_nchw");
@@ -1091,7 +1091,7 @@ extern "C" int colvo_pack_stem_pose(const float* frames, int B2, int H, int W, v
     COLVO_CHECK_ARG(frames && stem && pose_in && B2 >= 2 && B2 % 2 == 0 && B2 <= 65534 && H >= 1 && W >= 1,
                     "colvo_pack_stem_pose: bad arguments (B2 = 2 * pairs images)");
     const size_t HW = (size_t)H * W;
-    hipLaunchKernelGGL(k_pack_stem_pose, dim3(nblk(HW), B2 / 2), dim3(NT), 0, (hipStream_t)stream, frames, (int)HW, B2 / 2, stem, pose_in);
+    colvo::launch(k_pack_stem_pose, dim3(nblk(HW), B2 / 2), dim3(NT), 0, (hipStream_t)stream, frames, (int)HW, B2 / 2, stem, pose_in);
     COLVO_CHECK_LAUNCH("k_pack_stem_pose");
     return 0;
 }
@@ -1102,7 +1102,7 @@ extern "C" int colvo_unpack_nhwc_grad(int dtype, const void* dsrc, int B, int H,
                     "colvo_unpack_nhwc_grad: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_unpack_nhwc_grad: bad dtype");
     const size_t HW = (size_t)H * W;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_unpack_nhwc<ES, 4>), dim3(nblk((HW + 3) / 4), B), dim3(NT), 0, (hipStream_t)stream,
+    DISPATCH_ES(dtype, colvo::launch((k_unpack_nhwc<ES, 4>), dim3(nblk((HW + 3) / 4), B), dim3(NT), 0, (hipStream_t)stream,
                                           dsrc, (int)HW, Cpad, c_begin, c_count, dst_nchw, accumulate));
     COLVO_CHECK_LAUNCH("k_unpack_nhwc");
     return 0;
@@ -1124,7 +1124,7 @@ extern "C" int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, c
     const size_t lds = (size_t)9 * d->Cout * c_count * 4;
     hipStream_t s = (hipStream_t)stream;
 #define COLVO_DGP(ES_, NC_)                                                                                                        \
-    hipLaunchKernelGGL((k_conv_dgrad_planes<ES_, NC_>), dim3(nblk(npix)), dim3(NT), lds, s, dy, w_master, d->Cout, d->C0, c_begin, d->B, \
+    colvo::launch((k_conv_dgrad_planes<ES_, NC_>), dim3(nblk(npix)), dim3(NT), lds, s, dy, w_master, d->Cout, d->C0, c_begin, d->B, \
                        d->Hi, d->Wi, d->Ho, d->Wo, d->stride, dst, accumulate)
     if (d->dtype == COLVO_F32) { if (c_count == 1) COLVO_DGP(4, 1); else if (c_count == 2) COLVO_DGP(4, 2); else COLVO_DGP(4, 4); }
     else { if (c_count == 1) COLVO_DGP(2, 1); else if (c_count == 2) COLVO_DGP(2, 2); else COLVO_DGP(2, 4); }
@@ -1137,7 +1137,7 @@ extern "C" int colvo_relu_bwd_inplace(int dtype, const void* y, void* dy, size_t
     COLVO_CHECK_ARG(y && dy, "colvo_relu_bwd_inplace: null pointer argument");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_relu_bwd_inplace: bad dtype");
     if (n == 0) return 0;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_relu_bwd<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream, y, dy, n));
+    DISPATCH_ES(dtype, colvo::launch((k_relu_bwd<ES>), dim3(nblk(n)), dim3(NT), 0, (hipStream_t)stream, y, dy, n));
     COLVO_CHECK_LAUNCH("k_relu_bwd");
     return 0;
 }
@@ -1151,13 +1151,13 @@ extern "C" int colvo_depth_head_fwd(int dtype, const void* x, const float* w, co
     const size_t HW = (size_t)H * W;
     const int head_lds = (int)TUNE(head_fwd_lds);   // A/B switch
     if (C == 16 && dtype == COLVO_BF16 && head_lds && (H + 3) / 4 <= 65535) {
-        hipLaunchKernelGGL(k_depth_head_fwd16_lds, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, x, w,
+        colvo::launch(k_depth_head_fwd16_lds, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(NT), 0, (hipStream_t)stream, x, w,
                            bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth);
     } else if (C == 16) {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd16<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, x,
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_fwd16<ES>), dim3(nblk(HW), B), dim3(NT), 0, (hipStream_t)stream, x,
                                               w, bias, H, W, 1.0f / max_depth, 1.0f / min_depth, depth));
     } else {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_fwd<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float),
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_fwd<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float),
                                               (hipStream_t)stream, x, w, bias, H, W, C, 1.0f / max_depth, 1.0f / min_depth, depth));
     }
     COLVO_CHECK_LAUNCH("k_depth_head_fwd");
@@ -1176,15 +1176,15 @@ extern "C" int colvo_depth_head_bwd(int dtype, const void* x, const float* w, co
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W, n = (size_t)B * HW;
     const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
-    hipLaunchKernelGGL(k_depth_head_dpre, dim3(nblk(n)), dim3(NT), 0, s, depth, d_depth, n, lo, hi, scratch);
+    colvo::launch(k_depth_head_dpre, dim3(nblk(n)), dim3(NT), 0, s, depth, d_depth, n, lo, hi, scratch);
     COLVO_CHECK_LAUNCH("k_depth_head_dpre");
     if (dw) {
         if (int e = colvo_depth_head_wgrad(dtype, x, scratch, B, H, W, C, dw, db, stream)) return e;
     }
     if (C == 16 && ((uintptr_t)x | (uintptr_t)dx) % 16 == 0 && !head_dgrad_generic()) {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
     } else {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
                                               x, w, scratch, H, W, C, dx));
     }
     COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
@@ -1205,7 +1205,7 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
     hipStream_t s = (hipStream_t)stream;
     const size_t HW = (size_t)H * W, n = (size_t)B * HW;
     const float lo = 1.0f / max_depth, hi = 1.0f / min_depth;
-    hipLaunchKernelGGL(k_depth_head_dpre_parts, dim3(nblk(n)), dim3(NT), 0, s, depth, g_first, g_second, g_raw, g_raw_second,
+    colvo::launch(k_depth_head_dpre_parts, dim3(nblk(n)), dim3(NT), 0, s, depth, g_first, g_second, g_raw, g_raw_second,
                        scale_a, scale_b, n / 2, lo, hi, scratch);
     COLVO_CHECK_LAUNCH("k_depth_head_dpre_parts");
     if (dw) {
@@ -1213,9 +1213,9 @@ extern "C" int colvo_depth_head_bwd_parts(int dtype, const void* x, const float*
     }
     if (!dx) return 0;          // d(pre) only: the input gradient is made by colvo_conv_bwd_fused's HEAD form from `scratch`
     if (C == 16 && ((uintptr_t)x | (uintptr_t)dx) % 16 == 0 && !head_dgrad_generic()) {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_dgrad16<ES>), dim3(nblk(HW), B), dim3(NT), 0, s, x, w, scratch, H, W, dx));
     } else {
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_dgrad<ES>), dim3(nblk(HW), B), dim3(NT), 9 * C * sizeof(float), s,
                                               x, w, scratch, H, W, C, dx));
     }
     COLVO_CHECK_LAUNCH("k_depth_head_dgrad");
@@ -1255,7 +1255,7 @@ extern "C" int colvo_depth_head_wgrad_det(int dtype, const void* x, const float*
 
 extern "C" int colvo_depth_head_wgrad_reduce(const float* partials, int rows, float* dw, float* db, colvo_stream_t stream) {
     COLVO_CHECK_ARG(partials && dw && db && rows >= 1, "colvo_depth_head_wgrad_reduce: bad arguments");
-    hipLaunchKernelGGL(k_head_wgrad_reduce, dim3(9 * 16 + 1), dim3(NT), 0, (hipStream_t)stream, partials, rows, 9 * 16 + 1, dw, db);
+    colvo::launch(k_head_wgrad_reduce, dim3(9 * 16 + 1), dim3(NT), 0, (hipStream_t)stream, partials, rows, 9 * 16 + 1, dw, db);
     COLVO_CHECK_LAUNCH("k_head_wgrad_reduce");
     return 0;
 }
@@ -1275,17 +1275,17 @@ static int depth_head_wgrad_impl(int dtype, const void* x, const float* dpre, in
         // tap rows per thread: 1 (three workgroups per pixel range) measured 57 -> 45 us inside the step, step -1 %
         const int rows = (int)TUNE(head_wgrad_rows);   // A/B switch
         if (rows == 3) {
-            DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 3>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
+            DISPATCH_ES(dtype, colvo::launch((k_depth_head_wgrad<ES, 16, 3>), dim3((unsigned)((HW + ppb - 1) / ppb), B),
                                                   dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db, partials));
         } else {
-            DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad<ES, 16, 1>), dim3((unsigned)((HW + ppb - 1) / ppb), B, 3),
+            DISPATCH_ES(dtype, colvo::launch((k_depth_head_wgrad<ES, 16, 1>), dim3((unsigned)((HW + ppb - 1) / ppb), B, 3),
                                                   dim3(NT), 0, s, x, dpre, H, W, ppb, dw, db, partials));
         }
         if (partials)
-            hipLaunchKernelGGL(k_head_wgrad_reduce, dim3(9 * 16 + 1), dim3(NT), 0, s, (const float*)partials, rows_tab, 9 * 16 + 1, dw, db);
+            colvo::launch(k_head_wgrad_reduce, dim3(9 * 16 + 1), dim3(NT), 0, s, (const float*)partials, rows_tab, 9 * 16 + 1, dw, db);
     } else {
         const int rows = 4;
-        DISPATCH_ES(dtype, hipLaunchKernelGGL((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
+        DISPATCH_ES(dtype, colvo::launch((k_depth_head_wgrad_generic<ES>), dim3((H + rows - 1) / rows, B), dim3(NT),
                                               0, s, x, dpre, H, W, C, rows, dw, db));
     }
     COLVO_CHECK_LAUNCH("k_depth_head_wgrad");
@@ -1296,7 +1296,7 @@ extern "C" int colvo_pose_head_fwd(int dtype, const void* x, const float* w, con
                                    float pose_scale, float lcc_scale, float* out, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && w && bias && out && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_fwd: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_fwd: bad dtype");
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_fwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, bias, HW,
+    DISPATCH_ES(dtype, colvo::launch((k_pose_head_fwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, bias, HW,
                                           C, pose_scale, lcc_scale, out));
     COLVO_CHECK_LAUNCH("k_pose_head_fwd");
     return 0;
@@ -1307,7 +1307,7 @@ extern "C" int colvo_pose_head_bwd(int dtype, const void* x, const float* w, con
                                    float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && w && dx && dw && db && B >= 1 && HW >= 1 && C >= 1, "colvo_pose_head_bwd: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd: bad dtype");
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_pose, d_a,
+    DISPATCH_ES(dtype, colvo::launch((k_pose_head_bwd<ES>), dim3(B), dim3(NT), 0, (hipStream_t)stream, x, w, d_pose, d_a,
                                           d_b, scale_a, scale_b, HW, C, pose_scale, lcc_scale, dx, dw, db));
     COLVO_CHECK_LAUNCH("k_pose_head_bwd");
     return 0;
@@ -1318,7 +1318,7 @@ extern "C" int colvo_pose_head_bwd_det(int dtype, const void* x, const float* w,
                                        float pose_scale, float lcc_scale, void* dx, float* dw, float* db, colvo_stream_t stream) {
     COLVO_CHECK_ARG(x && w && dx && dw && db && B >= 1 && HW >= 1 && C >= 8, "colvo_pose_head_bwd_det: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_pose_head_bwd_det: bad dtype");
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_pose_head_bwd_det<ES>), dim3((C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, x, w,
+    DISPATCH_ES(dtype, colvo::launch((k_pose_head_bwd_det<ES>), dim3((C + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, x, w,
                                           d_pose, d_a, d_b, scale_a, scale_b, B, HW, C, pose_scale, lcc_scale, dx, dw, db));
     COLVO_CHECK_LAUNCH("k_pose_head_bwd_det");
     return 0;
@@ -1334,11 +1334,11 @@ extern "C" int colvo_adam_step(float* param, const float* grad, float* exp_avg, 
     if (n) {
         unsigned blocks = nblk((n + 3) / 4);
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+        colvo::launch(k_adam, dim3(blocks), dim3(NT), 0, s, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
                            eps, grad_scale, step_count, 0);
         COLVO_CHECK_LAUNCH("k_adam");
     }
-    hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
+    colvo::launch(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
     COLVO_CHECK_LAUNCH("k_inc_step");
     return 0;
 }
@@ -1353,7 +1353,7 @@ extern "C" int colvo_adam_step_t(float* param, const float* grad, float* exp_avg
     if (n == 0) return 0;
     unsigned blocks = nblk((n + 3) / 4);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
+    colvo::launch(k_adam, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
                        beta2, eps, grad_scale, (const int32_t*)nullptr, t);
     COLVO_CHECK_LAUNCH("k_adam");
     return 0;
@@ -1378,7 +1378,7 @@ extern "C" int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, fl
         total += blocks;
     }
     for (int i = count; i <= COLVO_MAX_ARENAS; ++i) as.first[i] = total;
-    hipLaunchKernelGGL(k_adam_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, as, lr, beta1, beta2, eps, grad_scale, t);
+    colvo::launch(k_adam_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, as, lr, beta1, beta2, eps, grad_scale, t);
     COLVO_CHECK_LAUNCH("k_adam_multi");
     return 0;
 }
@@ -1388,11 +1388,11 @@ extern "C" int colvo_adam_pack_step(int dtype, const void* table, int nentries, 
     COLVO_CHECK_ARG(table && nentries >= 1 && nblocks >= 1 && (step_count || t >= 1), "colvo_adam_pack_step: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_adam_pack_step: bad dtype");
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_ES(dtype, hipLaunchKernelGGL((k_adam_pack<ES>), dim3(nblocks), dim3(NT), 0, s, (const ColvoAdamPackEntry*)table,
+    DISPATCH_ES(dtype, colvo::launch((k_adam_pack<ES>), dim3(nblocks), dim3(NT), 0, s, (const ColvoAdamPackEntry*)table,
                                           nentries, lr, beta1, beta2, eps, grad_scale, (const int32_t*)step_count, t));
     COLVO_CHECK_LAUNCH("k_adam_pack");
     if (step_count) {
-        hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
+        colvo::launch(k_inc_step, dim3(1), dim3(1), 0, s, step_count);
         COLVO_CHECK_LAUNCH("k_inc_step");
     }
     return 0;
@@ -1415,7 +1415,7 @@ extern "C" int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int coun
         total += blocks;
     }
     for (int i = count; i <= COLVO_MAX_ARENAS; ++i) zs.first[i] = total;
-    hipLaunchKernelGGL(k_zero_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, zs);
+    colvo::launch(k_zero_multi, dim3(total), dim3(NT), 0, (hipStream_t)stream, zs);
     COLVO_CHECK_LAUNCH("k_zero_multi");
     return 0;
 }

@@ -63,6 +63,9 @@ int aux_streams() {
     return std::min(n, g_naux);
 }
 
+}  // namespace
+namespace colvo { thread_local LaunchTap g_launch_tap; }
+namespace {
 int order_after(hipStream_t later, hipStream_t earlier, const char* what) {
     hipEvent_t e = next_event();
     hipError_t he = hipEventRecord(e, earlier);
@@ -401,6 +404,8 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
     hipStream_t side_cur = ss;            // where stream-1 commands go until the next FORK
     int side_idx = 0;                     // 0: the caller's side stream, i > 0: g_aux[i - 1]
     bool aux_dirty[MAX_AUX] = {false, false, false};   // aux i holds work the caller's side stream has not been ordered after
+    hipEvent_t main_tail = nullptr;       // an event that stands for everything enqueued on the main stream so far (or none)
+    const bool stop_forks = ss && TUNE(fork_stop_event) != 0;
     for (int k = 0; k < n; ++k) {
         const ColvoCmd& c = cmds[k];
         COLVO_CHECK_ARG(c.stream == 0 || (c.stream == 1 && ss), "colvo_run_commands: command %d needs a side stream", k);
@@ -411,7 +416,12 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
             case COLVO_CMD_FORK: {       // the side stream continues after everything enqueued so far on the main stream
                 COLVO_CHECK_ARG(ss, "colvo_run_commands: FORK without a side stream");
                 if (naux) { side_idx = (side_idx + 1) % (naux + 1); side_cur = side_idx ? g_aux[side_idx - 1] : ss; }
-                rc = order_after(side_cur, ms, "fork");
+                if (main_tail) {         // the main stream's last kernel carried this event: no marker on the main queue
+                    const hipError_t he = hipStreamWaitEvent(side_cur, main_tail, 0);
+                    if (he != hipSuccess) { set_error("colvo_run_commands: fork failed: %s", hipGetErrorString(he)); rc = (int)he; }
+                } else {
+                    rc = order_after(side_cur, ms, "fork");
+                }
                 break;
             }
             case COLVO_CMD_SIDE_SYNC: {  // the side stream in use continues after everything enqueued so far on the OTHER side streams
@@ -426,10 +436,22 @@ extern "C" int colvo_run_commands(const ColvoCmd* cmds, int n, colvo_stream_t ma
                 rc = order_after(ms, ss, "join");
                 for (int i = 0; rc == 0 && i < naux; ++i)
                     if (aux_dirty[i]) rc = order_after(ms, g_aux[i], "join");
+                main_tail = nullptr;     // the main stream now also stands for the joined side work
                 break;
             }
             default:
-                rc = run_one(c, k, s);
+                if (c.stream) { rc = run_one(c, k, s); break; }
+                main_tail = nullptr;
+                if (stop_forks && k + 1 < n && cmds[k + 1].op == COLVO_CMD_FORK) {
+                    // a FORK follows: the command's kernels carry the event the side stream will wait on (common.h LaunchTap)
+                    LaunchTap& tap = g_launch_tap;
+                    tap.stop = next_event(); tap.stream = ms; tap.used = 0;
+                    rc = run_one(c, k, s);
+                    if (rc == 0 && tap.used > 0) main_tail = tap.stop;
+                    tap.stop = nullptr;
+                } else {
+                    rc = run_one(c, k, s);
+                }
         }
         if (rc != 0) return rc;   // the failing entry point has set the message
     }

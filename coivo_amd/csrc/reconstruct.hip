@@ -161,7 +161,7 @@ extern "C" int colvo_backproject(const float* depth, const float* K, const float
     COLVO_CHECK_ARG(depth && K && cam2world && points, "colvo_backproject: null pointer argument");
     COLVO_CHECK_ARG(B > 0 && H > 0 && W > 0 && B <= 65535 && (long long)H * W < (1ll << 30),
                     "colvo_backproject: bad shape B=%d H=%d W=%d", B, H, W);
-    hipLaunchKernelGGL(k_backproject, dim3((H * W + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream, depth, K,
+    colvo::launch(k_backproject, dim3((H * W + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream, depth, K,
                        cam2world, H, W, points);
     COLVO_CHECK_LAUNCH("k_backproject");
     return 0;
@@ -184,11 +184,11 @@ extern "C" int colvo_stitch_point_cloud(const float* depths, const float* K, con
                     "colvo_stitch_point_cloud: bad shape N=%d H=%d W=%d stride=%d", N, H, W, stride);
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(g.blocks_per_frame, N);
-    hipLaunchKernelGGL(k_stitch_count, grid, dim3(NT), 0, s, depths, g, max_depth, workspace);
+    colvo::launch(k_stitch_count, grid, dim3(NT), 0, s, depths, g, max_depth, workspace);
     COLVO_CHECK_LAUNCH("k_stitch_count");
-    hipLaunchKernelGGL(k_stitch_scan, dim3(1), dim3(NT), 0, s, workspace, N * g.blocks_per_frame, n_points);
+    colvo::launch(k_stitch_scan, dim3(1), dim3(NT), 0, s, workspace, N * g.blocks_per_frame, n_points);
     COLVO_CHECK_LAUNCH("k_stitch_scan");
-    hipLaunchKernelGGL(k_stitch_write, grid, dim3(NT), 0, s, depths, K, cam2world, g, max_depth, workspace, points);
+    colvo::launch(k_stitch_write, grid, dim3(NT), 0, s, depths, K, cam2world, g, max_depth, workspace, points);
     COLVO_CHECK_LAUNCH("k_stitch_write");
     return 0;
 }

@@ -66,6 +66,7 @@ namespace tune {
     X(head_dgrad_generic, 0, "depth-head input gradient: generic form instead of the 16-channel granule form")                      \
     X(march_rows_fwd, 0, "rows per strip segment of the fused-loss forward march (0: chosen to fill the wave slots in whole rounds)") \
     X(march_rows_bwd, 0, "... of the one-pass loss + gradient march")                                                               \
+    X(fork_stop_event, 1, "a FORK waits on the producing kernel's own completion (hipExtLaunchKernel stopEvent) instead of a recorded marker") \
     X(side_streams, 2, "weight-gradient streams colvo_run_commands alternates between (the caller's + library-owned ones)")
 
 struct Table {

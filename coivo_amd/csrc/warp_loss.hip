@@ -1710,10 +1710,10 @@ extern "C" int colvo_warp_loss_fwd(const float* tgt, const float* ref, const flo
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fwd: too many strips");
     const int nblk = (int)nitems;
-    hipLaunchKernelGGL(k_warp_loss_fwd_march, dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
+    colvo::launch(k_warp_loss_fwd_march, dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
                        lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, workspace);
     COLVO_CHECK_LAUNCH("k_warp_loss_fwd_march");
-    hipLaunchKernelGGL(k_warp_loss_fwd_finalize, dim3(1), dim3(NT), 0, s, workspace, nblk, loss_state);
+    colvo::launch(k_warp_loss_fwd_finalize, dim3(1), dim3(NT), 0, s, workspace, nblk, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fwd_finalize");
     return 0;
 }
@@ -1735,10 +1735,10 @@ extern "C" int colvo_warp_loss_bwd(const float* tgt, const float* ref, const flo
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_bwd: too many strips");
-    hipLaunchKernelGGL((k_warp_loss_bwd_march<false>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
+    colvo::launch((k_warp_loss_bwd_march<false>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose, K,
                        lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, loss_state, grad_loss, d_depth, workspace, 0, GeoArgs{});
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march");
-    hipLaunchKernelGGL(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, nseg * strips_x, pose,
+    colvo::launch(k_warp_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, nseg * strips_x, pose,
                        d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_finalize");
     return 0;
@@ -1760,11 +1760,11 @@ extern "C" int colvo_warp_loss_fused(const float* tgt, const float* ref, const f
     const int strips_x = (W + BCOLS - 1) / BCOLS, nseg = (H + seg_rows - 1) / seg_rows;
     const long long nitems = (long long)B * nseg * strips_x;
     COLVO_CHECK_ARG(nitems < (1ll << 30), "colvo_warp_loss_fused: too many strips");
-    hipLaunchKernelGGL((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose,
+    colvo::launch((k_warp_loss_bwd_march<true>), dim3((unsigned)((nitems + 3) / 4)), dim3(NT), 0, s, tgt, ref, depth, pose,
                        K, lcc_a, lcc_b, B, H, W, strips_x, nseg, seg_rows, ssim_weight, (const float*)nullptr,
                        (const float*)nullptr, d_depth_raw, workspace, 0, GeoArgs{});
     COLVO_CHECK_LAUNCH("k_warp_loss_bwd_march<fused>");
-    hipLaunchKernelGGL(k_warp_loss_fused_finalize, dim3(B + 1), dim3(FT), 0, s, workspace, nseg * strips_x, B, pose,
+    colvo::launch(k_warp_loss_fused_finalize, dim3(B + 1), dim3(FT), 0, s, workspace, nseg * strips_x, B, pose,
                        grad_partials, grad_unit, loss_state);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_finalize");
     return 0;
@@ -1779,7 +1779,7 @@ extern "C" int colvo_warp_loss_fused_bwd(const float* loss_state, const float* g
     const size_t n = (size_t)B * H * W;
     unsigned blocks = (unsigned)std::min<size_t>((n + NT * 4 - 1) / (NT * 4), 4096);
     if (blocks < (unsigned)B) blocks = (unsigned)B;
-    hipLaunchKernelGGL(k_warp_loss_fused_bwd, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, loss_state, grad_loss, d_depth_raw,
+    colvo::launch(k_warp_loss_fused_bwd, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, loss_state, grad_loss, d_depth_raw,
                        grad_partials, pose, B, n, d_depth, d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd");
     return 0;
@@ -1791,7 +1791,7 @@ extern "C" int colvo_warp_loss_fused_bwd_params(const float* loss_state, const f
     COLVO_CHECK_ARG(loss_state && grad_loss && grad_partials && pose && d_pose && d_a && d_b,
                     "colvo_warp_loss_fused_bwd_params: null pointer argument");
     COLVO_CHECK_ARG(B >= 1 && B <= 65534, "colvo_warp_loss_fused_bwd_params: bad batch %d", B);
-    hipLaunchKernelGGL(k_warp_loss_fused_bwd_params, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, loss_state, grad_loss,
+    colvo::launch(k_warp_loss_fused_bwd_params, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, loss_state, grad_loss,
                        grad_partials, pose, B, d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd_params");
     return 0;
@@ -1804,7 +1804,7 @@ extern "C" int colvo_inverse_warp(const float* ref, const float* depth, const fl
     hipStream_t s = (hipStream_t)stream;
     const size_t plane = (size_t)H * W;
     dim3 grid((unsigned)((plane + NT - 1) / NT), B);
-    hipLaunchKernelGGL(k_inverse_warp, grid, dim3(NT), 0, s, ref, depth, pose, K, C, H, W, warped, valid);
+    colvo::launch(k_inverse_warp, grid, dim3(NT), 0, s, ref, depth, pose, K, C, H, W, warped, valid);
     COLVO_CHECK_LAUNCH("k_inverse_warp");
     return 0;
 }
@@ -1821,9 +1821,9 @@ extern "C" int colvo_geo_loss_fwd(const float* depth_t, const float* depth_r, co
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_geo_loss_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
-    hipLaunchKernelGGL(k_geo_loss_fwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, workspace);
+    colvo::launch(k_geo_loss_fwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, workspace);
     COLVO_CHECK_LAUNCH("k_geo_loss_fwd");
-    hipLaunchKernelGGL(k_geo_loss_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), loss_state);
+    colvo::launch(k_geo_loss_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), loss_state);
     COLVO_CHECK_LAUNCH("k_geo_loss_finalize");
     return 0;
 }
@@ -1838,10 +1838,10 @@ extern "C" int colvo_geo_loss_bwd(const float* depth_t, const float* depth_r, co
     hipError_t e = hipMemsetAsync(d_depth_r, 0, (size_t)B * H * W * sizeof(float), s);
     if (e != hipSuccess) { set_error("colvo_geo_loss_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e)); return (int)e; }
     const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
-    hipLaunchKernelGGL(k_geo_loss_bwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, loss_state, grad_loss,
+    colvo::launch(k_geo_loss_bwd, dim3(nb, B), dim3(NT), 0, s, depth_t, depth_r, pose, K, H, W, loss_state, grad_loss,
                        d_depth_t, d_depth_r, workspace);
     COLVO_CHECK_LAUNCH("k_geo_loss_bwd");
-    hipLaunchKernelGGL(k_geo_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, (int)nb, pose, d_pose);
+    colvo::launch(k_geo_loss_bwd_finalize, dim3(B), dim3(NT), 0, s, workspace, (int)nb, pose, d_pose);
     COLVO_CHECK_LAUNCH("k_geo_loss_bwd_finalize");
     return 0;
 }
@@ -1852,9 +1852,9 @@ extern "C" int colvo_smooth_loss_fwd(const float* depth, const float* img, int B
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_smooth_loss_fwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
-    hipLaunchKernelGGL(k_smooth_fwd, dim3(nb, B), dim3(NT), 0, s, depth, img, H, W, workspace);
+    colvo::launch(k_smooth_fwd, dim3(nb, B), dim3(NT), 0, s, depth, img, H, W, workspace);
     COLVO_CHECK_LAUNCH("k_smooth_fwd");
-    hipLaunchKernelGGL(k_smooth_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), 1.0f / ((float)B * H * (W - 1)),
+    colvo::launch(k_smooth_finalize, dim3(1), dim3(NT), 0, s, workspace, (int)(nb * B), 1.0f / ((float)B * H * (W - 1)),
                        1.0f / ((float)B * (H - 1) * W), loss);
     COLVO_CHECK_LAUNCH("k_smooth_finalize");
     return 0;
@@ -1865,7 +1865,7 @@ extern "C" int colvo_smooth_loss_bwd(const float* depth, const float* img, int B
     COLVO_CHECK_ARG(depth && img && grad_loss && d_depth, "colvo_smooth_loss_bwd: null pointer argument");
     COLVO_CHECK_ARG(B >= 1 && B <= 65535 && H >= 2 && W >= 2 && (size_t)H * W < (1u << 30), "colvo_smooth_loss_bwd: bad shape");
     const unsigned nb = (unsigned)(((size_t)H * W + NT - 1) / NT);
-    hipLaunchKernelGGL(k_smooth_bwd, dim3(nb, B), dim3(NT), 0, (hipStream_t)stream, depth, img, H, W,
+    colvo::launch(k_smooth_bwd, dim3(nb, B), dim3(NT), 0, (hipStream_t)stream, depth, img, H, W,
                        1.0f / ((float)B * H * (W - 1)), 1.0f / ((float)B * (H - 1) * W), grad_loss, d_depth);
     COLVO_CHECK_LAUNCH("k_smooth_bwd");
     return 0;
@@ -1875,7 +1875,7 @@ extern "C" int colvo_avgpool2_fwd(const float* x, int planes, int H, int W, floa
     COLVO_CHECK_ARG(x && y, "colvo_avgpool2_fwd: null pointer argument");
     COLVO_CHECK_ARG(planes >= 1 && planes <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "colvo_avgpool2_fwd: H, W must be even");
     const int Ho = H / 2, Wo = W / 2;
-    hipLaunchKernelGGL(k_avgpool2_fwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
+    colvo::launch(k_avgpool2_fwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
                        x, Ho, Wo, y);
     COLVO_CHECK_LAUNCH("k_avgpool2_fwd");
     return 0;
@@ -1885,7 +1885,7 @@ extern "C" int colvo_avgpool2_bwd(const float* dy, int planes, int H, int W, flo
     COLVO_CHECK_ARG(dy && dx, "colvo_avgpool2_bwd: null pointer argument");
     COLVO_CHECK_ARG(planes >= 1 && planes <= 65535 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "colvo_avgpool2_bwd: H, W must be even");
     const int Ho = H / 2, Wo = W / 2;
-    hipLaunchKernelGGL(k_avgpool2_bwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
+    colvo::launch(k_avgpool2_bwd, dim3((unsigned)(((size_t)Ho * Wo + NT - 1) / NT), planes), dim3(NT), 0, (hipStream_t)stream,
                        dy, Ho, Wo, dx);
     COLVO_CHECK_LAUNCH("k_avgpool2_bwd");
     return 0;
@@ -1934,14 +1934,14 @@ extern "C" int colvo_full_objective_fwd(const float* tgt, const float* ref, cons
         const size_t cells = NL ? 7 * (size_t)B * (plane >> (2 * NL)) : 0;
         const unsigned blocks = (unsigned)(a.sm_blocks + (cells + NT - 1) / NT);
         if (blocks) {
-            if (NL == 2) hipLaunchKernelGGL((k_full_prepare<2>), dim3(blocks), dim3(NT), 0, s, a);
-            else if (NL == 1) hipLaunchKernelGGL((k_full_prepare<1>), dim3(blocks), dim3(NT), 0, s, a);
-            else hipLaunchKernelGGL((k_full_prepare<0>), dim3(blocks), dim3(NT), 0, s, a);
+            if (NL == 2) colvo::launch((k_full_prepare<2>), dim3(blocks), dim3(NT), 0, s, a);
+            else if (NL == 1) colvo::launch((k_full_prepare<1>), dim3(blocks), dim3(NT), 0, s, a);
+            else colvo::launch((k_full_prepare<0>), dim3(blocks), dim3(NT), 0, s, a);
             COLVO_CHECK_LAUNCH("k_full_prepare");
         }
         for (int l = 3; l < num_scales; ++l) {
             const size_t px = (size_t)p.h[l] * p.w[l];
-            hipLaunchKernelGGL(k_pyramid_level, dim3((unsigned)((px + NT - 1) / NT), 7 * B), dim3(NT), 0, s, workspace + p.tgt[l - 1],
+            colvo::launch(k_pyramid_level, dim3((unsigned)((px + NT - 1) / NT), 7 * B), dim3(NT), 0, s, workspace + p.tgt[l - 1],
                                workspace + p.ref[l - 1], workspace + p.dep[l - 1], B, p.h[l], p.w[l], workspace + p.tgt[l],
                                workspace + p.ref[l], workspace + p.dep[l]);
             COLVO_CHECK_LAUNCH("k_pyramid_level");
@@ -1970,14 +1970,14 @@ extern "C" int colvo_full_objective_fwd(const float* tgt, const float* ref, cons
         // both terms are masked means over the SAME valid pixels (photometric: 3 channels each, weight 1/S): relative to the
         // photometric gradient the term's weighs  geo_weight / n  over  (1/S) / (3 n)
         GeoArgs ga{depth_r, acc, workspace + p.geo_part, workspace + p.geo_raw, 3.0f * (float)num_scales * geo_weight};
-        hipLaunchKernelGGL((k_warp_loss_march_levels<true>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight, ga);
+        colvo::launch((k_warp_loss_march_levels<true>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight, ga);
     } else {
-        hipLaunchKernelGGL((k_warp_loss_march_levels<false>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight,
+        colvo::launch((k_warp_loss_march_levels<false>), dim3(grid), dim3(NT), 0, s, ml, pose, K, lcc_a, lcc_b, B, ssim_weight,
                            GeoArgs{});
     }
     COLVO_CHECK_LAUNCH("k_warp_loss_march_levels");
     // (3) every term's value, the total, the per-image gradient sums
-    hipLaunchKernelGGL(k_full_finalize, dim3(B * num_scales + 1), dim3(FT), 0, s, lv, geo ? workspace + p.geo_part : (const float*)nullptr,
+    colvo::launch(k_full_finalize, dim3(B * num_scales + 1), dim3(FT), 0, s, lv, geo ? workspace + p.geo_part : (const float*)nullptr,
                        smooth ? workspace + p.sm_part : (const float*)nullptr, p.sm_nblk, inv_nx, inv_ny, geo_weight, smooth_weight,
                        workspace + p.gpart, workspace + p.state, loss);
     COLVO_CHECK_LAUNCH("k_full_finalize");
@@ -2008,7 +2008,7 @@ extern "C" int colvo_full_objective_bwd(const float* workspace, const float* gra
     const bool geo = geo_weight != 0.0f, smooth = smooth_weight != 0.0f;
     unsigned nbx = (unsigned)(((size_t)H * W + NT - 1) / NT);
     if (nbx < (unsigned)B) nbx = (unsigned)B;
-    hipLaunchKernelGGL(k_full_combine, dim3(nbx, B + 1), dim3(NT), 0, (hipStream_t)stream, lv, workspace + p.state, grad_loss,
+    colvo::launch(k_full_combine, dim3(nbx, B + 1), dim3(NT), 0, (hipStream_t)stream, lv, workspace + p.state, grad_loss,
                        smooth ? workspace + p.sd : (const float*)nullptr, geo ? workspace + p.geo_raw : (const float*)nullptr,
                        geo ? reinterpret_cast<const unsigned long long*>(workspace + p.acc) : (const unsigned long long*)nullptr,
                        workspace + p.gpart, pose, H, W, smooth_weight, d_depth_t, geo ? d_depth_r : (float*)nullptr, d_pose, d_a, d_b);

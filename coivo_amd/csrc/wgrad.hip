@@ -591,7 +591,7 @@ inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
     const size_t wsize = (size_t)k.Cout * 9 * k.Ctot;
     const unsigned blocks = (unsigned)std::min<size_t>((wsize + NT - 1) / NT, 2048);
     const unsigned bblocks = k.db ? (unsigned)((k.Cout + NT - 1) / NT) : 0;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(blocks + bblocks), dim3(NT), 0, s, (const float*)k.slabs, nsplit, wsize, k.dw, blocks,
+    colvo::launch(k_wgrad_reduce, dim3(blocks + bblocks), dim3(NT), 0, s, (const float*)k.slabs, nsplit, wsize, k.dw, blocks,
                        (const float*)k.db_slabs, (size_t)k.Cout, k.db);
     COLVO_CHECK_LAUNCH("k_wgrad_reduce");
     return 0;
@@ -630,7 +630,7 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
 #ifdef COLVO_WTRACE
     wtrace_begin(k, grid.x, s);
 #endif
-    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
+    colvo::launch((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3 (teams)");
 #ifdef COLVO_WTRACE
     wtrace_end(k, grid.x, MT, NG, TAIL, KS, s);
@@ -691,7 +691,7 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
 #ifdef COLVO_WTRACE
     wtrace_begin(k, grid.x, s);
 #endif
-    hipLaunchKernelGGL((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
+    colvo::launch((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3");
 #ifdef COLVO_WTRACE
     wtrace_end(k, grid.x, MT, NG, TAIL, 1, s);
@@ -1008,7 +1008,7 @@ int launch_wgrad_up2(WgradK k, hipStream_t s) {
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
     k.nsplit = nsplit; k.cot = cot; k.xcd = (int)TUNE(xcd_remap);
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
-    hipLaunchKernelGGL((k_wgrad_up2<T, MT>), dim3((unsigned)(nsplit * cot * chunks)), dim3(NT), lds, s, k);
+    colvo::launch((k_wgrad_up2<T, MT>), dim3((unsigned)(nsplit * cot * chunks)), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad_up2");
     return wgrad_finish(k, nsplit, s);
 }
@@ -1115,7 +1115,7 @@ extern "C" int colvo_wgrad_reduce_group(const ColvoWgradSlabs* sets, int n, colv
         add(slabs, w.dw, wsize, w.nsplit);
         if (w.db) add(slabs + (size_t)w.nsplit * wsize, w.db, w.Cout, w.nsplit);
     }
-    hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(blk), dim3(NT), 0, (hipStream_t)stream, g);
+    colvo::launch(k_wgrad_reduce_group, dim3(blk), dim3(NT), 0, (hipStream_t)stream, g);
     COLVO_CHECK_LAUNCH("k_wgrad_reduce_group");
     return 0;
 }
