@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the bounded CPU-baseline sample")
     ap.add_argument("--no-roofline-cfg2", action="store_true",
                     help="skip the fused-loss measurement at BASELINE configs[2] (then `roofline` falls back to the in-step figure)")
+    ap.add_argument("--no-zero-in-step", action="store_true", help="developer A/B: FusedAdam without zero_grad_in_step (a clearing launch per step)")
     ap.add_argument("--no-side-measurements", action="store_true",
                     help="skip everything outside the K timed steps (interleaved call-sequence forms, in-step fused-op brackets, "
                          "scaling denominator): the process then runs warm-up + K steps only (tests compare final_loss bit for bit)")
@@ -399,7 +400,8 @@ def main():
                 if name.endswith("weight"):
                     fan_in = p.shape[1] * p.shape[2] * p.shape[3]
                     p.copy_((torch.randn(p.shape, generator=g) * (2.0 / fan_in) ** 0.5).to(dev))
-    opt = FusedAdam([dn, pn], lr=1e-4)
+    # (step() clears the gradients it has just read: the zero_grad() that opens each step then costs no launch -- optim.py)
+    opt = FusedAdam([dn, pn], lr=1e-4, zero_grad_in_step=not args.no_zero_in_step)
     ddp = None
     if world > 1 or args.rccl_single:
         ddp = GradBuckets([dn, pn], bucket_bytes=args.bucket_mb << 20,

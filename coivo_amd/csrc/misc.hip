@@ -837,15 +837,17 @@ __global__ __launch_bounds__(NT) void k_adam_pack(const ColvoAdamPackEntry* __re
     const ColvoAdamPackEntry e = tab[l];
     const int lb = blockIdx.x - e.blk_begin, tid = threadIdx.x;
     float* __restrict__ P = e.param + e.w_off;
-    const float* __restrict__ G = e.grad + e.w_off;
+    float* __restrict__ G = const_cast<float*>(e.grad) + e.w_off;      // (written only where the entry asks for zeroed gradients)
     float* __restrict__ M = e.exp_avg + e.w_off;
     float* __restrict__ V = e.exp_avg_sq + e.w_off;
+    const bool zg = e.zero_grad != 0;
     if (e.kind != 0) {                     // plain range: ADAM_PLAIN_PER_WG elements per workgroup
         const long long k0 = (long long)lb * ADAM_PLAIN_PER_WG;
         for (long long k = k0 + tid; k < e.n && k < k0 + ADAM_PLAIN_PER_WG; k += NT) {
             float pi = P[k], mi = M[k], vi = V[k];
             adam_one(pi, G[k], mi, vi, b1, b2, eps, gscale, c);
             M[k] = mi; V[k] = vi; P[k] = pi;
+            if (zg) G[k] = 0.0f;
         }
         return;
     }
@@ -870,6 +872,7 @@ __global__ __launch_bounds__(NT) void k_adam_pack(const ColvoAdamPackEntry* __re
                 const size_t idx = ((size_t)co * e.kk + t) * e.Cin + cc;
                 adam_one(pv[i], gv[i], mv[i], vv[i], b1, b2, eps, gscale, c);
                 M[idx] = mv[i]; V[idx] = vv[i]; P[idx] = pv[i];
+                if (zg) G[idx] = 0.0f;
                 tile[row][tid & 63] = pv[i];
                 if (e.fwd && e.fwd_off >= 0) Elem<ES>::st(e.fwd, e.fwd_off + idx, pv[i]);
             }

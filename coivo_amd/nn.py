@@ -158,6 +158,10 @@ class _ArenaModule(nn.Module):
         self._build_arena(p.device)
         return self
 
+    # True while the gradient arena is known to be all zero (set by optim.FusedAdam(zero_grad_in_step=True).step(), cleared by every
+    # backward pass): the optimizer's zero_grad() then skips its launch
+    _grads_clean = False
+
     def attach_grads(self) -> None:
         """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
         layers = self._layers()
@@ -636,6 +640,7 @@ class DepthNet(_ArenaModule):
         """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b[, g_raw_second]): the gradient of the
         first / second half of the images and a (scaled) addend for each half (ops.depth_head_bwd_parts), each may be None."""
         A, P, inst = saved
+        self._grads_clean = False
         self.attach_grads()
         B, _, H, W = depth.shape
         dev = depth.device
@@ -863,6 +868,7 @@ class PoseNet(_ArenaModule):
 
     def _backward_impl(self, saved, d_pose, d_a, d_b, scale_a=None, scale_b=None):
         A, P, (B, H, W), has_depth, inst, filled = saved
+        self._grads_clean = False
         self.attach_grads()
         dev = self.flat_param.device
         grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}

@@ -15,7 +15,11 @@ class FusedAdam:
     """opt = FusedAdam([depth_net, pose_net], lr=1e-4); opt.zero_grad(); loss.backward(); opt.step()."""
 
     def __init__(self, modules: Iterable[_ArenaModule], lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, zero_grad_in_step: bool = False):
+        """zero_grad_in_step (not torch's semantics -- off unless asked for): step() leaves the gradient arenas ZERO (the update
+        kernel clears each gradient as it reads it), and the zero_grad() that opens the next step costs no launch while nothing has
+        touched the gradients in between.  The loop `zero_grad(); backward(); step()` computes the same thing either way; code
+        that reads .grad AFTER step() must leave it off."""
         if weight_decay != 0.0:
             raise NotImplementedError("FusedAdam: weight decay is not on the ColVO path")
         self.modules: List[_ArenaModule] = list(modules)
@@ -24,6 +28,7 @@ class FusedAdam:
                 raise TypeError("FusedAdam takes the HIP-backed networks (coivo_amd.nn.DepthNet / PoseNet)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.grad_scale = 1.0
+        self.zero_grad_in_step = bool(zero_grad_in_step)
         self._multi = _lib.dev_env("COLVO_NO_MULTI_ARENA") is None          # developer A/B switches (COLVO_DEV=1)
         self._fused_pack = _lib.dev_env("COLVO_NO_ADAM_PACK") is None
         # Step numbers live on the host (one launch per network); while a hipGraph is being captured the device counters of
@@ -43,7 +48,9 @@ class FusedAdam:
             return
         for m in self.modules:
             m.join_side()
-        ops.zero_multi([m.flat_grad for m in self.modules])
+        # (a captured step always holds its clearing launch: a replay cannot know what happened to the arenas since the last one)
+        if not (all(m._grads_clean for m in self.modules) and not torch.cuda.is_current_stream_capturing()):
+            ops.zero_multi([m.flat_grad for m in self.modules])
         for m in self.modules:
             m.attach_grads()
 
@@ -101,30 +108,32 @@ class FusedAdam:
         # others in line when the state is read)
         for m in self.modules:
             m.operands_written()
+            m._grads_clean = self.zero_grad_in_step
         return True
 
     def _pack_table(self):
         import numpy as np
         def current_key():      # every address the table holds: a rebuilt arena / operand buffer / moment tensor invalidates it
             return tuple((m.flat_param.data_ptr(), m.flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                          m.compute_dtype) + tuple(None if getattr(m, a, None) is None else getattr(m, a).data_ptr()
+                          m.compute_dtype, self.zero_grad_in_step) + tuple(None if getattr(m, a, None) is None else getattr(m, a).data_ptr()
                                                    for a in ("_op_bwd", "_op_fwd"))
                          for m, st in zip(self.modules, self.state))
         if self._pack_cache is not None and all(m._pack_table is not None for m in self.modules) and self._pack_cache[0] == current_key():
             return self._pack_cache[1]
         ent = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("fwd", "<u8"), ("bwd", "<u8"),
                         ("w_off", "<i8"), ("fwd_off", "<i8"), ("bwd_off", "<i8"), ("n", "<i8"),
-                        ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+                        ("Cout", "<i4"), ("kk", "<i4"), ("Cin", "<i4"), ("blk", "<i4"), ("kind", "<i4"), ("zero_grad", "<i4")])
         rows, blk = [], 0
         for m, st in zip(self.modules, self.state):
             layers, rest, op_fwd, op_bwd = m.operand_layout()
             base = (m.flat_param.data_ptr(), m.flat_grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                     0 if op_fwd is None else op_fwd.data_ptr(), op_bwd.data_ptr())
+            zg = int(self.zero_grad_in_step)
             for w_off, fwd_off, bwd_off, cout, cin in layers:
-                rows.append(base + (w_off, fwd_off, bwd_off, 0, cout, 9, cin, blk, 0, 0))
+                rows.append(base + (w_off, fwd_off, bwd_off, 0, cout, 9, cin, blk, 0, zg))
                 blk += 9 * ((cout + 31) // 32) * ((cin + 63) // 64)
             for off, n in rest:
-                rows.append(base + (off, -1, 0, n, 0, 0, 0, blk, 1, 0))
+                rows.append(base + (off, -1, 0, n, 0, 0, 0, blk, 1, zg))
                 blk += (n + _lib.ADAM_PLAIN_PER_WG - 1) // _lib.ADAM_PLAIN_PER_WG
         tab = np.array(rows, dtype=ent)
         dev_tab = torch.from_numpy(tab.view(np.uint8).copy()).to(self.modules[0].flat_param.device)

@@ -366,7 +366,9 @@ int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int count, colvo_st
  * tap-flipped copy at bwd_off of `bwd`, both in `dtype`), taking kk * ceil(Cout/32) * ceil(Cin/64) workgroups from blk_begin on;
  * kind 1 = a plain range of n elements at w_off (biases, heads, padding: update only), ceil(n / COLVO_ADAM_PLAIN_PER_WG)
  * workgroups.  nblocks = the sum.  step_count: device step counter (incremented by a second launch; for steps captured into a
- * hipGraph) or NULL, then t is the 1-based step number. */
+ * hipGraph) or NULL, then t is the 1-based step number.  An entry with zero_grad != 0 has its range of `grad` set to ZERO once read
+ * (grad is then written, its const notwithstanding): the arena-clearing launch of the next step (colvo_zero_multi, 8.5 us + a
+ * dependent launch on the ColVO networks) is not needed. */
 #define COLVO_ADAM_PLAIN_PER_WG 2048
 typedef struct ColvoAdamPackEntry {
     float* param;
@@ -377,7 +379,7 @@ typedef struct ColvoAdamPackEntry {
     void* bwd;
     int64_t w_off, fwd_off, bwd_off, n;
     int32_t Cout, kk, Cin, blk_begin;
-    int32_t kind, pad_;
+    int32_t kind, zero_grad;
 } ColvoAdamPackEntry;
 int colvo_adam_pack_step(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
                          float eps, float grad_scale, int32_t* step_count, int t, colvo_stream_t stream);

@@ -388,3 +388,45 @@ def test_pose_input_filled_by_depthnet_gives_the_same_step_bitwise(monkeypatch):
     torch.cuda.synchronize()
     assert torch.equal(got_other, swapped)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adam_that_clears_the_gradients_equals_the_default_loop(dtype, monkeypatch):
+    """FusedAdam(zero_grad_in_step=True): step() leaves both gradient arenas zero and the next zero_grad() launches nothing; the
+    trajectory of `zero_grad(); backward(); step()` is bit for bit the default one (deterministic weight gradients).  Gradients
+    accumulated by TWO backward passes, and a backward pass between step() and zero_grad(), are still handled (the clean flag drops)."""
+    from coivo_amd import nn as hnn, ops
+    from coivo_amd.optim import FusedAdam
+    d = to_dev(synth.make_batch(2, 64, 96, seed=15))
+    calls = []
+    real = ops.zero_multi
+    monkeypatch.setattr(ops, "zero_multi", lambda ts: (calls.append(len(ts)), real(ts))[1])
+
+    def run(in_step):
+        _, _, dn, pn = _models(15, dtype)
+        dn.deterministic = pn.deterministic = True
+        opt = FusedAdam([dn, pn], lr=1e-3, zero_grad_in_step=in_step)
+        calls.clear()
+        losses = []
+        for it in range(4):
+            opt.zero_grad()
+            for _ in range(2 if it == 2 else 1):         # step 2 accumulates two passes
+                loss = hnn.dcdp_forward(dn, pn, d["tgt"], d["ref"], d["K"])[0]
+                loss.backward()
+            opt.step()
+            losses.append(loss.item())
+            if in_step:
+                dn.join_side(); pn.join_side()
+                assert not dn.flat_grad.any().item() and not pn.flat_grad.any().item()
+            if it == 2:                                    # a stray backward pass after the step: the arenas are dirty again
+                hnn.dcdp_forward(dn, pn, d["tgt"], d["ref"], d["K"])[0].backward()
+        torch.cuda.synchronize()
+        return losses, [n.flat_param.clone() for n in (dn, pn)], [st["exp_avg"].clone() for st in opt.state], list(calls)
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0]
+    for k in (1, 2):
+        for x, y in zip(a[k], b[k]):
+            assert torch.equal(x, y)
+    assert len(b[3]) == 4                                   # the default loop clears at every step
+    assert len(a[3]) == 2, a[3]                             # first step (never stepped) and the one after the stray backward pass
