@@ -60,8 +60,10 @@ constexpr int DH = PH + 2, DW = PW + 2;                                      // 
 // MODE 0: dy given.  1: HEAD form (dy made from the layer's output and the depth head's d(pre)).  2: HEAD form + the head's own weight
 // gradient.  Compile-time, not a kernel argument: a run-time branch around an MFMA makes hipcc merge the carried accumulators
 // through v_mov copies at the join -- reads of MFMA results in front of the guard (tools/isa_check_mfma.py).
+// Three workgroups per CU (168 VGPRs; the MODE 2 form would spill): with the grid at 3 x 256 the HEAD form's step is 0.7 % shorter
+// than with two (1.392 against 1.403 ms, same box; 768 workgroups at two per CU: 1.420 -- the third waits for a slot)
 template <int MODE>
-__global__ __launch_bounds__(NT, 2) void k_bwd16(const Bwd16K a) {
+__global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a) {
     constexpr bool HEAD = MODE >= 1, headw = MODE == 2;
     __shared__ __attribute__((aligned(16))) char sG[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sX[NPIX * PIXB];
@@ -509,7 +511,7 @@ extern "C" int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d) {
 
 static int bwd16_grid(const ColvoConvDesc* d, int* tiles_per_wg) {
     const int ntiles = d->B * ((d->Wi + TOW - 1) / TOW) * ((d->Hi + TOH - 1) / TOH);
-    // grid: bwd16_wgs workgroups (2 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
+    // grid: bwd16_wgs workgroups (3 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
     // 3.64 against 3.67 ms per step with 512), at most four times as many -- every workgroup ends with 2320 atomics on the same addresses
     int wgs = (int)TUNE(bwd16_wgs);
     wgs = std::max(wgs, std::min(4 * wgs, ntiles / 40));
