@@ -26,6 +26,7 @@
 // Built WITH -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py): the input-gradient accumulators are read every tile.
 #define COLVO_ACC_CONSTRAINT "+v"
 #include "conv_common.h"
+#include "tuning.h"
 
 namespace colvo {
 namespace {
@@ -480,7 +481,7 @@ using namespace colvo;
 
 static int head_wgrad_mfma_grid(int B, int H, int W, int* tiles_per_wg) {
     const int ntiles = B * ((W + TOW - 1) / TOW) * ((H + TOH - 1) / TOH);
-    int wgs = std::min(ntiles, 1024);
+    int wgs = std::min(ntiles, (int)TUNE(head_wgrad_wgs));
     const int tpw = (ntiles + wgs - 1) / wgs;
     if (tiles_per_wg) *tiles_per_wg = tpw;
     return (ntiles + tpw - 1) / tpw;

@@ -61,9 +61,14 @@ class GradBuckets:
             # active hardware queues as this GPU schedules well.  With the library's second side stream on top the step measured
             # 5.2 ms instead of 1.7 (bench.py --rccl-single): the claim keeps the weight gradients on ONE
             # side stream while this object is attached (streams.py; detach() gives the queue back).
-            from . import _lib, streams
+            from . import _lib, nn, streams
             if dist.get_backend(process_group) == "nccl":
                 streams.check_environment(self.world)
+            # Four hardware queues are served at a time (streams.py): main + ONE shared weight-gradient stream + the library's
+            # auxiliary one + RCCL's.  (Round 3 kept a side stream per network and switched the auxiliary one off instead: the
+            # one-rank RCCL step 1.55 ms, now 1.39; developer switch COLVO_DDP_OWN_SIDE=1.)
+            if _lib.dev_env("COLVO_DDP_OWN_SIDE") is None:
+                nn.share_side_stream(modules)
             if _lib.dev_env("COLVO_DDP_KEEP_AUX") is None:        # developer A/B switch (COLVO_DEV=1)
                 self._queue_claim = streams.claim_external_queue("rccl")
         self.transport_dtype = transport_dtype

@@ -117,8 +117,16 @@ class GraphedTrainStep:
         _lib.check(lib.colvo_set_capture_carry(int(self.carry)), "colvo_set_capture_carry")
         _lib.check(lib.colvo_graph_stats_reset(), "colvo_graph_stats_reset")
         g = torch.cuda.CUDAGraph()
+        nspace = int(_lib.dev_env("COLVO_GRAPH_SPACER_STREAMS", "0"))       # (developer probe: streams created in front of the capture)
+        self._spacers = [torch.cuda.Stream() for _ in range(nspace)]
+        for sp in self._spacers:
+            with torch.cuda.stream(sp):
+                torch.zeros(1, device=self.frames.device)
         try:
-            with torch.cuda.graph(g):
+            # thread_local: with a process group alive its watchdog thread polls the events of collectives still in flight; under
+            # the default (global) capture mode that poll is "not permitted when stream is capturing", fails the capture and takes
+            # the process down with it (seen at 64 pairs with --rccl-single; once in round 4's test runs)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self._step()
                 self.loss.copy_(out)
                 # every open chain is joined by now (the optimizer joins before it reads the gradients)

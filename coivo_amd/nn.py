@@ -58,6 +58,47 @@ class ConvParams(nn.Module):
         self.span: Tuple[int, int] = (0, 0)            # [begin, end) of this layer inside the arena
 
 
+_shared_side = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """The weight-gradient side stream of one network.  Developer A/B COLVO_SHARED_SIDE_STREAM=1: ONE per device, shared by every
+    network.  Measured (round 4, 8 pairs): a stream of its own per network is a hardware queue of its own and only four queues are
+    served at a time -- with main + two side streams + the library's auxiliary stream the limit is reached, a THIRD weight-gradient
+    stream (COLVO_SIDE_STREAMS=3) takes the step from 1.34 to 3.5 ms whatever GPU_MAX_HW_QUEUES says, with the shared stream it
+    does not (1.344 ms) -- but it does not win either (two: 1.333), the eager step is level (1.333 against 1.336), and the replayed
+    hipGraph lands its side branch on the main chain's queue (2.8-4.0 ms against 1.44; two more streams created in front of the
+    capture cure that: graph.py COLVO_GRAPH_SPACER_STREAMS).  Hence: per network, as before."""
+    if _lib.dev_env("COLVO_SHARED_SIDE_STREAM") is None:
+        return torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _shared_side.get(key)
+    if st is None:
+        st = _shared_side[key] = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY)
+    return st
+
+
+def share_side_stream(modules) -> Optional["torch.cuda.Stream"]:
+    """Put the weight gradients of every network in `modules` on ONE side stream (they keep running beside the main stream; the
+    networks' backward passes follow one another anyway) and tell the stream policy: a hardware queue is then free for an external
+    party -- ddp.GradBuckets calls this for RCCL's stream (streams.py has the measurements)."""
+    from . import streams
+    nets = [m for m in modules if isinstance(m, _ArenaModule) and m.flat_param.is_cuda]
+    if not nets or torch.cuda.is_current_stream_capturing():
+        return None
+    shared = next((m._side for m in nets if m._side is not None), None)
+    if shared is None:
+        shared = torch.cuda.Stream(device=nets[0].flat_param.device, priority=_SIDE_PRIORITY)
+    for m in nets:
+        if m._side is not shared:
+            m.join_side()
+            if m._side is not None:
+                shared.wait_stream(m._side)        # (work a hook may still have in flight there)
+            m._side = shared
+    streams.networks_share_side_stream(True)
+    return shared
+
+
 class _ArenaModule(nn.Module):
     """Base: owns the flat parameter / gradient arenas of its ConvParams children."""
 
@@ -286,7 +327,7 @@ class _ArenaModule(nn.Module):
                 pr.patch(name, t)
         pr, out = entry
         if pr.uses_side and self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_param.device, priority=_SIDE_PRIORITY)
+            self._side = _side_stream(self.flat_param.device)
         if self.grad_ready_hook is None or not pr.marks:
             pr.run(self._side)
         else:
@@ -344,7 +385,7 @@ class _ArenaModule(nn.Module):
         self._group, self._group_bytes = [], 0
         self._main = torch.cuda.current_stream()
         if self.overlap_wgrad and self._side is None:
-            self._side = torch.cuda.Stream(device=self.flat_param.device, priority=_SIDE_PRIORITY)
+            self._side = _side_stream(self.flat_param.device)
         self._side_used = False
 
     def _run_wgrad(self, L, fn, *tensors) -> None:

@@ -27,6 +27,7 @@ _lock = threading.RLock()      # re-entrant: a QueueClaim collected while the lo
 _claims: Dict[int, str] = {}
 _next_id = 0
 _base_aux = _DEFAULT_AUX    # what configure() asked for when no external queue is claimed
+_shared_side = False        # the networks run their weight gradients on ONE shared side stream (nn.share_side_stream)
 
 
 def hw_queue_limit(env=None) -> Optional[int]:
@@ -44,8 +45,17 @@ def folded(env=None) -> bool:
     return q is not None and q <= 2
 
 
+def _free_claims() -> int:
+    """External queues that fit beside the auxiliary stream.  Round 4 measured the real budget: FOUR queues are served at a time
+    (main + DepthNet's side stream + PoseNet's side stream + the auxiliary stream run at full speed, a fifth stream costs 1.34 ->
+    3.5 ms per step whatever GPU_MAX_HW_QUEUES says).  With one side stream per network nothing is left for an external party; when
+    the networks SHARE one side stream (ddp.GradBuckets arranges that) one external queue -- RCCL's -- fits: the one-rank RCCL step
+    measured 1.39 ms against 1.55 with the auxiliary stream switched off (and 3.67 with five streams)."""
+    return 1 if _shared_side else 0
+
+
 def _apply() -> int:
-    n = _base_aux if (not _claims or folded()) else 0
+    n = _base_aux if (len(_claims) <= _free_claims() or folded()) else 0
     from . import _lib
     _lib.check(_lib.load().colvo_set_aux_side_streams(n), "colvo_set_aux_side_streams")
     return n
@@ -55,11 +65,12 @@ def configure(n_external_queues: int = 0, aux_side_streams: int = _DEFAULT_AUX) 
     """Explicit form for hosts that drive streams of their own without going through GradBuckets / PairLoader: declare how
     many hardware queues OTHER than the step's main and side stream the process keeps busy.  Returns the number of auxiliary
     side streams colvo_run_commands may use from now on.  Replaces every earlier claim."""
-    global _base_aux, _next_id
+    global _base_aux, _next_id, _shared_side
     if n_external_queues < 0 or aux_side_streams < 0:
         raise ValueError("streams.configure: counts must be >= 0")
     with _lock:
         _claims.clear()
+        _shared_side = False
         _base_aux = aux_side_streams
         for _ in range(n_external_queues):
             _claims[_next_id] = "configured"
@@ -106,7 +117,16 @@ def external_queues() -> int:
 def aux_side_streams() -> int:
     """The limit currently handed to the library."""
     with _lock:
-        return _base_aux if (not _claims or folded()) else 0
+        return _base_aux if (len(_claims) <= _free_claims() or folded()) else 0
+
+
+def networks_share_side_stream(shared: bool) -> int:
+    """Told by nn.share_side_stream(): the networks' weight gradients run on one common side stream (one hardware queue instead of
+    one per network).  Returns the auxiliary-stream limit now in force."""
+    global _shared_side
+    with _lock:
+        _shared_side = bool(shared)
+        return _apply()
 
 
 def reset() -> None:

@@ -110,6 +110,15 @@ def test_stream_policy_claims(monkeypatch):
     c2.release()
     assert streams.aux_side_streams() == 3 and streams.external_queues() == 0
     assert streams.configure(1) == 0 and streams.configure(0) == 3
+    # the networks on ONE shared side stream (nn.share_side_stream, what ddp.GradBuckets arranges): one external queue fits
+    assert streams.networks_share_side_stream(True) == 3
+    c3 = streams.claim_external_queue("rccl")
+    assert streams.aux_side_streams() == 3 and streams.external_queues() == 1
+    c4 = streams.claim_external_queue("loader")
+    assert streams.aux_side_streams() == 0
+    c4.release(); c3.release()
+    assert streams.networks_share_side_stream(False) == 3
+    streams.reset()
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
     c = streams.claim_external_queue("x")
     assert streams.aux_side_streams() == 3          # folded onto two queues: the claim changes nothing
