@@ -474,10 +474,108 @@ __global__ __launch_bounds__(NT, 4) void k_head_wgrad_mfma(const HeadWgradK a) {
     if (lane == 0) row[9 * 16] = hbs;
 }
 
+// ---- input gradient of a stride-2 3x3 layer w.r.t. TWO input channels, as fp32 planes, by MFMA (colvo_conv_dgrad_planes) ----
+// PoseNet's first layer (8 -> 16, stride 2): only the two depth channels of its input gradient are wanted, as planes for DepthNet's
+// backward pass; the kernel sits between the two networks' backward passes on the main chain.  The VALU form (csrc/misc.hip: thread =
+// pixel pair, weights read from LDS once per FMA) took 13-24 us there for a 5 MB read and a 5 MB write.  Here a 2 x 2 block of input
+// pixels (2Y + py, 2X + px) is ONE row of a small product: it sees the four gradient pixels g[Y .. Y+1][X .. X+1] (16 channels each:
+// K = 64) and its 4 classes x 2 channels are 8 of the 16 output columns,
+//     dx[2Y+py][2X+px][c] = sum_{gy, gx, co} W'[(gy, gx, co)][(py, px, c)] g[Y+gy][X+gx][co],
+//     W' = w[co][ky][kx][c] with ky = 1 (py = 0, gy = 0), 2 (py = 1, gy = 0), 0 (py = 1, gy = 1), kx likewise -- zero elsewhere.
+// A wave takes 16 consecutive blocks of one block row per step: the gradient granules go from memory straight into the B operand (lane
+// = block, k-group = (gx, channel half); no LDS), the weights -- fp32 masters split into THREE bf16 terms (hi + mid + lo: the product is
+// exact to fp32 round-off, the plane test's bar) -- live in registers as the A operand: 6 MFMAs per 64 input pixels.
+struct PlanesK {
+    const char* g;          // [B][Ho][Wo][16] bf16
+    const float* w;         // [16][9][Cin] fp32
+    float* dst;             // [2][B][1][Hi][Wi]
+    int B, Hi, Wi, Ho, Wo, Cin, c_begin, accumulate;
+    int groups_x, ngroups, groups_per_wave;
+};
+
+__global__ __launch_bounds__(NT) void k_dgrad_planes_s2_mfma(const PlanesK a) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    // A operand: row n = l15 = (py, px, c), k = 32 q + 8 kg + j = (gy = q, gx = kg >> 1, co = 8 (kg & 1) + j)
+    bf16x8 wa[2][3];
+    {
+        const int n = l15, c = n & 1, px = (n >> 1) & 1, py = (n >> 2) & 1, gx = kg >> 1;
+        const int kx = px == 0 ? (gx == 0 ? 1 : -1) : (gx == 0 ? 2 : 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ky = py == 0 ? (q == 0 ? 1 : -1) : (q == 0 ? 2 : 0);
+            const bool on = n < 8 && kx >= 0 && ky >= 0;
+            uint16_t t0[8], t1[8], t2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int co = 8 * (kg & 1) + j;
+                const float wv = on ? a.w[((size_t)co * 9 + ky * 3 + kx) * a.Cin + a.c_begin + c] : 0.0f;
+                t0[j] = f2bf(wv);
+                const float r1 = wv - bf2f(t0[j]);
+                t1[j] = f2bf(r1);
+                t2[j] = f2bf(r1 - bf2f(t1[j]));
+            }
+            auto pack = [](const uint16_t (&t)[8]) {
+                const u32x4 v = u32x4{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16),
+                                      (unsigned)t[4] | ((unsigned)t[5] << 16), (unsigned)t[6] | ((unsigned)t[7] << 16)};
+                return __builtin_bit_cast(bf16x8, v);
+            };
+            wa[q][0] = pack(t0); wa[q][1] = pack(t1); wa[q][2] = pack(t2);
+        }
+    }
+    const long long img_g = (long long)a.Ho * a.Wo * 32;                     // bytes of one image's gradient
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)(img_g * a.B), 0x00020000);
+    const size_t plane = (size_t)a.B * a.Hi * a.Wi;
+    const int g0 = (blockIdx.x * 4 + wave) * a.groups_per_wave;
+    for (int i = 0; i < a.groups_per_wave; ++i) {
+        const int gid = g0 + i;                                              // wave-uniform
+        if (gid >= a.ngroups) break;
+        const int rowid = gid / a.groups_x, X = (gid - rowid * a.groups_x) * 16 + l15;
+        const int b = rowid / a.Ho, Y = rowid - b * a.Ho;
+        const int gxx = X + (kg >> 1);
+        u32x4 gv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool inb = (Y + q < a.Ho) && (gxx < a.Wo);
+            gv[q] = bld16(rg, inb ? (((Y + q) * a.Wo + gxx) * 16 + 8 * (kg & 1)) * 2 : OOB_OFF, (int)(b * img_g));
+        }
+        f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[q][sp], __builtin_bit_cast(bf16x8, gv[q]), acc[0], 0, 0, 0);
+        mfma_result_guard<bf16_t>(acc);
+        // lane (block l15, kg < 2): rows n = 4 kg + r = (py = kg, px = r >> 1, c = r & 1) -> input row 2Y + kg, columns 2X, 2X + 1
+        if (kg < 2 && X < a.Wo) {
+            const size_t o = ((size_t)b * a.Hi + 2 * Y + kg) * a.Wi + 2 * X;
+            float2* d0 = reinterpret_cast<float2*>(a.dst + o);
+            float2* d1 = reinterpret_cast<float2*>(a.dst + plane + o);
+            float2 v0 = make_float2(acc[0][0], acc[0][2]), v1 = make_float2(acc[0][1], acc[0][3]);
+            if (a.accumulate) { const float2 p0 = *d0, p1 = *d1; v0.x += p0.x; v0.y += p0.y; v1.x += p1.x; v1.y += p1.y; }
+            *d0 = v0; *d1 = v1;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace colvo
 
 using namespace colvo;
+
+// (called by colvo_conv_dgrad_planes, csrc/misc.hip, for the shapes this form covers)
+int colvo::launch_dgrad_planes_s2_mfma(const void* g, const float* w, int Cin, int c_begin, int B, int Hi, int Wi, int Ho, int Wo,
+                                       float* dst, int accumulate, hipStream_t stream) {
+    PlanesK k{};
+    k.g = (const char*)g; k.w = w; k.dst = dst; k.B = B; k.Hi = Hi; k.Wi = Wi; k.Ho = Ho; k.Wo = Wo; k.Cin = Cin; k.c_begin = c_begin;
+    k.accumulate = accumulate;
+    k.groups_x = (Wo + 15) / 16; k.ngroups = B * Ho * k.groups_x;
+    // 2 groups per wave up to 8 pairs of 256x320 (1280 workgroups), more beyond
+    k.groups_per_wave = std::max(2, (k.ngroups + 4 * 2048 - 1) / (4 * 2048));
+    const int wgs = (k.ngroups + 4 * k.groups_per_wave - 1) / (4 * k.groups_per_wave);
+    colvo::launch(k_dgrad_planes_s2_mfma, dim3((unsigned)wgs), dim3(NT), 0, stream, k);
+    return 0;
+}
 
 static int head_wgrad_mfma_grid(int B, int H, int W, int* tiles_per_wg) {
     const int ntiles = B * ((W + TOW - 1) / TOW) * ((H + TOH - 1) / TOH);

@@ -53,6 +53,10 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned lds, hi
     }
 }
 
+// csrc/bwd16.hip: the MFMA form of colvo_conv_dgrad_planes (bf16, stride 2, 16 output channels, two input channels, even extents)
+int launch_dgrad_planes_s2_mfma(const void* g, const float* w, int Cin, int c_begin, int B, int Hi, int Wi, int Ho, int Wo, float* dst,
+                                int accumulate, hipStream_t stream);
+
 __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }

@@ -1123,6 +1123,15 @@ extern "C" int colvo_conv_dgrad_planes(const ColvoConvDesc* d, const void* dy, c
                     c_begin + c_count <= d->C0,
                     "colvo_conv_dgrad_planes: Cout a multiple of 8 up to 128, 1 / 2 / 4 channels inside [0, C0) (Cout=%d, channels %d..%d of %d)",
                     d->Cout, c_begin, c_begin + c_count - 1, d->C0);
+    if (d->dtype == COLVO_BF16 && d->stride == 2 && d->Cout == 16 && c_count == 2 && d->Hi % 2 == 0 && d->Wi % 2 == 0 &&
+        (long long)d->B * d->Ho * d->Wo * 32 < 0x7fffffffLL && TUNE(planes_mfma) != 0) {
+        // PoseNet's first layer in the training step: one small MFMA product per 2 x 2 block of input pixels (csrc/bwd16.hip)
+        const int rc = colvo::launch_dgrad_planes_s2_mfma(dy, w_master, d->C0, c_begin, d->B, d->Hi, d->Wi, d->Ho, d->Wo, dst, accumulate,
+                                                          (hipStream_t)stream);
+        if (rc != 0) return rc;
+        COLVO_CHECK_LAUNCH("k_dgrad_planes_s2_mfma");
+        return 0;
+    }
     const size_t npix = d->stride == 2 ? (size_t)d->B * d->Hi * ((d->Wi + 1) / 2) : (size_t)d->B * d->Hi * d->Wi;   // threads
     const size_t lds = (size_t)9 * d->Cout * c_count * 4;
     hipStream_t s = (hipStream_t)stream;

@@ -409,6 +409,8 @@ def test_dgrad_both_sources_equals_two_calls(B, H, W, C0, C1, Cout, dtype):
     # B, Hi, Wi, C0, Cout, stride, c_begin, c_count
     (2, 64, 96, 8, 16, 2, 6, 2),       # PoseNet conv1: the two depth channels of the 8-channel input
     (1, 13, 21, 8, 16, 2, 6, 2),       # odd extent: ragged last output row / column
+    (2, 32, 40, 8, 16, 2, 6, 2),       # (bf16: the MFMA form, 16 blocks per wave step) a block row that ends inside a group of 16
+    (3, 4, 2, 8, 16, 2, 0, 2),         # ... a single block column; the first two channels
     (2, 16, 24, 16, 32, 1, 3, 4),      # stride 1, four channels from the middle
     (3, 9, 7, 8, 8, 2, 0, 1),          # one channel
 ])
