@@ -25,7 +25,8 @@ f = newest(f"{SRC}/bench_trace/*/*_kernel_stats.csv")
 rows = list(csv.DictReader(open(f)))
 with open(f"profiles/{R}_bench_kernel_stats.csv", "w", newline="") as o:
     w = csv.writer(o)
-    w.writerow(["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph off: 25 fast-path steps (5 warm-up + 20 timed), 23 steps of the spec call sequence (spec_sequence_ms side measurement: 3 + 20), 23 steps with the widened objective (full_objective side measurement) and the configs[2] roofline probe of the fused loss (25 launches)"])
+    steps = sum(int(r["Calls"]) for r in rows if "k_adam_pack" in r["Name"])
+    w.writerow([f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --graph off: {steps} training steps in all (k_adam_pack calls) = 5 warm-up + 20 timed fast-path steps, then the side measurements of the round-4 protocol -- the three call-sequence forms interleaved A-B-C in blocks (fast path / spec call sequence / widened objective), the pipeline-full repeat of the timed loop, 10 steps with event brackets around the fused op -- and the configs[2] roofline probe of the fused loss (k_warp_loss_bwd_march at B=32 640x512).  Per-step figures: divide a kernel's Calls by its launches per step, not by a step count"])
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for r in rows:
         w.writerow([r["Name"].replace("colvo::(anonymous namespace)::", "")[:110], r["Calls"], r["TotalDurationNs"], r["AverageNs"],
