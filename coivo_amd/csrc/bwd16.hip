@@ -376,12 +376,12 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
 // The VALU kernel of csrc/misc.hip (thread = strided pixels, 48 accumulators, nine scattered d(pre) loads per pixel) runs at 26 + 5 us
 // for a 47 MB read at 16 frames -- on the weight-gradient streams, which are what ends the backward pass at 8 pairs.  Here a workgroup
 // walks 8 x 16 tiles: y tile (256 granules, one per thread) and the 10 x 18 d(pre) patch in LDS, wave w takes the 32 pixels of k-step
-// w: A = y^T by transposed reads, B[q][t] = dpre[q + 1 - t] rounded to bf16 (as y is), ONE MFMA per wave and tile; partial rows per
-// wave for the table reduction (k_head_wgrad_reduce).
+// w: A = y^T by transposed reads, B[q][t] = dpre[q + 1 - t] rounded to bf16 (as y is), ONE MFMA per wave and tile; one partial row per
+// workgroup for the table reduction (k_head_wgrad_reduce).
 struct HeadWgradK {
     const char* y;          // [B][H][W][16] bf16
     const float* dpre;      // [B][H][W]
-    float* partials;        // [4 * grid][145]
+    float* partials;        // [grid][145]
     int B, H, W;
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
 };
@@ -465,13 +465,19 @@ __global__ __launch_bounds__(NT, 4) void k_head_wgrad_mfma(const HeadWgradK a) {
         }
         mfma_result_guard<bf16_t>(acc);                 // (carried across the loop: closed every tile, see k_bwd16)
     }
-    float* row = a.partials + ((size_t)blockIdx.x * 4 + wave) * (9 * 16 + 1);
+    // ONE partial row per workgroup: the four waves' sums meet in LDS in a fixed order (the reduction's second launch reads its table
+    // column-wise, 580 bytes from row to row: a quarter of the rows is a quarter of its cache lines -- beside k_bwd16 in the step it ran
+    // 27-35 us for 4096 rows, 7 us alone)
+    __shared__ float sR[4][9 * 16 + 1];
     if (l15 < 9) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) row[l15 * 16 + 4 * kg + r] = acc[0][r];
+        for (int r = 0; r < 4; ++r) sR[wave][l15 * 16 + 4 * kg + r] = acc[0][r];
     }
     const float hbs = wave_sum(hb);
-    if (lane == 0) row[9 * 16] = hbs;
+    if (lane == 0) sR[wave][9 * 16] = hbs;
+    __syncthreads();
+    if (tid < 9 * 16 + 1)
+        a.partials[(size_t)blockIdx.x * (9 * 16 + 1) + tid] = (sR[0][tid] + sR[1][tid]) + (sR[2][tid] + sR[3][tid]);
 }
 
 // ---- input gradient of a stride-2 3x3 layer w.r.t. TWO input channels, as fp32 planes, by MFMA (colvo_conv_dgrad_planes) ----
@@ -587,7 +593,7 @@ static int head_wgrad_mfma_grid(int B, int H, int W, int* tiles_per_wg) {
 
 extern "C" int colvo_depth_head_wgrad_mfma_rows(int B, int H, int W) {
     if (B < 1 || H < 1 || W < 1 || (long long)B * H * W * 32 >= 0x40000000LL) return 0;
-    return 4 * head_wgrad_mfma_grid(B, H, W, nullptr);
+    return head_wgrad_mfma_grid(B, H, W, nullptr);
 }
 
 extern "C" int colvo_depth_head_wgrad_mfma(const void* y, const float* dpre, int B, int H, int W, float* partials, colvo_stream_t stream) {

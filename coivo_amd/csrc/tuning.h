@@ -58,7 +58,7 @@ namespace tune {
     X(wgrad_team_wgs, 256, "... grid size of the team form")                                                                        \
     X(bwd16, 1, "input + weight gradient of the 16 -> 16 full-resolution layer in one pass (k_bwd16, csrc/bwd16.hip)")                \
     X(bwd16_wgs, 768, "... its grid: every workgroup ends with 2320 atomics on the same addresses")                                  \
-    X(head_wgrad_wgs, 1024, "grid of k_head_wgrad_mfma (4 partial rows per workgroup)") \
+    X(head_wgrad_wgs, 1024, "grid of k_head_wgrad_mfma (one partial row per workgroup)") \
     X(planes_mfma, 1, "input gradient of PoseNet's first layer w.r.t. the two depth channels by MFMA (k_dgrad_planes_s2_mfma)") \
     X(fwd16, 1, "the 16 -> 16 full-resolution layer and the depth head behind it in one pass (k_fwd16_head, csrc/fwd16.hip)")          \
     X(fwd16_wgs, 1024, "... its grid (at least; one workgroup per 8 tiles beyond that)")                                              \
