@@ -53,6 +53,7 @@ namespace tune {
     X(wgrad_atomic_mb, 3, "cap on the fp32 atomic traffic of a launch, MB (12 MB 592 us, 6 MB 575, 3 MB 566 over the stack)")       \
     X(wgrad_wg_lo, 256, "... but at least this many workgroups")                                                                    \
     X(wgrad_wg_hi, 1024, "... and at most this many")                                                                               \
+    X(wgrad_short_walk, 32, "... half the floor while a workgroup of the full grid would walk fewer pixel tiles than this (0: off)")                                                                               \
     X(wgrad_teams, 4, "pixel-tile teams per workgroup on the full-resolution layers (1 = off)")                                     \
     X(wgrad_team_max_slabs, 2, "... for layers with at most this many (co tile, chunk) slabs")                                      \
     X(wgrad_team_wgs, 256, "... grid size of the team form")                                                                        \

@@ -597,6 +597,19 @@ inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
     return 0;
 }
 
+// The floor of a weight-gradient grid: `base` workgroups (tuning: wgrad_wg_lo / wgrad_team_wgs), but HALF of that while a workgroup of
+// the full grid would walk fewer than wgrad_short_walk pixel tiles.  A workgroup's fixed costs -- 2 us of set-up and first loads, 6-7 us
+// of fp32 atomics at the end (profiles/r4_wgrad_phases.md) -- are then most of its life; alone on the GPU the kernel is still fastest
+// with one workgroup per CU (what round 2-3 tuned for), but in the step three kernels share the CUs and the sum of workgroup lives is
+// what counts: 128 instead of 256 workgroups at 16 frames measured -2.8 % per step (1.3097 -> 1.2726 ms), 96 -> +1 %, 64 -> +9 %;
+// at 64 / 128 frames, where the walks are 4-8 times longer, halving every layer cost 0.4-0.5 %.
+static inline int wgrad_grid_floor(int base, int ntiles, int per_split) {
+    const int short_walk = (int)TUNE(wgrad_short_walk);
+    const int nsplit_at_base = std::max(1, (base + per_split - 1) / per_split);
+    if (short_walk > 0 && ntiles / nsplit_at_base < short_walk) return std::max(1, base / 2);
+    return base;
+}
+
 template <typename T, int MT, int NG, bool TAIL, int KS>
 int launch_wgrad_teams(WgradK k, hipStream_t s) {
     constexpr int G = TT<T>::G;
@@ -618,7 +631,7 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
     const int cot = (k.Cout + 16 * MT - 1) / (16 * MT);
     // one workgroup per CU (KS * 4 waves fill its SIMDs): as many pixel-range splits as keep the grid within 256
     const int per_split = chunks * cot;
-    const int wg_target = (int)TUNE(wgrad_team_wgs);   // tuning knob
+    const int wg_target = wgrad_grid_floor((int)TUNE(wgrad_team_wgs), k.ntiles, per_split);
     int nsplit = std::max(1, wg_target / per_split);
     if (nsplit > k.ntiles) nsplit = k.ntiles;
     k.tiles_per_split = (k.ntiles + nsplit - 1) / nsplit;
@@ -674,7 +687,7 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
     const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
     const int per_split = chunks * cot;
     const double atomic_budget = TUNE_F(wgrad_atomic_mb) * 1e6;
-    const int wg_lo = (int)TUNE(wgrad_wg_lo);
+    const int wg_lo = wgrad_grid_floor((int)TUNE(wgrad_wg_lo), k.ntiles, per_split);
     const int wg_hi = (int)TUNE(wgrad_wg_hi);
     int nsplit = (int)(atomic_budget / wbytes);
     const int lo = (wg_lo + per_split - 1) / per_split, hi = (wg_hi + per_split - 1) / per_split;
@@ -999,7 +1012,8 @@ int launch_wgrad_up2(WgradK k, hipStream_t s) {
     const double wbytes = (double)k.Cout * 9.0 * k.Ctot * 4.0;
     const int per_split = chunks * cot;
     int nsplit = (int)(TUNE_F(wgrad_atomic_mb) * 1e6 / wbytes);
-    const int lo = ((int)TUNE(wgrad_wg_lo) + per_split - 1) / per_split, hi = ((int)TUNE(wgrad_wg_hi) + per_split - 1) / per_split;
+    const int lo = (wgrad_grid_floor((int)TUNE(wgrad_wg_lo), k.ntiles, per_split) + per_split - 1) / per_split;
+    const int hi = ((int)TUNE(wgrad_wg_hi) + per_split - 1) / per_split;
     if (nsplit > hi) nsplit = hi;
     if (nsplit < lo) nsplit = lo;
     if (nsplit > k.ntiles) nsplit = k.ntiles;
