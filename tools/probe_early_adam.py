@@ -53,6 +53,21 @@ def main():
             return True
         return False
 
+    def step_next():
+        """timing probe of the OTHER overlap: the update on a side stream under the NEXT step's forward pass (the main stream does
+        not wait for it at all here -- an upper bound; a real form lets the first layers' update run on the main stream and makes
+        the forward pass wait for the rest where it first needs it)"""
+        opt.zero_grad()
+        d_t, d_r, d_l = dn.forward_pair_split(frames)
+        pose, a, bb = pn(tgt, ref, d_t, d_r)
+        loss = Fh.photometric_loss(tgt, ref, d_l, pose, K, a, bb)
+        loss.backward(gradient=one)
+        x = pn._side
+        dn.join_side(); pn.join_side()
+        x.wait_stream(main)
+        with torch.cuda.stream(x):
+            opt.step()
+
     def step(early):
         opt.zero_grad()
         d_t, d_r, d_l = dn.forward_pair_split(frames)
@@ -89,6 +104,25 @@ def main():
     torch.cuda.synchronize()
     for r in range(3):
         print(f"round {r}: base {timed(False, args.steps):.4f} ms   early({args.layer}) {timed(True, args.steps):.4f} ms", flush=True)
+    dn.grad_ready_hook = None
+    global_step = step
+
+    def timed_fn(fn, n):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        evs[0].record()
+        for i in range(n):
+            fn()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        t = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+        return t[len(t) // 2]
+
+    for _ in range(10):
+        step_next()
+    torch.cuda.synchronize()
+    for r in range(3):
+        print(f"round {r}: base {timed_fn(lambda: global_step(False), args.steps):.4f} ms   update under the next forward pass "
+              f"{timed_fn(step_next, args.steps):.4f} ms", flush=True)
 
 
 if __name__ == "__main__":
