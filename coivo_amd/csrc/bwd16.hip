@@ -577,7 +577,7 @@ int colvo::launch_dgrad_planes_s2_mfma(const void* g, const float* w, int Cin, i
     k.accumulate = accumulate;
     k.groups_x = (Wo + 15) / 16; k.ngroups = B * Ho * k.groups_x;
     // 2 groups per wave up to 8 pairs of 256x320 (1280 workgroups), more beyond
-    k.groups_per_wave = std::max(2, (k.ngroups + 4 * 2048 - 1) / (4 * 2048));
+    k.groups_per_wave = std::max((int)TUNE(planes_groups), (k.ngroups + 4 * 2048 - 1) / (4 * 2048));
     const int wgs = (k.ngroups + 4 * k.groups_per_wave - 1) / (4 * k.groups_per_wave);
     colvo::launch(k_dgrad_planes_s2_mfma, dim3((unsigned)wgs), dim3(NT), 0, stream, k);
     return 0;

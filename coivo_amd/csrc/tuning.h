@@ -61,6 +61,7 @@ namespace tune {
     X(bwd16_wgs, 768, "... its grid: every workgroup ends with 2320 atomics on the same addresses")                                  \
     X(head_wgrad_wgs, 1024, "grid of k_head_wgrad_mfma (one partial row per workgroup)") \
     X(planes_mfma, 1, "input gradient of PoseNet's first layer w.r.t. the two depth channels by MFMA (k_dgrad_planes_s2_mfma)") \
+    X(planes_groups, 2, "... 16-block groups a wave walks (its weight set-up is amortised over them)") \
     X(fwd16, 1, "the 16 -> 16 full-resolution layer and the depth head behind it in one pass (k_fwd16_head, csrc/fwd16.hip)")          \
     X(fwd16_wgs, 1024, "... its grid (at least; one workgroup per 8 tiles beyond that)")                                              \
     /* ---- heads, fused loss, streams ---- */                                                                                      \
