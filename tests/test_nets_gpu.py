@@ -430,3 +430,39 @@ def test_adam_that_clears_the_gradients_equals_the_default_loop(dtype, monkeypat
             assert torch.equal(x, y)
     assert len(b[3]) == 4                                   # the default loop clears at every step
     assert len(a[3]) == 2, a[3]                             # first step (never stepped) and the one after the stray backward pass
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_forks_on_completion_signals_order_the_weight_gradients_like_recorded_events(dtype):
+    """csrc/program.hip: a FORK waits on the event the producing kernel carried (hipExtLaunchKernel stopEvent) instead of a recorded
+    marker (tuning `fork_stop_event`).  With deterministic weight gradients every kernel of the step is order-independent, so the
+    two forms must end in BIT-IDENTICAL gradients -- a weight-gradient kernel that started before its dy was complete would not --
+    over several passes (the event ring is re-used) and with the halved weight-gradient grids switched off as well."""
+    from coivo_amd import _lib, nn as hnn
+    d = to_dev(synth.make_batch(2, 64, 96, seed=23))
+    frames = torch.cat([d["tgt"], d["ref"]])
+
+    def run(stop_event, short_walk):
+        _lib.tune_set("fork_stop_event", stop_event)
+        _lib.tune_set("wgrad_short_walk", short_walk)
+        try:
+            _, _, dn, pn = _models(23, dtype)
+            dn.deterministic = pn.deterministic = True
+            outs = []
+            for _ in range(12):
+                dn.zero_grad(); pn.zero_grad()
+                hnn.dcdp_forward(dn, pn, None, None, d["K"], frames=frames)[0].backward()
+                dn.join_side(); pn.join_side()
+                outs.append((dn.flat_grad.clone(), pn.flat_grad.clone()))
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            _lib.tune_set("fork_stop_event", 1)
+            _lib.tune_set("wgrad_short_walk", 32)
+
+    a, b, c = run(1, 32), run(0, 32), run(1, 0)
+    for (ga, pa), (gb, pb), (gc, pc) in zip(a, b, c):
+        assert torch.equal(ga, gb) and torch.equal(pa, pb)
+        assert torch.equal(ga, a[0][0]) and torch.equal(pa, a[0][1])                     # and the same from pass to pass
+        # (another grid = another split of the pixel ranges = another summation order: round-off, not bits)
+        assert (ga - gc).abs().max().item() <= 1e-4 * ga.abs().max().item()
