@@ -21,7 +21,8 @@ namespace tune {
 // name, default, what it decides
 #define COLVO_TUNE_TABLE(X)                                                                                                        \
     /* ---- forward / input-gradient kernels (conv.hip): grids are counted in 256-thread workgroups ---- */                        \
-    X(bn64_min_wgs, 1024, "64-wide output-channel tiles only when that grid still has this many workgroups, else 32-wide")         \
+    X(bn64_min_wgs, 4096, "64-wide output-channel tiles only when that grid still has this many workgroups, else 32-wide "           \
+                          "(round 4, in the step: 1024 -> 4096 -0.8 % at 32 pairs, level at 8 and 64)")                              \
     X(bn32_min_wgs, 0, "32-wide tiles only above this many workgroups, else 16-wide (0: measured neutral)")                        \
     X(lone_max_wgs, 1024, "grids up to this size take the two-chunk register ring (~1 workgroup per CU, one wave per SIMD)")       \
     X(depth2_min_chunks, 8, "... if the layer has at least this many 32-channel chunks")                                           \
@@ -47,7 +48,8 @@ namespace tune {
     /* ---- weight gradient (wgrad.hip) ---- */                                                                                     \
     X(wgrad_up2, 1, "weight gradient of up-sampled layers in the four-class form (16 instead of 36 products, k_wgrad_up2)")          \
     X(wgrad_mt_max, 2, "output-channel tile = 16 x this (32-wide measured better than 64 on every layer at 16 images)")             \
-    X(wgrad_mt4_min_walk, 24, "... but 64-wide from this many pixel tiles per workgroup (at a 256-workgroup grid) on")              \
+    X(wgrad_mt4_min_walk, 16, "... but 64-wide from this many pixel tiles per workgroup (at a 256-workgroup grid) on "              \
+                               "(24 -> 16 in the step: -0.4 % at 32 pairs, level elsewhere)")                                        \
     X(wgrad_ng_max, 4, "16-byte channel granules per chunk")                                                                        \
     X(wgrad_one_chunk_rule, 1, "16-wide tiles where the input is a single chunk (enc1a/enc1b/enc2a 27/31/26 -> 20/24/24 us)")       \
     X(wgrad_atomic_mb, 3, "cap on the fp32 atomic traffic of a launch, MB (12 MB 592 us, 6 MB 575, 3 MB 566 over the stack)")       \

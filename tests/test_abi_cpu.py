@@ -126,7 +126,7 @@ def test_tuning_table_hooks_and_no_stray_getenv(lib):
     """One table of dispatch thresholds (csrc/tuning.h): entries can be read / set by name, unknown names fail loudly, and no
     kernel source reads an environment variable of its own (the developer-build ablation switches excepted)."""
     from coivo_amd import _lib
-    assert _lib.tune_get("bn64_min_wgs") == 1024 and _lib.tune_get("wgrad_atomic_mb") == 3
+    assert _lib.tune_get("bn64_min_wgs") == 4096 and _lib.tune_get("wgrad_atomic_mb") == 3
     _lib.tune_set("quad_min_wgs", 7)
     assert _lib.tune_get("quad_min_wgs") == 7
     _lib.tune_set("quad_min_wgs", 2048)
