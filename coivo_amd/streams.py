@@ -2,10 +2,12 @@
 `colvo_run_commands` may use, from who else drives hardware queues in this process.
 
 Why a policy at all (measured on MI355X, ROCm 7.2): the step runs its input-gradient chain
-on the caller's stream and the weight gradients on one or two side streams.  With FOUR or more hardware queues active and
-cross-queue dependencies between them the runtime serialises the backward pass (1.5 ms -> 4-5 ms per step).  The budget is
-therefore three active queues: main + side + ONE more -- the library's auxiliary side stream when nobody else needs it, or an
-external party's stream: RCCL's communicator stream (ddp.GradBuckets), a loader's copy stream (data.PairLoader).
+on the caller's stream and the weight gradients on one or two side streams.  Beyond a small number of ACTIVE hardware queues
+with cross-queue dependencies between them the runtime serialises the backward pass (1.3 ms -> 3.5-5 ms per step).  Rounds 2-3 took
+that number to be three; round 4 measured it: FOUR queues are served at a time -- main + one side stream per network (two) + the
+library's auxiliary stream is already four, which is why an external party's stream (RCCL's communicator stream, ddp.GradBuckets; a
+loader's copy stream, data.PairLoader) has to displace the auxiliary stream -- unless the networks share ONE side stream
+(nn.share_side_stream, what GradBuckets arranges), which leaves room for one external queue beside it (_free_claims below).
 
     claim = streams.claim_external_queue("rccl")   # the auxiliary stream is switched off while any claim is held
     ...
