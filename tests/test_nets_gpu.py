@@ -466,3 +466,41 @@ def test_forks_on_completion_signals_order_the_weight_gradients_like_recorded_ev
         assert torch.equal(ga, a[0][0]) and torch.equal(pa, a[0][1])                     # and the same from pass to pass
         # (another grid = another split of the pixel ranges = another summation order: round-off, not bits)
         assert (ga - gc).abs().max().item() <= 1e-4 * ga.abs().max().item()
+
+
+def test_networks_on_one_shared_side_stream_compute_the_same_step():
+    """nn.share_side_stream (what ddp.GradBuckets arranges so that RCCL's queue fits beside the auxiliary stream): both networks'
+    weight gradients on ONE side stream.  Deterministic mode: bit-identical gradients and parameters over three steps, also when the
+    streams are merged AFTER the networks have run with streams of their own; the stream policy then tolerates one external claim."""
+    from coivo_amd import nn as hnn, streams
+    from coivo_amd.optim import FusedAdam
+    d = to_dev(synth.make_batch(2, 64, 96, seed=29))
+    frames = torch.cat([d["tgt"], d["ref"]])
+
+    def run(share_at):
+        _, _, dn, pn = _models(29, torch.bfloat16)
+        dn.deterministic = pn.deterministic = True
+        opt = FusedAdam([dn, pn], lr=1e-3)
+        out = []
+        for it in range(3):
+            if it == share_at:
+                shared = hnn.share_side_stream([dn, pn])
+                assert shared is not None and dn._side is shared and pn._side is shared
+                claim = streams.claim_external_queue("test")
+                assert streams.aux_side_streams() > 0              # one external queue fits beside the auxiliary stream now
+                claim.release()
+            opt.zero_grad()
+            hnn.dcdp_forward(dn, pn, None, None, d["K"], frames=frames)[0].backward()
+            dn.join_side(); pn.join_side()
+            out.append((dn.flat_grad.clone(), pn.flat_grad.clone()))
+            opt.step()
+        torch.cuda.synchronize()
+        streams.reset()
+        return out, dn.flat_param.clone(), pn.flat_param.clone(), (dn, pn)
+
+    a, b, c = run(-1), run(0), run(1)
+    assert a[3][0]._side is not a[3][1]._side                       # the default: a side stream per network
+    for other in (b, c):
+        for (g0, p0), (g1, p1) in zip(a[0], other[0]):
+            assert torch.equal(g0, g1) and torch.equal(p0, p1)
+        assert torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
