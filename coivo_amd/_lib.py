@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -122,6 +122,7 @@ SIGNATURES = {
     "colvo_set_capture_policy": (_i, [_i, _i]),
     "colvo_set_capture_carry": (_i, [_i]),
     "colvo_capture_join": (_i, [_vp]),
+    "colvo_capture_reset": (_i, [_vp]),
     "colvo_graph_stats": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
     "colvo_graph_stats_reset": (_i, []),
     "colvo_tune_set": (_i, [C.c_char_p, C.c_double]),

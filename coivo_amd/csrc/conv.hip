@@ -35,6 +35,7 @@
 //     read with ds_read_b64_tr_b16 (hardware transpose), f32 fragments with plain ds_read_b32.
 #define COLVO_ACC_CONSTRAINT "+v"     // built with -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py)
 #include "conv_common.h"
+#include "conv_stage.h"
 
 namespace colvo {
 namespace {
@@ -151,15 +152,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut,
 // i.e. 8 / 16 contiguous bytes of the NHWC output -- the epilogue stores straight from the accumulators (bias, ReLU,
 // mask, accumulate per lane; buffer stores drop out-of-range lanes), with no LDS transposition and no index division.
 // Only pool2 (input gradient of an up-sampled source) still goes through the fp32 tile in LDS.
-template <typename T> struct EV;
-template <> struct EV<float> { typedef u32x4 type; };
-template <> struct EV<bf16_t> { typedef u32x2 type; };
-template <typename T>
-__device__ __forceinline__ typename EV<T>::type epi_load(__amdgpu_buffer_rsrc_t r, int off, int soff) {
-    if constexpr (TT<T>::ES == 4) return bld16(r, off, soff);
-    else return __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
-}
-
 // Direct epilogue in three steps so that a caller can issue the mask / accumulate loads early (persistent kernel:
 // before the tile's MFMAs): (1) byte offsets of the lane's two pixels, (2) loads, (3) arithmetic + stores.
 // rout / rmask: descriptors whose base + soff (wave-uniform) is pixel (0, 0) of the output image of this tile.
@@ -613,113 +605,6 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 4 : ((BN <= 32 && DEPTH == 1 && !
     __syncthreads();
     conv_epilogue<T, BN, NTH>(a, sOut, b, oy0, ox0, n0, tid);
 }
-
-// --------------------------------------------------------------------------------------------- //
-// staging helpers shared by the fat-workgroup kernels below (k_dgrad_s2, k_conv_up2, k_dgrad_up2, k_conv_q)  //
-// --------------------------------------------------------------------------------------------- //
-// logical workgroup id (1-D grid, XCD-contiguous) -> image, tile row / column, first output channel; channel tile fastest
-struct TileCoord { int b, ty, tx, n0; };
-template <int BN>
-__device__ __forceinline__ TileCoord tile_coord(const ConvK& a) {
-    const int lid = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x, a.xcd));
-    const int tlin = lid / a.ntn;
-    const int tpi = a.tiles_x * a.tiles_y;
-    TileCoord c;
-    c.n0 = (lid - tlin * a.ntn) * BN;
-    c.b = tlin / tpi;
-    const int trem = tlin - c.b * tpi;
-    c.ty = trem / a.tiles_x;
-    c.tx = trem - c.ty * a.tiles_x;
-    return c;
-}
-
-// The [BN][9][CK] weight slab of one channel chunk: global -> registers -> LDS, exactly as in k_conv3x3 (one per-thread offset
-// plus a scalar stride per staged granule; rows beyond N fall outside the descriptor and read as zero).
-template <typename T, int BN, int NG>
-struct SlabStage {
-    static constexpr int G = TT<T>::G, ES = TT<T>::ES;
-    static constexpr int CK = NG * G, NGR = 9 * NG, STEPS = (NGR + 3) / 4;
-    static constexpr int WROW = wrow_bytes(STEPS * 4);
-    static constexpr int WTOT = BN * NGR, WIT = (WTOT + NT - 1) / NT;
-    int woff0, woffL, tapB;
-    int wlds[WIT];
-    __amdgpu_buffer_rsrc_t rw;
-
-    __device__ __forceinline__ void init(const ConvK& a, int n0, int tid) {
-        tapB = a.Ctot * ES;
-        const int n = tid / NGR, gi = tid - n * NGR;
-        const int tap = gi / NG, cg = gi - tap * NG;
-        woff0 = ((n0 + n) * 9 + tap) * tapB + cg * 16;
-        woffL = ((WIT - 1) * NT + tid < WTOT) ? woff0 : OOB_OFF;
-        rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * 9 * a.Ctot * ES, 0x00020000);
-    }
-    // (kept apart from init(): the kernels issue their first loads before they compute what only the LDS side needs)
-    __device__ __forceinline__ void lds_offsets(int tid) {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = it * NT + tid;
-            const int n = i / NGR;
-            wlds[it] = i * 16 + n * (WROW - NGR * 16);
-        }
-    }
-    __device__ __forceinline__ void load(int k, int dead, u32x4 (&w)[WIT]) const {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            w[it] = bld16(rw, (((it == WIT - 1) ? woffL : woff0) + it * (NT / NG) * tapB) | dead, so);
-    }
-    __device__ __forceinline__ void store(char* sW, int tid, const u32x4 (&w)[WIT]) const {
-#pragma unroll
-        for (int it = 0; it < WIT; ++it)
-            if (WTOT % NT == 0 || it < WIT - 1 || it * NT + tid < WTOT) st16(sW + wlds[it], w[it]);
-    }
-    __device__ __forceinline__ void zero_padding(char* sW, int tid) const {      // weight rows of 9 * NG granules, padded to 4 * STEPS
-        if constexpr (STEPS * 4 != NGR) {
-            for (int i = tid; i < BN * (STEPS * 4 - NGR); i += NT) {
-                const int n = i / (STEPS * 4 - NGR), q = i - n * (STEPS * 4 - NGR);
-                st16(sW + n * WROW + (NGR + q) * 16, u32x4{0u, 0u, 0u, 0u});
-            }
-        }
-    }
-};
-
-// The input patch of one chunk from ONE directly stored source: patch pixel (py, px) = source pixel (y_org + py * 1, x_org + px),
-// zero outside the source; LDS rows at the padded pitch a.pwp.
-template <typename T, int NG, int PPF, bool S2 = false>      // S2: fragment rows two patch pixels apart (conv_common.h pitch_bytes_s2)
-struct PatchStage {
-    static constexpr int G = TT<T>::G, ES = TT<T>::ES, CK = NG * G;
-    static constexpr int PIXP = S2 ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
-    int poff[PPF], plds[PPF];
-    int ptotal;
-    __amdgpu_buffer_rsrc_t rimg;
-
-    __device__ __forceinline__ void init(const ConvK& a, int b, int tid, int PH, int PW, int y_org, int x_org) {
-        const int Hs = a.g.Hs[0], Ws = a.g.Ws[0], Cs = a.g.C[0];
-        rimg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g.src[0] + (size_t)b * Hs * Ws * Cs * ES), 0, Hs * Ws * Cs * ES,
-                                                 0x00020000);
-        ptotal = PH * PW * NG;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            const int i = it * NT + tid;
-            const int pix = i / NG, cg = i - pix * NG;
-            const int py = mdiv(pix, a.m_pw), px = pix - py * PW;
-            const int vy = y_org + py, vx = x_org + px;
-            const bool inb = (i < ptotal) && ((unsigned)vy < (unsigned)Hs) && ((unsigned)vx < (unsigned)Ws);
-            poff[it] = inb ? ((vy * Ws + vx) * Cs + cg * G) * ES : OOB_OFF;
-            plds[it] = (py * a.pwp + px) * PIXP + cg * 16;
-        }
-    }
-    __device__ __forceinline__ void load(int k, int dead, u32x4 (&pv)[PPF]) const {
-        const int so = dead ? 0 : k * CK * ES;
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) pv[it] = bld16(rimg, poff[it] | dead, so);
-    }
-    __device__ __forceinline__ void store(char* sP, int tid, const u32x4 (&pv)[PPF]) const {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it)
-            if (it * NT + tid < ptotal) st16(sP + plds[it], pv[it]);
-    }
-};
 
 // --------------------------------------------------------------------------------------------- //
 // input gradient of a STRIDE-2 conv, parity-decomposed                                           //
@@ -1876,8 +1761,11 @@ extern "C" int colvo_conv_fwd(const ColvoConvDesc* d, const void* x0, const void
         }
     }
     {
-        const int r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
-                                            : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
+        // large grids of ordinary stride-1 layers: the register-tiled kernel (conv_rt.hip), then the quad-tile kernel
+        int r = try_launch_conv_rt(k, d->B, d->dtype, (hipStream_t)stream);
+        if (r >= 0) return r;
+        r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
+                                  : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
         if (r >= 0) return r;
     }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
@@ -1962,8 +1850,10 @@ extern "C" int colvo_conv_dgrad(const ColvoConvDesc* d, int src, const void* dy,
     k.bias = nullptr; k.relu = 0; k.out = (char*)dx; k.mask = (const char*)relu_mask;
     k.accumulate = accumulate; k.pool2 = up;
     if (d->stride == 1 && !up) {
-        const int r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
-                                            : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
+        int r = try_launch_conv_rt(k, d->B, d->dtype, (hipStream_t)stream);
+        if (r >= 0) return r;
+        r = d->dtype == COLVO_F32 ? try_launch_conv_q<float>(k, d->B, (hipStream_t)stream)
+                                  : try_launch_conv_q<bf16_t>(k, d->B, (hipStream_t)stream);
         if (r >= 0) return r;
     }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, up != 0, (hipStream_t)stream)
@@ -1998,6 +1888,10 @@ extern "C" int colvo_conv_dgrad_both(const ColvoConvDesc* d, const void* dy, con
     k.bias = nullptr; k.relu = 0; k.accumulate = 0; k.pool2 = 0;
     k.out = (char*)dx0; k.mask = (const char*)relu_mask0;
     k.out2 = (char*)dx1; k.mask2 = (const char*)relu_mask1; k.nsplit = d->C0;
+    {
+        const int r = try_launch_conv_rt(k, d->B, d->dtype, (hipStream_t)stream);
+        if (r >= 0) return r;
+    }
     return d->dtype == COLVO_F32 ? launch_conv_t<float>(k, d->B, false, (hipStream_t)stream)
                                  : launch_conv_t<bf16_t>(k, d->B, false, (hipStream_t)stream);
 }

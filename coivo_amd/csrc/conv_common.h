@@ -14,6 +14,47 @@
 #include "tuning.h"
 
 namespace colvo {
+
+// (named namespace: the descriptor crosses translation units -- conv.hip dispatches to conv_rt.hip)
+enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
+
+struct Gather {               // how the (virtual) conv input is read from the stored sources
+    const char* src[2];
+    int C[2];
+    int Hs[2], Ws[2];
+    int mode[2];
+    int Hi, Wi;               // virtual input extent (zero outside)
+    int stride;
+};
+
+struct ConvK {
+    Gather g;
+    int Ho, Wo;               // conv output extent
+    const char* w;            // [N][9][Ctot]
+    int Ctot, N;
+    const float* bias;
+    int relu;
+    char* out;                // [B][Ho(/2)][Wo(/2)][N]
+    const char* mask;         // same shape as out or null
+    // input gradient w.r.t. BOTH sources of a concat layer in one launch (colvo_conv_dgrad_both): output channels >= nsplit
+    // (a multiple of the channel tile) belong to the second source and go to out2 / mask2 with N - nsplit channels per pixel
+    char* out2;
+    const char* mask2;
+    int nsplit;               // 0: single output
+    int accumulate, pool2;
+    int toh, tow, tiles_x, tiles_y;
+    int pwp;                  // LDS pitch of a patch row, in pixels (>= patch width: padded against bank conflicts, pick_tile)
+    uint32_t m_pw, m_tow;     // ceil(2^32 / patch width), ceil(2^32 / tow): index / d == umulhi(index, m) for index < 2^16
+    int ntn, xcd;             // one-tile kernel: output-channel tiles per pixel tile (1-D grid, n-tile fastest), XCD remap on/off
+#ifdef COLVO_ABLATE
+    int abl;                  // developer build only (tools/ablate_conv.sh): bit mask of kernel phases to skip
+    long long* trace;         // developer build only: [workgroup][8] wall-clock stamps (100 MHz) of the kernel phases
+#endif
+};
+
+// conv_rt.hip: register-tiled stride-1 kernel for large grids (forward and input gradient); -1: the layer does not qualify
+int try_launch_conv_rt(const ConvK& k, int B, int dtype, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -51,42 +92,6 @@ constexpr int pitch_bytes_s2(int payload) { return ((payload / 16) | 1) * 16; }
 // congruent to p modulo 8: a read group's 8 CONSECUTIVE tile pixels then keep their conflict-free spacing across a tile-row
 // boundary as well (tiles whose width is not a multiple of 8: the 16x20, 8x10, 4x5 ... maps).  Multiples of 8 need no padding.
 inline int wgrad_row_pitch(int pw, int tow) { return (tow % 8 == 0) ? pw : pw + (((tow - pw) % 8) + 8) % 8; }
-
-enum { MODE_DIRECT = 0, MODE_UP2 = 1, MODE_DILATE = 2 };
-
-struct Gather {               // how the (virtual) conv input is read from the stored sources
-    const char* src[2];
-    int C[2];
-    int Hs[2], Ws[2];
-    int mode[2];
-    int Hi, Wi;               // virtual input extent (zero outside)
-    int stride;
-};
-
-struct ConvK {
-    Gather g;
-    int Ho, Wo;               // conv output extent
-    const char* w;            // [N][9][Ctot]
-    int Ctot, N;
-    const float* bias;
-    int relu;
-    char* out;                // [B][Ho(/2)][Wo(/2)][N]
-    const char* mask;         // same shape as out or null
-    // input gradient w.r.t. BOTH sources of a concat layer in one launch (colvo_conv_dgrad_both): output channels >= nsplit
-    // (a multiple of the channel tile) belong to the second source and go to out2 / mask2 with N - nsplit channels per pixel
-    char* out2;
-    const char* mask2;
-    int nsplit;               // 0: single output
-    int accumulate, pool2;
-    int toh, tow, tiles_x, tiles_y;
-    int pwp;                  // LDS pitch of a patch row, in pixels (>= patch width: padded against bank conflicts, pick_tile)
-    uint32_t m_pw, m_tow;     // ceil(2^32 / patch width), ceil(2^32 / tow): index / d == umulhi(index, m) for index < 2^16
-    int ntn, xcd;             // one-tile kernel: output-channel tiles per pixel tile (1-D grid, n-tile fastest), XCD remap on/off
-#ifdef COLVO_ABLATE
-    int abl;                  // developer build only (tools/ablate_conv.sh): bit mask of kernel phases to skip
-    long long* trace;         // developer build only: [workgroup][8] wall-clock stamps (100 MHz) of the kernel phases
-#endif
-};
 
 #ifdef COLVO_ABLATE
 #define ABL(bit) ((a.abl & (bit)) != 0)

@@ -206,7 +206,7 @@ struct CaptureTail {
 // policy 1.  Keyed by the capture's id: a new capture starts empty whatever an aborted one left behind.  One capture at a time per
 // process (the step is captured by one thread); the mutex only keeps a stray concurrent call from corrupting the vectors.
 struct CaptureState {
-    unsigned long long id = 0;
+    unsigned long long id = ~0ull;          // (the runtime numbers its captures from 0: no capture has this id)
     CaptureTail sides[2], fork_at;
     int seg = 0;
     std::vector<ColvoCmd> pending;
@@ -344,6 +344,30 @@ extern "C" int colvo_capture_join(colvo_stream_t stream) {
     if (id != st.id) return 0;                  // nothing of this capture is open
     const int policy = g_capture_policy.load(std::memory_order_relaxed);
     return capture_join_all(st, policy, policy == 3 ? 2 : 1, ms);
+}
+
+extern "C" int colvo_capture_reset(colvo_stream_t stream) {
+    hipStream_t ms = (hipStream_t)stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ms && hipStreamIsCapturing(ms, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("colvo_capture_reset: the stream is being captured (end or abandon the capture first)");
+        return (int)hipErrorStreamCaptureUnsupported;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_cap_mu);
+        CaptureState& st = g_cap;
+        st.id = ~0ull;                       // no capture ever has this id: the next one starts empty whatever its id is
+        st.seg = 0;
+        st.pending.clear(); st.pending.shrink_to_fit();
+        st.fork_at.nodes.clear();
+        for (CaptureTail& sd : st.sides) sd.nodes.clear();
+    }
+    g_capture_policy.store(2, std::memory_order_relaxed);
+    g_capture_group.store(2, std::memory_order_relaxed);
+    g_capture_carry.store(0, std::memory_order_relaxed);
+    LaunchTap& tap = g_launch_tap;           // (a command that failed between arming and disarming cannot leave it armed, but
+    tap.stop = nullptr; tap.stream = nullptr; tap.used = 0;   //  "pre-capture state" should not depend on that argument)
+    return 0;
 }
 
 extern "C" int colvo_graph_stats_reset(void) {

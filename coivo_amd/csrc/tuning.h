@@ -42,6 +42,12 @@ namespace tune {
     X(quad_min_wgs, 8192, "... from this many quad-tile workgroups on (iconv2 at configs[2] size 370 -> 275 us; at 2560-5120 "      \
                           "workgroups of 256x320 frames it loses 3-6 % of the pass)")                                               \
     X(quad_max_chunks, 4, "... and at most this many chunks (deeper layers keep the two-chunk ring)")                               \
+    X(conv_rt, 1, "register-tiled stride-1 kernel (k_conv_rt, csrc/conv_rt.hip: 16x16 pixels x 64/32 channels, 4x4 fragments per wave)") \
+    X(rt_min_wgs, 512, "... from this many of its workgroups on (64 frames, us fwd / dgrad, one-tile -> this: enc2b 42.4 / 52.6 -> 35.6 / "  \
+                       "41.9, iconv3 65.9 / 52.3 -> 52.8 / 42.3, iconv4 61.8 / 43.6 -> 51.9 / 35.4, enc3b 36.6 / 43.4 -> 32.3 / 35.5, "   \
+                       "enc4b 37.2 / 42.1 -> 35.4 / 38.2; at 16 frames its 128-320-workgroup grids lose 0.5-1.8 us per layer)")          \
+    X(rt_min_fill_pct, 60, "... and only where the 16x16 tiling covers at most 100/this times the image (32x40 maps: 83 %, 16x20: 62 %)") \
+    X(rt_min_chunks, 2, "... and the layer has at least this many 32-channel chunks")                                                 \
     X(xcd_remap, 1, "XCD-contiguous 1-D grids (step +4.3 % without)")                                                               \
     X(lds_aware_tiles, 1, "tile shapes / padded LDS row pitch chosen against ds_read_b128 bank conflicts")                          \
     X(lds_tile_max_pad, 8, "... at most this many padding pixels per patch row")                                                    \

@@ -56,6 +56,7 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.stats = None                           # colvo_graph_stats of the captured graph (GRAPH_STAT_NAMES)
         self._warmup = warmup
+        self._spacers = []
 
     # one eager step on the static buffers
     def _step(self) -> torch.Tensor:
@@ -89,6 +90,8 @@ class GraphedTrainStep:
         from . import _lib
         lib = _lib.load()
         nets = (self.depth_net, self.pose_net)
+        for n in nets:
+            n._grads_clean = False                  # whatever an earlier step left: the captured step starts with its clearing launch
         self.opt.use_device_step_counter()          # a captured host-side step number would repeat at every replay
         snap_p = [n.flat_param.clone() for n in nets]
         snap_o = [{k: v.clone() for k, v in st.items()} for st in self.opt.state]
@@ -136,13 +139,53 @@ class GraphedTrainStep:
                 self.stats = dict(zip(GRAPH_STAT_NAMES, [int(v) for v in buf]))   # runtime refuses to list the graph's nodes)
                 if rc != 0:
                     self.stats["error"] = lib.colvo_last_error().decode("utf-8", "replace")
+        except BaseException:
+            # a failed capture leaves node handles of a graph that will never exist in the library's bookkeeping
+            lib.colvo_capture_reset(None)
+            raise
         finally:
             lib.colvo_set_capture_carry(0)
         if self.stats["pending_commands"]:
+            lib.colvo_capture_reset(None)
             raise RuntimeError("hipGraph capture ended with weight-gradient commands still held back (a join is missing)")
         self.graph = g
         restore()          # capture itself does not execute, but keep the state exactly as the caller left it
         torch.cuda.synchronize()
+
+    def close(self) -> None:
+        """Destroy the captured graph NOW, at a defined point, and return the library to its pre-capture state.
+
+        Without it the teardown happens whenever the last reference goes: torch's CUDAGraph destructor calls hipGraphExecDestroy /
+        hipGraphDestroy, gives the graph's private pool back and synchronises the device (ROCm >= 6.2 defers the release of a graph
+        exec's resources to the next synchronising call), the library keeps the dead graph's node handles and held-back command
+        copies until the next capture, and the networks -- which sit in reference cycles (recorded passes, autograd closures) --
+        keep their persistent buffers until a full garbage collection.  A process that re-captures (another batch size, another
+        policy; round 4's test run: eight captures in one process) then tears graphs down in the middle of unrelated work.  Here:
+        device idle, nothing capturing, graph exec and graph destroyed, pool released, library reset (colvo_capture_reset), the
+        capture-only scratch of the step dropped.  The step object can capture() again afterwards.  DESIGN.md section 3.4."""
+        import gc
+        from . import _lib
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("GraphedTrainStep.close() while a stream is being captured")
+        torch.cuda.synchronize()
+        g, self.graph = self.graph, None
+        if g is not None:
+            g.reset()                   # hipGraphExecDestroy + hipGraphDestroy + the private pool, while the device is idle
+            del g
+        self._spacers = []
+        self.stats = None
+        _lib.check(_lib.load().colvo_capture_reset(_lib.stream_ptr()), "colvo_capture_reset")
+        for n in (self.depth_net, self.pose_net):
+            n.join_side()
+        gc.collect()                    # cyclic garbage of earlier steps' networks goes now, not inside somebody else's capture
+        torch.cuda.synchronize()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __call__(self, frames: Optional[torch.Tensor] = None, K: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.graph is None:
@@ -153,7 +196,9 @@ class GraphedTrainStep:
             self.K.copy_(K, non_blocking=True)
         self._operands_current()
         self.graph.replay()
+        clean = bool(getattr(self.opt, "zero_grad_in_step", False)) and self.opt.writes_operand_copies()
         for n in (self.depth_net, self.pose_net):
+            n._grads_clean = clean           # the replayed update cleared the arenas (or did not): an eager zero_grad() may skip
             if self.opt.writes_operand_copies():
                 n.operands_written()         # the captured update left master weights AND operand copies current
             else:

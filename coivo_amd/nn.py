@@ -125,6 +125,7 @@ class _ArenaModule(nn.Module):
         # to finish before DepthNet's backward may start; its weight gradients then run beside DepthNet's kernels.
         self.defer_join = _lib.dev_env("COLVO_NO_DEFER_JOIN") is None
         self._join_pending = False
+        self._cap_side_open = False          # under hipGraph capture: a pass of this network left its side chain open (carry mode)
         self.grad_ready_hook: Optional[Callable[["_ArenaModule", int, int], None]] = None
         # deterministic: weight gradients through per-split slabs + fixed-order second launches instead of float atomics
         # (include/colvo.h colvo_conv_wgrad_det): bitwise repeatable steps at the price of ~one small launch per layer.  Read when a
@@ -377,6 +378,8 @@ class _ArenaModule(nn.Module):
                     pr.flush = None
             pr.run(self._side, done, None)
         if getattr(pr, "deferred_join", False):
+            if torch.cuda.is_current_stream_capturing():
+                self._cap_side_open = True
             self._queue_join()
         return out
 
@@ -480,9 +483,23 @@ class _ArenaModule(nn.Module):
         capture the side chain lives in the library (csrc/program.hip, carry mode): the next captured node is made to depend on it."""
         if torch.cuda.is_current_stream_capturing():
             _lib.check(_lib.load().colvo_capture_join(_lib.stream_ptr()), "colvo_capture_join")
+            self._cap_side_open = False
         elif self._join_pending and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._join_pending = False
+
+    def _order_deterministic_pass(self) -> None:
+        """Deterministic mode, a SECOND backward pass of this network while the first one's weight gradients may still be running on
+        the side streams (deferred join: one network applied twice inside one backward): the one-split write-out of
+        colvo_conv_wgrad_det adds to dw / db with a plain read-modify-write -- sole writer within a launch, not across two launches on
+        different streams -- so the earlier pass's side work is joined first.  The default (atomic) form needs no order."""
+        if not self.deterministic:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            if self._cap_side_open:          # (carry mode leaves this network's side chain open; policy 3 has two of them)
+                self.join_side()
+        elif self._join_pending:
+            self.join_side()
 
     def _layer_done(self, L: ConvParams) -> None:
         if self._rec is not None:
@@ -521,6 +538,7 @@ class _PassInst:
         self.busy = False
         self.passes: Dict[str, tuple] = {}
         self.saved = None
+        self.gen = 0             # bumped by every forward run on this instance: a hand-over of one of its buffers names the run
 
 
 class _Lease:
@@ -674,7 +692,9 @@ class DepthNet(_ArenaModule):
             return A
 
         A = self._run_pass(inst, "fwd", {"img": img, "depth": depth}, body)
-        self._pose_in = (A["pose_in"], img.data_ptr(), depth.data_ptr(), depth._version) if pose_fill else None
+        inst.gen += 1
+        # (the tag holds `img` itself: while the tag lives the frames' memory cannot be handed to another tensor)
+        self._pose_in = (A["pose_in"], img, depth.data_ptr(), depth._version, inst, inst.gen, img._version) if pose_fill else None
         return depth, (A, P, inst)
 
     def _backward_impl(self, saved, depth: torch.Tensor, d_depth: Optional[torch.Tensor], parts=None) -> None:
@@ -683,6 +703,7 @@ class DepthNet(_ArenaModule):
         A, P, inst = saved
         self._grads_clean = False
         self.attach_grads()
+        self._order_deterministic_pass()
         B, _, H, W = depth.shape
         dev = depth.device
         if parts is None:
@@ -869,11 +890,18 @@ class PoseNet(_ArenaModule):
         # and d_r are, untouched, the frames that pass read and the depths it wrote
         filled = getattr(d_t, "_colvo_pose_in", None) if has_depth else None
         if filled is not None:
-            buf, frames_ptr, depth_ptr, version = filled
+            # ... and the buffer still holds THAT pass: it belongs to DepthNet's pass instance, which a later forward re-uses as
+            # soon as this one's autograd context is gone (at once under no_grad) -- `gen` names the run that filled it -- and
+            # the frames have not been written in place since (d1 = forward_pair(f1); d2 = forward_pair(f2);
+            # pose_net(f1[:B], f1[B:], *d1) passed the address / depth-version checks with f2's rgb and d2's depth in the buffer)
+            buf, frames, depth_ptr, version, src_inst, gen, frames_version = filled
+            frames_ptr = frames.data_ptr()
             ok = (tuple(buf.shape) == (B, H, W, 8) and buf.dtype == dt and tgt.is_contiguous() and ref.is_contiguous()
                   and d_t.is_contiguous() and d_r.is_contiguous() and tgt.data_ptr() == frames_ptr
                   and ref.data_ptr() == frames_ptr + 12 * B * H * W and d_t.data_ptr() == depth_ptr
-                  and d_r.data_ptr() == depth_ptr + 4 * B * H * W and d_t._version == version and d_r._version == version)
+                  and d_r.data_ptr() == depth_ptr + 4 * B * H * W and d_t._version == version and d_r._version == version
+                  and src_inst.gen == gen and frames._version == frames_version and tgt._version == frames_version
+                  and ref._version == frames_version)
             filled = buf if ok else None
         if filled is not None:
             has_depth = "filled"
@@ -911,6 +939,7 @@ class PoseNet(_ArenaModule):
         A, P, (B, H, W), has_depth, inst, filled = saved
         self._grads_clean = False
         self.attach_grads()
+        self._order_deterministic_pass()
         dev = self.flat_param.device
         grads = {"d_pose": d_pose, "d_a": d_a, "d_b": d_b, "scale_a": scale_a, "scale_b": scale_b}
         grads = {k: v.contiguous() for k, v in grads.items() if v is not None}

@@ -106,9 +106,12 @@ class FusedAdam:
                    "colvo_adam_pack_step")
         # (with device-side step numbers only the first network's counter is advanced here; _sync_step_state() brings the
         # others in line when the state is read)
+        # (while the step is being CAPTURED nothing has run: the arenas are as dirty as they were -- a capture that fails, or one
+        # without warm-up steps, must not leave the flag set; graph.GraphedTrainStep sets it after a replay.  ADVICE r4)
+        clean = self.zero_grad_in_step and not torch.cuda.is_current_stream_capturing()
         for m in self.modules:
             m.operands_written()
-            m._grads_clean = self.zero_grad_in_step
+            m._grads_clean = clean
         return True
 
     def _pack_table(self):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 8
+#define COLVO_ABI_VERSION 9
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -492,6 +492,11 @@ int colvo_capture_join(colvo_stream_t stream);
 #define COLVO_GRAPH_STATS_N 16
 int colvo_graph_stats(colvo_stream_t stream, long long* out, int n);
 int colvo_graph_stats_reset(void);
+/* Return the library to its pre-capture state: what the last capture left in its bookkeeping (handles of graph nodes that die with
+ * the graph, copies of held-back commands, the fork point), capture policy / group / carry mode back to their defaults, the calling
+ * thread's launch tap disarmed.  Call it when a captured graph is destroyed or a capture failed (coivo_amd.graph.GraphedTrainStep.close);
+ * fails with hipErrorStreamCaptureUnsupported-style code and changes nothing while `stream` (may be NULL) is being captured. */
+int colvo_capture_reset(colvo_stream_t stream);
 
 /* Dispatch thresholds (coivo_amd/csrc/tuning.h: ONE table, defaults measured on MI355X; production reads no environment
  * variable).  Developer / test hooks: set or read an entry by name ("quad_min_wgs", "wgrad_atomic_mb", ...); with COLVO_DEV=1 in

@@ -164,3 +164,59 @@ def matched_grad_rows(seed, batch, dn, pn, out_path=None, weights_seed=None):
           f"{o64['flips']} in the fp64 oracle ({o64['flip_worst']:.2e})")
     hip = [("depth." + n, p.grad) for n, p in dn.named_parameters()] + [("pose." + n, p.grad) for n, p in pn.named_parameters()]
     return grad_parity_table(hip, o32["grads"], o64["grads"], out_path), o32, o64
+
+
+# ---------------------------------------------------------------------------------------------------------------------- #
+# bf16 mode against the oracle.                                                                        #
+# What the HIP networks do differently in bf16 mode: weights are rounded to bf16 (operand copies), every conv layer's output #
+# is STORED in bf16 (its accumulation is fp32), so is every layer's input gradient, and the packed network inputs; heads,    #
+# loss and weight-gradient accumulation stay fp32.  `oracle_step_bf16` evaluates the fp32 oracle on bf16-rounded weights --  #
+# the target -- and, with emulate=True, with exactly those roundings inserted: the distance between the two is the size of    #
+# the bf16 data path's own noise, measured in the same step on the same inputs, and the bar for the HIP gradients is a       #
+# multiple of it (no constant that has to be re-tuned per shape).                                                            #
+# ---------------------------------------------------------------------------------------------------------------------- #
+class _RoundBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def bf16_rounded_state(module):
+    return {k: v.to(torch.bfloat16).to(v.dtype) for k, v in module.state_dict().items()}
+
+
+def oracle_step_bf16(seed, batch, masks=None, emulate=False, weights_seed=None):
+    """The fp32 oracle's coupled step on bf16-ROUNDED weights; ReLU decisions forced to `masks` (hip_relu_masks) where given;
+    emulate: the bf16 storage points of the HIP networks inserted (see above).  -> dict(loss, d_t, d_r, grads [(name, tensor)])."""
+    from oracle import colvo_spec as S
+    dn, pn = S.make_models(seed if weights_seed is None else weights_seed)
+    dn.load_state_dict(bf16_rounded_state(dn))
+    pn.load_state_dict(bf16_rounded_state(pn))
+    for tag, net, first, fp32_layers in (("depth", dn, "enc1a", ("head",)), ("pose", pn, "conv1", ("pred",))):
+        for name, mod in net.named_children():
+            if name in fp32_layers:
+                continue
+            m = None if masks is None else masks.get(f"{tag}.{name}")
+
+            def hook(mod, inp, out, m=m):
+                if emulate:
+                    out = _RoundBf16.apply(out)           # (commutes with the ReLU behind it)
+                if m is None:
+                    return out
+                flip = (out > 0) != m
+                if not bool(flip.any()):
+                    return out
+                o = out.detach()
+                delta = torch.where(o == 0, torch.where(m, torch.full_like(o, 1e-30), torch.full_like(o, -1e-30)), -2 * o)
+                return out + torch.where(flip, delta, torch.zeros_like(o))
+            mod.register_forward_hook(hook)
+            if emulate and name == first:
+                mod.register_forward_pre_hook(lambda mod, inp: (_RoundBf16.apply(inp[0]),))
+    loss, d_t, d_r, pose, a, b = S.dcdp_forward(dn, pn, batch["tgt"], batch["ref"], batch["K"])
+    loss.backward()
+    grads = [("depth." + n, p.grad) for n, p in dn.named_parameters()] + [("pose." + n, p.grad) for n, p in pn.named_parameters()]
+    return dict(loss=loss.item(), d_t=d_t.detach(), d_r=d_r.detach(), pose=pose.detach(), grads=grads)

@@ -1,9 +1,11 @@
-"""Child-process bodies of tests/test_graph_gpu.py: ONE hipGraph capture per process.
+"""Child-process bodies of tests/test_graph_gpu.py.
    python tests/graph_cases.py <case> [args...]      -> prints GRAPH_CASE_OK <case> on success
 
-The HIP runtime has ended the session process with a silent abort() twice in round 4 while -- or right after -- a process had
-captured several graphs (gpurun_out/r4d/t_conv.log: inside hipStreamEndCapture; gpurun_out/r4w/t.log: in the first host-to-device copy
-after eight captures); a process that captures once has never been seen to.  Test infrastructure, not product code."""
+Each case runs in a process of its own so that a failed capture (the runtime ends some of them with abort(): round 4,
+gpurun_out/r4d/t_conv.log -- the process group's watchdog polling events under a global-mode capture) fails ONE test with its
+output attached instead of taking the session down.  A child that aborts FAILS its test (round 4 re-ran it once; removed).
+case_eight_captures_in_one_process is the multi-capture regime itself: capture, replay, close(), eight times, then a host-to-device
+copy and an eager step (round 4's second abort, gpurun_out/r4w/t.log).  Test infrastructure, not product code."""
 import os
 import sys
 
@@ -153,6 +155,63 @@ def case_explicit_dependencies(policy):
         assert st["calls_with_carried_commands"] >= 1, st                           # PoseNet's tail rides into DepthNet's backward
         assert st["leaves"] == 1, st
     assert dn._side is None or not torch.cuda.is_current_stream_capturing()
+
+
+def case_eight_captures_in_one_process():
+    """Eight GraphedTrainStep captures one after the other in ONE process (the four policies x two dtypes of
+    test_graphed_step_matches_eager, as round 4's session process ran them), each replayed against an eager twin and closed
+    (GraphedTrainStep.close: graph exec destroyed at a defined point, library back in its pre-capture state); then what aborted in
+    round 4: a pageable host-to-device copy, and an eager step of networks that were captured before.  Also: a step object captures
+    again after close(), and colvo_capture_reset refuses to run under capture."""
+    from coivo_amd import _lib
+    from coivo_amd import nn as hnn
+    from coivo_amd.graph import GraphedTrainStep
+    B, H, W, seed = 2, 64, 96, 61
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+    frames = torch.cat([b["tgt"], b["ref"]])
+    last = None
+    for dtype in (torch.float32, torch.bfloat16):
+        for policy in (0, 1, 2, 3):
+            dn1, pn1, opt1 = _setup(seed, dtype)
+            dn2, pn2, opt2 = _setup(seed, dtype)
+            with GraphedTrainStep(dn2, pn2, opt2, B, H, W, capture_policy=policy, capture_group=5) as step:
+                for it in range(2):
+                    opt1.zero_grad()
+                    loss = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"])[0]
+                    loss.backward()
+                    opt1.step()
+                    g = step(frames, b["K"]).item()
+                    tol = (2e-6 if dtype == torch.float32 else 2e-4) * (1 if it == 0 else 50)
+                    assert abs(loss.item() - g) < 1e-7 + tol, (dtype, policy, it, loss.item(), g)
+                assert step.graph is not None
+            assert step.graph is None and step.stats is None
+            assert _lib.tune_get("xcd_remap") == 1          # (the library is alive and answers)
+            last = (dn2, pn2, opt2, step)
+    # round 4's abort: the first host-to-device copy after the eighth capture
+    b2 = to_dev(synth.make_batch(B, H, W, seed=seed + 1))
+    torch.cuda.synchronize()
+    # an eager step of networks whose step was captured (and closed) before
+    dn2, pn2, opt2, step = last
+    opt2.zero_grad()
+    l_e = hnn.dcdp_forward(dn2, pn2, b2["tgt"], b2["ref"], b2["K"])[0]
+    l_e.backward()
+    opt2.step()
+    assert 0 < l_e.item() < 1
+    # the closed step object captures again (a ninth capture) and replays
+    l_g = step(torch.cat([b2["tgt"], b2["ref"]]), b2["K"]).item()
+    assert 0 < l_g < 1 and step.graph is not None
+    # the reset entry point refuses to run under capture and leaves the capture intact
+    lib = _lib.load()
+    g = torch.cuda.CUDAGraph()
+    buf = torch.zeros(8, device=b2["K"].device)
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        assert lib.colvo_capture_reset(_lib.stream_ptr()) != 0 and b"being captured" in lib.colvo_last_error()
+        buf += 1
+    g.replay()
+    torch.cuda.synchronize()
+    assert buf[0].item() == 1.0
+    step.close()
+    assert lib.colvo_capture_reset(_lib.stream_ptr()) == 0
 
 
 if __name__ == "__main__":

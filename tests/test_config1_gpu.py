@@ -74,9 +74,14 @@ def test_config1_bf16_depth_l1_and_loss(oracle_step):
     o32 = o["f32"]
     l1 = 0.5 * ((d_t.detach().cpu() - o32["d_t"]).abs().mean().item() + (d_r.detach().cpu() - o32["d_r"]).abs().mean().item())
     rel = l1 / o32["d_t"].abs().mean().item()
-    print(f"configs[1] bf16: depth L1 vs ref {l1:.3e} (relative {rel:.3e}), loss {loss.item():.6f} vs {o32['loss']:.6f}")
-    assert rel < 1e-2
-    assert abs(loss.item() - o32["loss"]) < 2e-3
+    line = f"configs[1] bf16: depth L1 vs ref {l1:.3e} (relative {rel:.3e}), loss {loss.item():.6f} vs {o32['loss']:.6f}"
+    print(line)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        with open(os.path.join(ROOT, "gpurun_out", "config1_bf16.txt"), "w") as f:
+            f.write(line + "\n")
+    # about 3 x what the bench line reports for this batch ('depth_l1_vs_oracle': mean_rel 1.1e-3 in rounds 3-4); round 4 allowed 1e-2
+    assert rel < 3.5e-3
+    assert abs(loss.item() - o32["loss"]) < 1e-3
     og = dict(o32["grads"])
     for net, tag, names in ((dn, "depth.", ("enc3b.weight", "iconv3.weight", "up1.weight", "head.weight")),
                             (pn, "pose.", ("conv2.weight", "conv6.weight"))):

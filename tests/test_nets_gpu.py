@@ -385,9 +385,29 @@ def test_pose_input_filled_by_depthnet_gives_the_same_step_bitwise(monkeypatch):
         swapped = pn(b["ref"], b["tgt"], d_t2.clone(), d_r2.clone())[0]
         d_t3, d_r3 = dn.forward_pair(frames)
         got = pn(frames[:B], frames[B:], d_t3, d_r3)[0]
+        # two pair passes under no_grad share ONE pass instance (the first one's lease ends with its context), so the
+        # buffer d1 was tagged with holds the SECOND pass's frames and depths by the time PoseNet sees d1 -- addresses and
+        # depth versions still match.  The hand-over names the run that filled the buffer: PoseNet must pack for itself here.
+        b2 = to_dev(synth.make_batch(B, H, W, seed=seed + 5))
+        frames2 = torch.cat([b2["tgt"], b2["ref"]], dim=0)
+        d1 = dn.forward_pair(frames)
+        d1 = (d1[0], d1[1])
+        keep = (d1[0].clone(), d1[1].clone())
+        d2 = dn.forward_pair(frames2)
+        stale = pn(frames[:B], frames[B:], *d1)[0]
+        fresh = pn(b["tgt"], b["ref"], *keep)[0]                    # (packs for itself from the same values)
+        # ... and frames changed in place between the pair pass and PoseNet: the buffer holds the OLD rgb, PoseNet must not take it
+        frames3 = frames.clone()
+        d3 = dn.forward_pair(frames3)
+        frames3.mul_(0.5)
+        inplace = pn(frames3[:B], frames3[B:], *d3)[0]
+        inplace_ref = pn(frames3[:B].clone(), frames3[B:].clone(), d3[0].clone(), d3[1].clone())[0]
     torch.cuda.synchronize()
     assert torch.equal(got_other, swapped)
     assert torch.equal(got, want)
+    assert not torch.equal(d2[0], keep[0])
+    assert torch.equal(stale, fresh), "PoseNet read a pose_in buffer that a later DepthNet pass had refilled"
+    assert torch.equal(inplace, inplace_ref), "PoseNet read a pose_in buffer filled before the frames were changed in place"
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

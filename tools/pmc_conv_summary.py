@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/pmc_conv_<tag>/ (tools/pmc_conv.sh) into profiles/<tag>_conv_pmc.json: per conv kernel dispatch
 shape (kernel name x grid), the mean counter values, duration, and the ratios that say what bounds the kernel.
-   tools/pmc_conv_summary.py <tag>"""
+   tools/pmc_conv_summary.py <tag> [frames] [out.json]"""
 import collections
 import csv
 import glob
@@ -10,6 +10,8 @@ import os
 import sys
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r2"
+FRAMES = sys.argv[2] if len(sys.argv) > 2 else "16"
+OUTNAME = sys.argv[3] if len(sys.argv) > 3 else f"profiles/{TAG}_conv_pmc.json"
 SRC = f"gpurun_out/pmc_conv_{TAG}"
 
 
@@ -71,9 +73,9 @@ for (name, grid, lds), c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("d
     out.append(d)
 
 os.makedirs("profiles", exist_ok=True)
-json.dump({"source": f"rocprofv3 --kernel-trace --pmc <group> -- python3 tools/bench_conv.py 16 bf16 (tools/pmc_conv.sh {TAG}); "
+json.dump({"source": f"rocprofv3 --kernel-trace --pmc <group> -- python3 tools/bench_conv.py {FRAMES} bf16 (tools/pmc_conv.sh {TAG} {FRAMES}); "
                      "one pass per counter group; durations from the sq1 pass (profiled: slower than un-profiled runs)",
-           "kernels": out}, open(f"profiles/{TAG}_conv_pmc.json", "w"), indent=1)
+           "kernels": out}, open(OUTNAME, "w"), indent=1)
 for d in out[:40]:
     w = d.get("wave_cycles_share", {})
     print(f"{d['kernel'][:52]:52s} grid {d['grid_threads']:7d} {d['duration_us']:7.1f} us  wait {w.get('wait_any(waitcnt/barrier)', 0):.2f} "
