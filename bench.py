@@ -29,6 +29,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--rccl-single" in sys.argv:
     # initialisation, so it has to be in the environment before torch is imported.  A value the user exported is left alone
     # (coivo_amd.streams warns about 3..7); the effective value is reported in the JSON line (`hw_queues`).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # a captured step (configs[4]) holds RCCL collectives: fresh events for every eager collective instead of recycled ones that
+    # may carry a captured mark (coivo_amd/graph.py _check_process_group_environment); read when the process group is created
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 import torch
 
@@ -70,6 +73,9 @@ def parse():
                     help="train on the widened objective (SURVEY.md 8f-1/2: 3-scale photometric + geometric consistency + "
                          "smoothness) instead of BASELINE's plain DCDP+LCC step; reported as such in config.workload")
     ap.add_argument("--bucket-mb", type=int, default=16)
+    ap.add_argument("--per-rank-loss", action="store_true",
+                    help="developer A/B: data parallel with the mean of the per-rank masked means (rounds 1-4) instead of the spec's "
+                         "ONE masked mean over the whole batch (one all-reduce of two floats behind the loss kernel, coivo_amd/ddp.py)")
     ap.add_argument("--grad-transport", choices=["f32", "bf16"], default=None, help="override the configuration's transport dtype")
     ap.add_argument("--spec-calls", action="store_true",
                     help="time the step written as the spec's verbatim call sequence (INTEGRATION.md section 1, first snippet: "
@@ -405,7 +411,8 @@ def main():
     ddp = None
     if world > 1 or args.rccl_single:
         ddp = GradBuckets([dn, pn], bucket_bytes=args.bucket_mb << 20,
-                          transport_dtype=torch.bfloat16 if args.grad_transport == "bf16" else None)
+                          transport_dtype=torch.bfloat16 if args.grad_transport == "bf16" else None,
+                          exact_batch_loss=not args.per_rank_loss)
         opt.grad_scale = ddp.grad_scale
     batch = synth.make_batch(B, H, W, seed=1234 + rank, device=dev)
     frames = torch.cat([batch["tgt"], batch["ref"]], dim=0)      # one resident buffer: target frames, then reference
@@ -599,6 +606,30 @@ def main():
                                                  "exchange (rank 0's GPU, 20 steps): the denominator of the scaling ratio"}
         opt.grad_scale = scale_was
         ddp.resume()
+        # where in the step the bucket collectives go out: one extra traced step behind two lead-in steps
+        for _ in range(2):
+            fast_step(False)
+        ddp.trace_buckets(True)
+        e_start, e_bwd, e_done = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e_start.record()
+        opt.zero_grad()
+        d_t_, d_r_, d_l_ = dn.forward_pair_split(frames)
+        pose_, a_, b_ = pn(tgt, ref, d_t_, d_r_)
+        loss_ = Fh.photometric_loss(tgt, ref, d_l_, pose_, K, a_, b_)
+        loss_.backward(gradient=one)
+        e_bwd.record()
+        ddp.finish()
+        opt.step()
+        e_done.record()
+        torch.cuda.synchronize()
+        side["bucket_trace"] = {"buckets": ddp.bucket_trace(e_start), "backward_done_ms": round(e_start.elapsed_time(e_bwd), 4),
+                                "step_done_ms": round(e_start.elapsed_time(e_done), 4),
+                                "what": "one traced step: hip-event offset (ms after the step's first launch, on the issuing stream) of "
+                                        "every gradient bucket's all-reduce, in launch order; backward_done_ms = the main stream behind "
+                                        "the backward pass, step_done_ms = behind finish() + the optimizer.  Buckets issued well before "
+                                        "backward_done_ms overlap the rest of the backward pass; the time between backward_done_ms and "
+                                        "step_done_ms minus the optimizer's (~0.07 ms) is the exposed tail of the exchange"}
+        ddp.trace_buckets(False)
     if world == 1 and not use_graph and not args.no_side_measurements and ddp is None:
         # The three forms of the step -- fast path (forward_pair_split + gradient handover), the spec's verbatim call sequence, the
         # widened objective -- INTERLEAVED A-B-C-A-B-C in blocks after a common warm-up, hip-event medians per form: their order is
@@ -689,6 +720,8 @@ def main():
                           "global_batch": world * B, "height": H, "width": W,
                           "parallelism": f"dp{world}" + (" (one rank through the RCCL path)" if args.rccl_single else ""),
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
+                          "batch_loss": (None if ddp is None else "one masked mean over the global batch (valid-pixel count all-reduced)"
+                                         if ddp.exact_batch_loss else "mean of the per-rank masked means"),
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},
                "timing": "value / ms_per_step: wall clock around EXACTLY `steps` steps between barrier + torch.cuda.synchronize() on both "

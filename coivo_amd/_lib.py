@@ -61,6 +61,7 @@ SIGNATURES = {
     "colvo_warp_loss_fused": (_i, [_vp] * 7 + [_i, _i, _i, _f] + [_vp] * 6),
     "colvo_warp_loss_fused_bwd": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
     "colvo_warp_loss_fused_bwd_params": (_i, [_vp] * 4 + [_i] + [_vp] * 4),
+    "colvo_warp_loss_rescale": (_i, [_vp, _i, _vp]),
     "colvo_inverse_warp": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 3),
     "colvo_geo_loss_workspace_floats": (_sz, [_i, _i, _i]),
     "colvo_geo_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _i] + [_vp] * 3),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "colvo_depth_head_wgrad_mfma_rows": (_i, [_i, _i, _i]),
     "colvo_depth_head_wgrad_mfma": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "colvo_conv_wgrad": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6),
+    "colvo_conv_wgrad_clean": (_i, [_vp] * 6 + [_i, _vp]),
     "colvo_conv_wgrad_scratch_bytes": (_sz, [C.POINTER(ConvDesc)]),
     "colvo_conv_wgrad_det": (_i, [C.POINTER(ConvDesc)] + [_vp] * 6 + [_sz, _vp]),
     "colvo_conv_wgrad_splits": (_i, [C.POINTER(ConvDesc)]),

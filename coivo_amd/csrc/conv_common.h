@@ -118,8 +118,10 @@ struct WgradK {
     uint32_t m_pw, m_tow;     // see ConvK
     int nsplit, cot, xcd;     // 1-D grid: (co tile, chunk) fastest, pixel-range split slowest; XCD remap on/off
     int pwl;                  // LDS pitch of a patch row, in pixels (wgrad_row_pitch)
-    int det;                  // deterministic form with ONE split: plain read-modify-write instead of atomics (no slab)
+    int det;                  // ONE split: 1 = deterministic form, plain read-modify-write instead of atomics (no slab); 2 = the arena is
+                              // known to be zero: plain stores
     int slabs_only;           // host side: colvo_conv_wgrad_slabs -- always slabs (a single split too), no second launch
+    int clean;                // host side: the caller vouches that dw / db are zero (colvo_conv_wgrad_clean)
     // Deterministic form (colvo_conv_wgrad_det): every pixel-range split STORES its sums into a slab of its own instead of
     // adding them to dw / db with float atomics; k_wgrad_reduce then adds the slabs in split order.  null: atomics.
     float* slabs;             // [nsplit][Cout * 9 * Ctot]

@@ -96,6 +96,7 @@ static int run_one(const ColvoCmd& c, int k, colvo_stream_t s) {
             if (c.p[5] && c.i[1]) return colvo_conv_wgrad_slabs(&c.desc, c.p[0], c.p[1], c.p[2], (void*)c.p[5], (size_t)(uint32_t)c.i[0], s);
             if (c.p[5]) return colvo_conv_wgrad_det(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], (void*)c.p[5],
                                                     (size_t)(uint32_t)c.i[0], s);
+            if (c.i[2]) return colvo_conv_wgrad_clean(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], 1, s);
             return colvo_conv_wgrad(&c.desc, c.p[0], c.p[1], c.p[2], (float*)c.p[3], (float*)c.p[4], s);
         case COLVO_CMD_PACK_NCHW: {
             const float* src[4] = {(const float*)c.p[0], (const float*)c.p[1], (const float*)c.p[2], (const float*)c.p[3]};

@@ -46,6 +46,8 @@ namespace tune {
     X(rt_min_wgs, 512, "... from this many of its workgroups on (64 frames, us fwd / dgrad, one-tile -> this: enc2b 42.4 / 52.6 -> 35.6 / "  \
                        "41.9, iconv3 65.9 / 52.3 -> 52.8 / 42.3, iconv4 61.8 / 43.6 -> 51.9 / 35.4, enc3b 36.6 / 43.4 -> 32.3 / 35.5, "   \
                        "enc4b 37.2 / 42.1 -> 35.4 / 38.2; at 16 frames its 128-320-workgroup grids lose 0.5-1.8 us per layer)")          \
+    X(rt_bn32_min_wgs, 2048, "... the 32-channel form (iconv2 forward) from this many on: 75.9 -> 59.5 us at 64 frames (5120 workgroups), "  \
+                             "19.0 -> 18.8 at 16 (1280) with the step 0.7 % slower")                                                    \
     X(rt_min_fill_pct, 60, "... and only where the 16x16 tiling covers at most 100/this times the image (32x40 maps: 83 %, 16x20: 62 %)") \
     X(rt_min_chunks, 2, "... and the layer has at least this many 32-channel chunks")                                                 \
     X(xcd_remap, 1, "XCD-contiguous 1-D grids (step +4.3 % without)")                                                               \
@@ -62,6 +64,7 @@ namespace tune {
     X(wgrad_wg_lo, 256, "... but at least this many workgroups")                                                                    \
     X(wgrad_wg_hi, 1024, "... and at most this many")                                                                               \
     X(wgrad_short_walk, 32, "... half the floor while a workgroup of the full grid would walk fewer pixel tiles than this (0: off)")                                                                               \
+    X(wgrad_store_clean, 1, "single-split layers STORE their sums when the caller vouches for a zero arena (colvo_conv_wgrad_clean)")    \
     X(wgrad_teams, 4, "pixel-tile teams per workgroup on the full-resolution layers (1 = off)")                                     \
     X(wgrad_team_max_slabs, 2, "... for layers with at most this many (co tile, chunk) slabs")                                      \
     X(wgrad_team_wgs, 256, "... grid size of the team form")                                                                        \

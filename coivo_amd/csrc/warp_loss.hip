@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NT) void k_warp_loss_fwd_finalize(const float* __re
         loss_state[0] = s0[0] / denom;
         loss_state[1] = 1.0f / denom;
         loss_state[2] = s1[0];
-        loss_state[3] = 0.0f;
+        loss_state[3] = s0[0];          // the masked sum itself: what a data-parallel caller adds up across ranks (colvo_warp_loss_rescale)
     }
 }
 
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(FT) void k_warp_loss_fused_finalize(const float* __
             loss_state[0] = v[0] / denom;
             loss_state[1] = 1.0f / denom;
             loss_state[2] = v[1];
-            loss_state[3] = 0.0f;
+            loss_state[3] = v[0];       // the masked sum itself (colvo_warp_loss_rescale)
         }
         return;
     }
@@ -1794,6 +1794,23 @@ extern "C" int colvo_warp_loss_fused_bwd_params(const float* loss_state, const f
     colvo::launch(k_warp_loss_fused_bwd_params, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, loss_state, grad_loss,
                        grad_partials, pose, B, d_pose, d_a, d_b);
     COLVO_CHECK_LAUNCH("k_warp_loss_fused_bwd_params");
+    return 0;
+}
+
+// Data parallel: loss_state[2] (valid pixels) and loss_state[3] (masked sum) have been added up over `world` ranks -> the loss of
+// the WHOLE batch and the normaliser every rank's raw gradients take so that (1 / world) x the all-reduced gradient is the gradient
+// of that loss: world / max(3 n_global, 1).  The same arithmetic as the finalize kernels (world = 1: bit for bit what they wrote).
+__global__ void k_warp_loss_rescale(float* __restrict__ loss_state, float world) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float denom = fmaxf(3.0f * loss_state[2], 1.0f);
+    loss_state[0] = loss_state[3] / denom;
+    loss_state[1] = world == 1.0f ? 1.0f / denom : world / denom;
+}
+
+extern "C" int colvo_warp_loss_rescale(float* loss_state, int world, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(loss_state && world >= 1, "colvo_warp_loss_rescale: null state or world < 1");
+    colvo::launch(k_warp_loss_rescale, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_state, (float)world);
+    COLVO_CHECK_LAUNCH("k_warp_loss_rescale");
     return 0;
 }
 

@@ -393,7 +393,17 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
             e = (size_t)co * 9 * a.Ctot + wc0 + ocol[fi];
             return ocol[fi] >= 0 && co < a.Cout;
         };
-        if (!a.slabs && a.det) {
+        if (!a.slabs && a.det == 2) {
+            // ONE split and a gradient arena known to be zero (colvo_conv_wgrad_clean): this workgroup is the first and only writer
+            // of its elements in this step -- plain stores, neither atomics (6-7.7 us of a workgroup's life, profiles/r4_wgrad_phases.md)
+            // nor the loads of the read-modify-write
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { size_t e; if (elem(mi, fi, r, e)) a.dw[e] = acc[mi][fi][r]; }
+        } else if (!a.slabs && a.det) {
             float old[MT][FPW][4];
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(NT * KS) void k_wgrad3x3(const WgradK a) {
 #pragma unroll
             for (int ph = 0; ph < NPH * KS; ++ph) t += sdb[ph * 16 * MT + tid];
             if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else if (a.det == 2) a.db[co0 + tid] = t;
             else if (a.det) a.db[co0 + tid] += t;
             else atomicAdd(a.db + co0 + tid, t);
         }
@@ -572,6 +583,8 @@ inline bool wgrad_prepare(WgradK& k, int nsplit, int* err) {
     // deterministic form with one split: every weight element has exactly one writer, which adds to dw / db with a plain
     // read-modify-write -- reproducible without slabs or a second launch
     k.det = (k.scratch && nsplit == 1 && !k.slabs_only) ? 1 : 0;
+    // ... and when the caller vouches that dw / db are still zero (colvo_conv_wgrad_clean) the sole writer just stores
+    if (k.clean && nsplit == 1 && !k.slabs_only && TUNE(wgrad_store_clean)) k.det = 2;
     if (k.scratch && (nsplit > 1 || k.slabs_only)) {
         const long long wsize = (long long)k.Cout * 9 * k.Ctot;
         const long long need = (long long)nsplit * (wsize + k.Cout) * 4;
@@ -966,6 +979,10 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
                 if (rr < nrow) a.slabs[(size_t)bsplit * a.Cout * 9 * a.Ctot + e0 + rr * erow] = sum[rr];
+        } else if (a.det == 2) {            // one split, arena known to be zero: plain stores (see k_wgrad3x3)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (rr < nrow) a.dw[e0 + rr * erow] = sum[rr];
         } else if (a.det) {                 // deterministic form, one split = sole writer: plain read-modify-write, loads first
             float old[4];
 #pragma unroll
@@ -989,6 +1006,7 @@ __global__ __launch_bounds__(NT) void k_wgrad_up2(const WgradK a) {
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) t += sdb[ph * 16 * MT + tid];
             if (a.db_slabs) a.db_slabs[(size_t)bsplit * a.Cout + co0 + tid] = t;
+            else if (a.det == 2) a.db[co0 + tid] = t;
             else if (a.det) a.db[co0 + tid] += t;
             else atomicAdd(a.db + co0 + tid, t);
         }
@@ -1076,11 +1094,16 @@ int launch_wgrad_t(const WgradK& k, hipStream_t s) {
 using namespace colvo;
 
 static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
-                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only = 0);
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only = 0, int clean = 0);
 
 extern "C" int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
                                 float* db, colvo_stream_t stream) {
     return wgrad_impl(d, x0, x1, dy, dw, db, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int colvo_conv_wgrad_clean(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
+                                      float* db, int arena_is_zero, colvo_stream_t stream) {
+    return wgrad_impl(d, x0, x1, dy, dw, db, nullptr, 0, nullptr, stream, 0, arena_is_zero ? 1 : 0);
 }
 
 extern "C" int colvo_conv_wgrad_det(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw,
@@ -1145,7 +1168,7 @@ extern "C" size_t colvo_conv_wgrad_scratch_bytes(const ColvoConvDesc* d) {
 }
 
 static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
-                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only) {
+                      void* scratch, size_t scratch_bytes, int* plan_out, colvo_stream_t stream, int slabs_only, int clean) {
     if (int e = check_desc(d, "colvo_conv_wgrad")) return e;
     COLVO_CHECK_ARG(x0 && dy && dw && (d->C1 == 0 || x1), "colvo_conv_wgrad: null pointer argument");
     // The kernel addresses dY and the sources with 32-bit buffer offsets (< 1 GiB per tensor): larger batches are
@@ -1166,7 +1189,8 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
                 sub.B = std::min(bmax, d->B - b0);
                 int plan = 0;
                 if (int e = wgrad_impl(&sub, (const char*)x0 + b0 * e0, x1 ? (const char*)x1 + b0 * e1 : nullptr,
-                                       (const char*)dy + b0 * ey, dw, db, scratch, scratch_bytes, plan_out ? &plan : nullptr, stream))
+                                       (const char*)dy + b0 * ey, dw, db, scratch, scratch_bytes, plan_out ? &plan : nullptr, stream, 0,
+                                       b0 == 0 ? clean : 0))        // (only the first slice finds the arena clean)
                     return e;
                 if (plan_out) *plan_out = std::max(*plan_out, plan);
             }
@@ -1179,6 +1203,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
     k.dy = (const char*)dy; k.Cout = d->Cout; k.dw = dw; k.Ctot = d->C0 + d->C1; k.db = db;
     k.scratch = (const char*)scratch; k.scratch_bytes = scratch ? (long long)scratch_bytes : 0; k.plan_out = plan_out;
     k.slabs_only = slabs_only;
+    k.clean = clean;
     {
         // single up-sampled source in whole 32-channel (bf16) / 16-channel (f32) chunks: the four-class form over source positions
         const int ck = d->dtype == COLVO_F32 ? 16 : 32;

@@ -50,11 +50,18 @@ class GradBuckets:
     """
 
     def __init__(self, modules: Sequence, process_group=None, bucket_bytes: int = 16 << 20,
-                 transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20):
+                 transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20, exact_batch_loss: bool = True):
+        """exact_batch_loss (default): the photometric loss is normalised by the valid-pixel count of the WHOLE batch, as the spec
+        does (oracle/SPEC.md section 5), not per rank: functional.photometric_loss all-reduces two floats (valid pixels, masked sum)
+        right after its forward kernel and every rank scales its raw gradients by world / max(3 n_global, 1) -- data parallel then
+        IS the spec's big-batch step (tests/ddp_gpu_worker.py compares with the oracle's plain batch loss).  False: the mean of the
+        per-rank masked means (rounds 1-4), which differs when the ranks' valid-pixel counts do; saves one tiny collective between
+        forward and backward.  The widened objective (dcdp_full_loss) keeps per-rank normalisers either way."""
         if not dist.is_initialized():
             raise RuntimeError("GradBuckets needs an initialised torch.distributed process group")
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.exact_batch_loss = bool(exact_batch_loss)
         self._queue_claim = None
         if any(getattr(m, "flat_grad", None) is not None and m.flat_grad.is_cuda for m in modules):
             # The communicator brings a stream of its own: main + weight-gradient side stream + communicator is as many
@@ -84,6 +91,23 @@ class GradBuckets:
             self.states.append(st)
             m.grad_ready_hook = self._make_hook(st)
         self.attached = True
+        self._install_reducer(True)
+
+    # ---- the spec's batch normalisation under data parallelism ------------------------------------ #
+    def _install_reducer(self, on: bool) -> None:
+        from . import functional
+        if on and self.exact_batch_loss:
+            functional.set_batch_reducer(self._reduce_loss_state)
+        elif functional._batch_reducer == self._reduce_loss_state:
+            functional.set_batch_reducer(None)
+
+    def _reduce_loss_state(self, state: torch.Tensor) -> None:
+        """state = {loss, 1/max(3n,1), n_valid, masked sum} of this rank's forward (device): -> the whole batch's."""
+        from . import _lib
+        # (also with one rank: `bench.py --rccl-single` then prices this collective like the bucket ones, and the state comes back
+        # bit for bit -- a one-rank sum is the identity and the rescale repeats the forward's own arithmetic)
+        dist.all_reduce(state[2:4], op=dist.ReduceOp.SUM, group=self.group)           # (the caller's stream waits for it)
+        _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(state), self.world, _lib.stream_ptr()), "colvo_warp_loss_rescale")
 
     @property
     def grad_scale(self) -> float:
@@ -109,9 +133,29 @@ class GradBuckets:
             return launched
         return hook
 
+    def trace_buckets(self, on: bool = True) -> None:
+        """Measurement aid (bench.py): while on, every bucket launch records a timing event on the stream it is issued from, just
+        in front of the collective; bucket_trace(start) then lists where in the step each collective went out -- a first multi-GPU
+        record shows the overlap (or its absence) without a profiler."""
+        self._trace = [] if on else None
+
+    def bucket_trace(self, start: "torch.cuda.Event"):
+        """[{network, bytes, issued_ms after `start`}] of the buckets launched since trace_buckets(True), in launch order; call after
+        finish() and a device synchronisation."""
+        return [{"network": name, "bytes": nbytes, "issued_ms": round(start.elapsed_time(e0), 4)} for name, nbytes, e0 in (self._trace or [])]
+
+    _trace = None
+
     def _launch(self, st: _ArenaState, lo: int, hi: int) -> None:
         if hi <= lo:
             return
+        if self._trace is not None and not torch.cuda.is_current_stream_capturing():
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._trace.append((type(st.module).__name__, (hi - lo) * st.module.flat_grad.element_size(), e0))
+        self._launch_bucket(st, lo, hi)
+
+    def _launch_bucket(self, st: _ArenaState, lo: int, hi: int) -> None:
         sl = st.module.flat_grad[lo:hi]
         if st.staging is not None:
             buf = st.staging[lo:hi]
@@ -148,17 +192,20 @@ class GradBuckets:
         for st in self.states:
             st.module.grad_ready_hook = None
         self.attached = False
+        self._install_reducer(False)
 
     def resume(self) -> None:
         for st, h in zip(self.states, getattr(self, "_paused_hooks", [])):
             st.module.grad_ready_hook = h
         self.attached = True
+        self._install_reducer(True)
 
     def detach(self) -> None:
         """Unhook from the networks and give the communicator's hardware queue back to the stream policy."""
         for st in self.states:
             st.module.grad_ready_hook = None
         self.attached = False
+        self._install_reducer(False)
         if self._queue_claim is not None:
             self._queue_claim.release()
             self._queue_claim = None

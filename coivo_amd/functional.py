@@ -44,6 +44,18 @@ def _timed(kind, call):
     return r
 
 
+# Data parallel (ddp.GradBuckets(exact_batch_loss=True)): called with the loss state {loss, 1/max(3n,1), n_valid, masked sum} right
+# after the forward kernel; it adds the last two up over the ranks and rescales (include/colvo.h colvo_warp_loss_rescale), so that
+# loss AND gradients are those of the spec's ONE masked mean over the whole batch (oracle/SPEC.md section 5) instead of the mean
+# of per-rank means.  None: single process.
+_batch_reducer = None
+
+
+def set_batch_reducer(fn) -> None:
+    global _batch_reducer
+    _batch_reducer = fn
+
+
 class GradHandover:
     """Mailbox between photometric_loss and the producer of one of its arguments (DepthNet.forward_pair_split for `depth`,
     PoseNet.forward for `pose` / `lcc_a` / `lcc_b`).
@@ -131,6 +143,8 @@ class _WarpLoss(torch.autograd.Function):
                 _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
                 B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw), _lib.ptr(gpart), _lib.ptr(gunit),
                 _lib.stream_ptr())), "colvo_warp_loss_fused")
+            if _batch_reducer is not None:
+                _batch_reducer(state)
             ctx.gunit = gunit
             ctx.save_for_backward(pose, state, d_raw, gpart)
             ctx.shape = (B, H, W)
@@ -138,6 +152,8 @@ class _WarpLoss(torch.autograd.Function):
         _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fwd(
             _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
             B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr())), "colvo_warp_loss_fwd")
+        if _batch_reducer is not None and any(ctx.needs_input_grad[2:7]):
+            _batch_reducer(state)
         ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
         return state[0]
 
@@ -195,6 +211,15 @@ def photometric_loss(tgt, ref, depth, pose, K, lcc_a, lcc_b, *, ssim_weight: flo
     hp = getattr(pose, "_colvo_handover", None)
     if hp is not None and not (getattr(lcc_a, "_colvo_handover", None) is hp and getattr(lcc_b, "_colvo_handover", None) is hp):
         hp = None                      # pose, lcc_a and lcc_b must come from ONE PoseNet call
+    # `depth` = the target half `d[:B]` of depth_net(cat(tgt, ref)) (nn.DepthNet.forward): the pass made a second output for
+    # exactly this call -- the same values, a gradient path of its own with the deferred normalisation -- so that the spec's
+    # call sequence, which hands ONE tensor to PoseNet and to the loss, runs like forward_pair_split.  Taken once; a second loss
+    # on the same tensor, or a tensor changed in place since, takes the ordinary path.
+    twin = getattr(depth, "_colvo_loss_twin", None)
+    if twin is not None:
+        depth._colvo_loss_twin = None
+        if twin[0]._version == twin[1] and torch.is_grad_enabled():
+            depth = twin[0]
     return _WarpLoss.apply(tgt, ref, depth, pose, K, lcc_a, lcc_b, ssim_weight, getattr(depth, "_colvo_handover", None), hp)
 
 

@@ -119,6 +119,7 @@ class GraphedTrainStep:
         _lib.check(lib.colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
         _lib.check(lib.colvo_set_capture_carry(int(self.carry)), "colvo_set_capture_carry")
         _lib.check(lib.colvo_graph_stats_reset(), "colvo_graph_stats_reset")
+        self._check_process_group_environment()
         g = torch.cuda.CUDAGraph()
         nspace = int(_lib.dev_env("COLVO_GRAPH_SPACER_STREAMS", "0"))       # (developer probe: streams created in front of the capture)
         self._spacers = [torch.cuda.Stream() for _ in range(nspace)]
@@ -151,6 +152,27 @@ class GraphedTrainStep:
         self.graph = g
         restore()          # capture itself does not execute, but keep the state exactly as the caller left it
         torch.cuda.synchronize()
+
+    def _check_process_group_environment(self) -> None:
+        """A captured step with RCCL collectives inside wants TORCH_NCCL_CUDA_EVENT_CACHE=0 in the environment BEFORE the process group
+        is created.  Round 5, tests/graph_rccl_worker.py, one run in two: the process group's watchdog thread ended the process with
+        'operation not permitted on an event last recorded in a capturing stream' from WorkNCCL::isCompleted() -- an event query on
+        an EAGER collective.  torch keeps captured collectives away from the watchdog, but it recycles their events through a
+        cache; an event recorded on RCCL's stream while that stream was part of a capture keeps its captured mark in this HIP runtime
+        when an eager collective re-records it, and the watchdog's query then fails.  Without the cache every eager collective gets
+        fresh events.  (A hypothesis from one stack trace; the setting costs an event creation per collective.)"""
+        import os
+        import warnings
+        if self.ddp is None:
+            return
+        try:
+            import torch.distributed as dist
+            nccl = dist.is_initialized() and dist.get_backend(self.ddp.group) == "nccl"
+        except Exception:           # noqa: BLE001
+            nccl = False
+        if nccl and os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "1").strip().lower() not in ("0", "false", "off", "no", "n"):
+            warnings.warn("hipGraph capture with RCCL collectives inside: export TORCH_NCCL_CUDA_EVENT_CACHE=0 before "
+                          "init_process_group (GraphedTrainStep._check_process_group_environment says why)", RuntimeWarning, stacklevel=3)
 
     def close(self) -> None:
         """Destroy the captured graph NOW, at a defined point, and return the library to its pre-capture state.

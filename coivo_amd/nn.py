@@ -203,6 +203,7 @@ class _ArenaModule(nn.Module):
     # True while the gradient arena is known to be all zero (set by optim.FusedAdam(zero_grad_in_step=True).step(), cleared by every
     # backward pass): the optimizer's zero_grad() then skips its launch
     _grads_clean = False
+    _arena_zero_for_pass = False        # _grads_clean as the running backward pass found it (handed to its weight-gradient commands)
 
     def attach_grads(self) -> None:
         """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
@@ -222,6 +223,7 @@ class _ArenaModule(nn.Module):
         if self.flat_grad is not None:
             ops.zero_(self.flat_grad)          # one hipMemsetAsync, no torch fill kernel
             self.attach_grads()
+            self._grads_clean = True           # until a backward pass -- or anything else that writes .grad: unguarded -- touches it
 
     def mark_params_changed(self) -> None:
         self._manual_version += 1
@@ -327,6 +329,10 @@ class _ArenaModule(nn.Module):
             for name, t in externals.items():
                 pr.patch(name, t)
         pr, out = entry
+        if pr.flag_slots:
+            # "the gradient arena is still zero" for this pass's weight-gradient commands: true for the first backward pass behind an
+            # optimizer step that cleared the gradients (FusedAdam(zero_grad_in_step=True)) or an explicit zero_grad()
+            pr.set_flags(1 if self._arena_zero_for_pass else 0)
         if pr.uses_side and self._side is None:
             self._side = _side_stream(self.flat_param.device)
         if self.grad_ready_hook is None or not pr.marks:
@@ -580,6 +586,20 @@ class DepthNet(_ArenaModule):
         self._build_arena(torch.device(device))
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
+        """depth [B,1,H,W].  For an even batch -- the DCDP pair batch `depth_net(torch.cat([tgt, ref]))` of the spec's train step --
+        the result is a _PairDepth: an ordinary depth tensor for every use, except that the spec's own next line, `d[:B]` /
+        `d[B:]` with B = half the batch, returns the two halves as OUTPUTS of the network's autograd node (as forward_pair_split
+        does) instead of slices of one output: no slice-backward nodes (zero-fill + copy + add each), PoseNet's input can come
+        from the pass, and photometric_loss(.., d[:B], ..) finds the loss's own gradient path (functional.photometric_loss)."""
+        if (img.dim() == 4 and img.shape[0] % 2 == 0 and img.shape[0] >= 2 and self.use_programs
+                and _lib.dev_env("COLVO_NO_PAIR_FORWARD") is None):
+            from .functional import GradHandover
+            hand = GradHandover()
+            d_t, d_r, d_l, full = _DepthNetPairFn.apply(self, img, self._trigger(), hand, False, True)
+            d_l._colvo_handover = hand
+            self._tag_pose_in((d_t, d_r))
+            d_t._colvo_loss_twin = (d_l, d_l._version)      # photometric_loss swaps it in (once): the loss's own gradient path
+            return _PairDepth.wrap(full, d_t, d_r)
         return _DepthNetFn.apply(self, img, self._trigger())
 
     def forward_pair(self, frames: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -701,6 +721,7 @@ class DepthNet(_ArenaModule):
         """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b[, g_raw_second]): the gradient of the
         first / second half of the images and a (scaled) addend for each half (ops.depth_head_bwd_parts), each may be None."""
         A, P, inst = saved
+        self._arena_zero_for_pass = self._grads_clean
         self._grads_clean = False
         self.attach_grads()
         self._order_deterministic_pass()
@@ -803,6 +824,29 @@ class DepthNet(_ArenaModule):
         self._run_pass(inst, which, ext, body)
 
 
+class _PairDepth(torch.Tensor):
+    """What DepthNet.forward returns for an even batch: the depth of the whole batch, an ordinary tensor in every respect (ops on
+    it return plain tensors), whose two half-batch slices `d[:B]` / `d[B:]` are the pre-split outputs of the network's node."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def wrap(full: torch.Tensor, d_t: torch.Tensor, d_r: torch.Tensor) -> "_PairDepth":
+        t = full.as_subclass(_PairDepth)
+        t._colvo_halves = (full.shape[0] // 2, d_t, d_r, full._version)
+        return t
+
+    def __getitem__(self, idx):
+        h = self.__dict__.get("_colvo_halves")
+        if h is not None and isinstance(idx, slice) and idx.step in (None, 1) and self._version == h[3]:
+            B, d_t, d_r, _ = h
+            start, stop, _ = idx.indices(2 * B)
+            if (start, stop) == (0, B):
+                return d_t
+            if (start, stop) == (B, 2 * B):
+                return d_r
+        return super().__getitem__(idx)
+
+
 class _DepthNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net: DepthNet, img, trigger):
@@ -827,26 +871,40 @@ class _DepthNetPairFn(torch.autograd.Function):
     backward kernel as they are (no zero-fill, cat or add kernels in between)."""
 
     @staticmethod
-    def forward(ctx, net: DepthNet, frames, trigger, handover, both=False):
+    def forward(ctx, net: DepthNet, frames, trigger, handover, both=False, whole=False):
         depth, saved = net._forward_impl(frames, pair=True)
-        ctx.net, ctx.saved, ctx.handover = net, saved, handover
+        ctx.net, ctx.saved, ctx.handover, ctx.whole = net, saved, handover, whole
+        ctx.set_materialize_grads(False)           # an output nobody used arrives as None, not as a tensor of zeros to add
         ctx.lease = _Lease(saved[2])
         ctx.save_for_backward(depth)
         B = frames.shape[0] // 2
         if both:                                   # forward_pair_full: BOTH depths once more, for an objective that takes both
             return depth[:B], depth[B:], depth[:B], depth[B:]
+        if whole:                                  # DepthNet.forward: the whole batch as a fourth output (any other use of `d`)
+            return depth[:B], depth[B:], depth[:B], depth.view_as(depth)
         return depth[:B], depth[B:], depth[:B]
 
     @staticmethod
-    def backward(ctx, g_t, g_r, g_l, g_lr=None):
+    def backward(ctx, g_t, g_r, g_l, g_4=None):
         (depth,) = ctx.saved_tensors
         sa = sb = None
         if ctx.handover is not None:
             sa, sb = ctx.handover.take((g_l,))     # unnormalised loss gradient + its two device scale factors
-        ctx.net._backward_impl(ctx.saved, depth, None, parts=(g_t, g_r, g_l, sa, sb, g_lr))
+        if ctx.whole and g_4 is not None:
+            # the whole-batch output was used as well (d.mean(), a slice other than the halves ...): the general backward on the sum
+            B = depth.shape[0] // 2
+            d_depth = g_4.clone()
+            for half, g in ((d_depth[:B], g_t), (d_depth[B:], g_r)):
+                if g is not None:
+                    half.add_(g)
+            if g_l is not None:
+                d_depth[:B].add_(g_l * (sa * sb) if sa is not None else g_l)
+            ctx.net._backward_impl(ctx.saved, depth, d_depth)
+        else:
+            ctx.net._backward_impl(ctx.saved, depth, None, parts=(g_t, g_r, g_l, sa, sb, None if ctx.whole else g_4))
         ctx.saved = None
         ctx.lease.release()
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class PoseNet(_ArenaModule):
@@ -937,6 +995,7 @@ class PoseNet(_ArenaModule):
 
     def _backward_impl(self, saved, d_pose, d_a, d_b, scale_a=None, scale_b=None):
         A, P, (B, H, W), has_depth, inst, filled = saved
+        self._arena_zero_for_pass = self._grads_clean
         self._grads_clean = False
         self.attach_grads()
         self._order_deterministic_pass()

@@ -175,18 +175,24 @@ def conv_wgrad_scratch(d: ConvDesc, device) -> torch.Tensor:
     return torch.empty((n + 3) // 4, device=device, dtype=torch.float32)
 
 
-def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db, scratch: Optional[torch.Tensor] = None) -> None:
+def conv_wgrad(d: ConvDesc, x0, x1, dy, dw, db, scratch: Optional[torch.Tensor] = None, arena_is_zero: bool = False) -> None:
     """dw / db += the layer's weight / bias gradient.  With `scratch` (conv_wgrad_scratch) the deterministic form: per-split slabs
-    + a fixed-order second launch instead of float atomics."""
+    + a fixed-order second launch instead of float atomics.  arena_is_zero: the caller vouches that dw / db hold zeros -- single-split
+    layers then store instead of adding (include/colvo.h colvo_conv_wgrad_clean)."""
     _need_cuda(x0, x1, dy, dw, db, scratch)
     nb = 0 if scratch is None else scratch.numel() * scratch.element_size()
     rec = program.recording()
     if rec is not None:
-        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, dw, db, scratch), (nb,))
+        # (i[2] = "the arena is still zero": patched per replay by Program.set_flags, nn._ArenaModule._run_pass)
+        return rec.add(_lib.CMD_CONV_WGRAD, d, (x0, x1, dy, dw, db, scratch), (nb, 0, 0), flag_slot=2 if scratch is None else None)
     lib = _lib.load()
     if scratch is not None:
         _lib.check(lib.colvo_conv_wgrad_det(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db),
                                             _lib.ptr(scratch), nb, _lib.stream_ptr()), "colvo_conv_wgrad_det")
+        return
+    if arena_is_zero:
+        _lib.check(lib.colvo_conv_wgrad_clean(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), 1,
+                                              _lib.stream_ptr()), "colvo_conv_wgrad_clean")
         return
     _lib.check(lib.colvo_conv_wgrad(C.byref(d), _lib.ptr(x0), _lib.ptr(x1), _lib.ptr(dy), _lib.ptr(dw),
                                     _lib.ptr(db), _lib.stream_ptr()), "colvo_conv_wgrad")

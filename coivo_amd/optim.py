@@ -53,6 +53,8 @@ class FusedAdam:
             ops.zero_multi([m.flat_grad for m in self.modules])
         for m in self.modules:
             m.attach_grads()
+            m._grads_clean = True           # (cleared just now or known clean; the next backward pass takes it from here --
+                                            #  captured: the graph holds the clearing launch in front of every replayed backward)
 
     @torch.no_grad()
     def step(self) -> None:

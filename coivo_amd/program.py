@@ -31,6 +31,8 @@ class Program:
         self._slots: Dict[str, List[Tuple[int, int]]] = {}
         self._arr = None
         self.uses_side = False
+        self.flag_slots: List[Tuple[int, int]] = []   # (command, integer slot) of per-replay flags (set_flags)
+        self._flag_value = 0
 
     # ---- recording ------------------------------------------------------------------------------------------- #
     def __enter__(self):
@@ -53,7 +55,7 @@ class Program:
         return t
 
     def add(self, op: int, desc=None, p: Sequence[Optional[torch.Tensor]] = (), i: Sequence[int] = (),
-            f: Sequence[float] = (), raw: Sequence = ()) -> None:
+            f: Sequence[float] = (), raw: Sequence = (), flag_slot: Optional[int] = None) -> None:
         """raw: [(slot, address, keepalive)] -- pointer slots that are not tensors (a host-side table the command refers to)."""
         c = _lib.Cmd()
         c.op, c.stream = op, self.stream
@@ -72,6 +74,8 @@ class Program:
             c.f[k] = float(v)
         if self.stream:
             self.uses_side = True
+        if flag_slot is not None:            # an integer argument the host sets before each replay (set_flags)
+            self.flag_slots.append((len(self.cmds), flag_slot))
         self.cmds.append(c)
 
     def fork(self) -> None:
@@ -108,6 +112,21 @@ class Program:
         arr = self._arr
         for ci, k in self._slots[name]:
             arr[ci].p[k] = ptr
+
+    def set_flags(self, value: int) -> None:
+        """Write `value` into every registered per-replay integer slot (today: "the gradient arena is still zero" of the weight-
+        gradient commands, include/colvo.h COLVO_CMD_CONV_WGRAD)."""
+        value = int(value)
+        if value == self._flag_value or self._arr is None:
+            if self._arr is None:
+                for ci, k in self.flag_slots:
+                    self.cmds[ci].i[k] = value
+                self._flag_value = value
+            return
+        arr = self._arr
+        for ci, k in self.flag_slots:
+            arr[ci].i[k] = value
+        self._flag_value = value
 
     def run(self, side: Optional[torch.cuda.Stream], begin: int = 0, end: Optional[int] = None) -> None:
         n = len(self._arr) if end is None else end

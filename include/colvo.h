@@ -48,7 +48,7 @@ const char* colvo_last_error(void);
 size_t colvo_warp_loss_workspace_floats(int B, int H, int W);
 
 /* Forward.  tgt, ref [B,3,H,W]; depth [B,1,H,W]; pose [B,6]; K [B,3,3]; lcc_a, lcc_b [B].
- * loss_state[4] (device) receives { loss, 1/max(3*n_valid,1), n_valid, 0 }.  H, W >= 2. */
+ * loss_state[4] (device) receives { loss, 1/max(3*n_valid,1), n_valid, masked sum = loss * max(3*n_valid,1) }.  H, W >= 2. */
 int colvo_warp_loss_fwd(const float* tgt, const float* ref, const float* depth, const float* pose,
                         const float* K, const float* lcc_a, const float* lcc_b,
                         int B, int H, int W, float ssim_weight,
@@ -82,6 +82,13 @@ int colvo_warp_loss_fused_bwd(const float* loss_state, const float* grad_loss, c
 int colvo_warp_loss_fused_bwd_params(const float* loss_state, const float* grad_loss, const float* grad_partials,
                                      const float* pose, int B, float* d_pose, float* d_a, float* d_b,
                                      colvo_stream_t stream);
+
+/* Data parallel with the spec's batch normalisation (oracle/SPEC.md section 5: ONE masked mean over the whole batch).  The caller
+ * adds loss_state[2..3] (valid pixels, masked sum) up over its `world` ranks -- one all-reduce of two floats -- and this call turns
+ * the state into the global one: loss_state[0] = the loss of the whole batch, loss_state[1] = world / max(3 n_global, 1), so that
+ * (1 / world) x the sum of the ranks' gradients is the gradient of that loss.  Every backward entry point above reads the scale
+ * from loss_state[1].  world = 1 leaves the state bit for bit as the forward wrote it. */
+int colvo_warp_loss_rescale(float* loss_state, int world, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * SURVEY.md §8f-1  geometric consistency (README.md:1 "Considering Geometric and Photometric   *
@@ -235,6 +242,12 @@ int colvo_depth_head_wgrad_mfma(const void* y, const float* dpre, int B, int H, 
  * (the caller zeroes them once per step). */
 int colvo_conv_wgrad(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
                      float* dw, float* db, colvo_stream_t stream);
+/* The same with a promise: arena_is_zero != 0 says dw and db hold zeros and nothing else writes them while this call runs (the first
+ * backward pass behind an optimizer step that cleared the gradients).  Layers whose grid has ONE pixel-range split per weight slab
+ * then STORE their sums instead of adding them with fp32 atomics (a third of such a workgroup's life, profiles/r4_wgrad_phases.md);
+ * every other layer, and arena_is_zero == 0, is colvo_conv_wgrad.  The result is the same either way. */
+int colvo_conv_wgrad_clean(const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy,
+                           float* dw, float* db, int arena_is_zero, colvo_stream_t stream);
 
 /* Deterministic weight gradients.  The plain calls end in fp32 atomics (one add per weight and pixel-range split): the sum
  * depends on the order the workgroups finish in, in the last bits.  The _det forms give every split a slab of its own in
@@ -423,8 +436,9 @@ int colvo_read_npy_u8_frames(const char* const* paths, int n, int h, int w, uint
 enum {
     COLVO_CMD_CONV_FWD = 1,      /* p: x0 x1 w_fwd bias y */
     COLVO_CMD_CONV_DGRAD,        /* i: src accumulate; p: dy w_bwd relu_mask dx */
-    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db scratch; i: scratch_bytes slabs_only (scratch != NULL: colvo_conv_wgrad_det, or with
-                                    slabs_only colvo_conv_wgrad_slabs) */
+    COLVO_CMD_CONV_WGRAD,        /* p: x0 x1 dy dw db scratch; i: scratch_bytes slabs_only arena_is_zero (scratch != NULL:
+                                    colvo_conv_wgrad_det, or with slabs_only colvo_conv_wgrad_slabs; scratch == NULL and arena_is_zero:
+                                    colvo_conv_wgrad_clean -- the host patches that integer before each replay) */
     COLVO_CMD_PACK_NCHW,         /* i: dtype c0 c1 c2 c3 nsrc B H W Cpad; p: src0..src3 dst */
     COLVO_CMD_UNPACK_NHWC_GRAD,  /* i: dtype B H W Cpad c_begin c_count accumulate; p: dsrc dst */
     COLVO_CMD_DEPTH_HEAD_FWD,    /* i: dtype B H W C; f: min max; p: x w bias depth */

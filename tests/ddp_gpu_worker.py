@@ -13,9 +13,12 @@ sys.path.insert(0, ROOT)
 
 
 def _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g_pn):
-    """DP == big batch against the SPEC: the all-reduced gradient x 1/world and the parameters after one Adam step vs the oracle's
-    single-process update on the mean of the per-rank losses (fp32 and fp64 oracle at the HIP path's ReLU decisions of each rank's
-    own slice: tests/gpu_util.py), at the bar of grad_parity_failures."""
+    """DP == big batch against the SPEC, un-redefined: the all-reduced gradient x 1/world and the parameters
+    after one Adam step vs the oracle's single-process step on the WHOLE batch of world x B pairs -- ONE masked mean over all of its
+    valid pixels (oracle/SPEC.md section 5; GradBuckets(exact_batch_loss=True) all-reduces the valid-pixel count and the masked sum
+    behind the loss kernel) -- fp32 and fp64 oracle at the HIP path's ReLU decisions of every rank's slice (tests/gpu_util.py), at
+    the bar of grad_parity_failures.  Rounds 3-4 compared with the mean of the per-rank losses instead.  Every rank must report
+    the loss of the whole batch."""
     from oracle import colvo_spec as S
     from tests import gpu_util as G
     masks = G.hip_relu_masks(dn, pn)
@@ -24,24 +27,30 @@ def _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g
     if rank != 0:
         return
     cpu = {k: v.detach().cpu() for k, v in full.items() if torch.is_tensor(v)}
+    # the ranks' ReLU decisions in the big batch's order: DepthNet runs on [all target frames | all reference frames]
+    big = {}
+    for key in gathered[0][0]:
+        parts = [g[0][key] for g in gathered]
+        if key.startswith("depth."):
+            big[key] = torch.cat([p[:B] for p in parts] + [p[B:] for p in parts], dim=0)
+        else:
+            big[key] = torch.cat(parts, dim=0)
     acc = {}
     for dtype in (torch.float32, torch.float64):
-        tot, tot_loss = None, 0.0
-        for r in range(world):
-            sl = slice(r * B, (r + 1) * B)
-            o = G.oracle_step(seed, {k: cpu[k][sl] for k in ("tgt", "ref", "K")}, dtype, gathered[r][0])
-            assert o["flip_worst"] < G.RELU_MARGIN, f"rank {r}: forced a ReLU decision at |pre| = {o['flip_worst']:.3e}"
-            tot_loss += o["loss"] / world
-            g = [(n, t.detach().double() / world) for n, t in o["grads"]]
-            tot = g if tot is None else [(n, a + b) for (n, a), (_, b) in zip(tot, g)]
-        acc[dtype] = (tot, tot_loss)
-    hip_loss = sum(l for _, l in gathered) / world
+        o = G.oracle_step(seed, {k: cpu[k] for k in ("tgt", "ref", "K")}, dtype, big)
+        assert o["flip_worst"] < G.RELU_MARGIN, f"forced a ReLU decision at |pre| = {o['flip_worst']:.3e}"
+        acc[dtype] = ([(n, t.detach().double()) for n, t in o["grads"]], o["loss"])
+    assert all(abs(l - gathered[0][1]) < 1e-7 for _, l in gathered), [l for _, l in gathered]     # every rank: the batch's loss
+    hip_loss = gathered[0][1]
     assert abs(hip_loss - acc[torch.float32][1]) < 1e-5, (hip_loss, acc[torch.float32][1])
+    # (the per-rank means differ from it: this batch would not pass with the round-4 normalisation)
+    per_rank = [G.oracle_step(seed, {k: cpu[k][r * B:(r + 1) * B] for k in ("tgt", "ref", "K")}, torch.float32)["loss"] for r in range(world)]
+    print(f"oracle: batch loss {acc[torch.float32][1]:.7f}, mean of the per-rank losses {sum(per_rank) / world:.7f}", flush=True)
     hip = [("depth." + n, p.grad.detach().double() / world) for n, p in dn.named_parameters()] + \
           [("pose." + n, p.grad.detach().double() / world) for n, p in pn.named_parameters()]
     rows = G.grad_parity_table(hip, acc[torch.float32][0], acc[torch.float64][0])
     bad = G.grad_parity_failures(rows)
-    assert not bad, "data-parallel gradient vs the oracle's mean-of-rank-losses gradient:\n" + "\n".join(bad)
+    assert not bad, "data-parallel gradient vs the oracle's gradient of the whole batch's loss:\n" + "\n".join(bad)
     # one Adam step of the oracle on that gradient vs FusedAdam(grad_scale = 1/world) on the all-reduced arena
     dn_o, pn_o = S.make_models(seed)
     params = list(dn_o.parameters()) + list(pn_o.parameters())
@@ -117,14 +126,32 @@ def main():
         dist.all_gather(ref, t)
         assert all(torch.equal(r, ref[0]) for r in ref), "ranks diverged"
     if rank == 0:
-        # single-process reference: the per-rank batches accumulated into one arena
+        # single-process reference: the per-rank batches accumulated into one arena -- with the normalisation the ranks used: the
+        # photometric loss of every slice takes the WHOLE batch's valid-pixel count and masked sum (what the ranks all-reduce behind
+        # their loss kernels), here added up from a forward-only pass over the slices; the widened objective has no such exchange
+        from coivo_amd import _lib, functional as Fh
         dn2, pn2 = fresh()
         opt2 = FusedAdam([dn2, pn2], lr=1e-4)
         opt2.grad_scale = 1.0 / world
+        slices = [slice(r * B, (r + 1) * B) for r in range(world)]
+        if not obj:
+            seen = []
+            Fh.set_batch_reducer(lambda st: seen.append(st.clone()))
+            for s2 in slices:
+                hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2])
+            assert len(seen) == world
+            glob = seen[0][2:4].clone()
+            for st in seen[1:]:
+                glob += st[2:4]
+
+            def whole_batch(st):
+                st[2:4].copy_(glob)
+                _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(st), world, _lib.stream_ptr()), "colvo_warp_loss_rescale")
+            Fh.set_batch_reducer(whole_batch)
         opt2.zero_grad()
-        for r in range(world):
-            s2 = slice(r * B, (r + 1) * B)
+        for s2 in slices:
             hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2], **obj)[0].backward()
+        ddp._install_reducer(True)               # back to the data-parallel one for the steps below
         torch.cuda.synchronize()
         for a, b, name in ((g_dn, dn2.flat_grad, "DepthNet"), (g_pn, pn2.flat_grad, "PoseNet")):
             scale = b.abs().max().item()

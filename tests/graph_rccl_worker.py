@@ -22,6 +22,7 @@ def main():
     from oracle import colvo_spec as S
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # (coivo_amd/graph.py _check_process_group_environment)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -34,7 +35,10 @@ def main():
         dn.deterministic = pn.deterministic = True
         return dn, pn, FusedAdam([dn, pn], lr=1e-4)
 
-    B, H, W, seed = 2, 64, 96, 63
+    # default: B=2 64x96; `... f32 64 256 320` = the per-GPU shape of BASELINE configs[4] (64 pairs of 320x256): from 32 pairs on
+    # GraphedTrainStep cuts the weight-gradient chain into one-command segments (graph.py), a branch the small shape never reaches
+    B, H, W = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (2, 64, 96)
+    seed = 63
     b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.make_batch(B, H, W, seed=seed).items()}
     frames = torch.cat([b["tgt"], b["ref"]])
     dn1, pn1, opt1 = setup(seed)
@@ -42,6 +46,7 @@ def main():
     ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport)
     ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport)
     step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
+    assert step.capture_group == (1 if B >= 32 else 2)
     eager, graphed = [], []
     for _ in range(3):
         opt1.zero_grad()

@@ -8,9 +8,10 @@ four-pixel forms), so 64 / 128 DepthNet images pick kernel variants that neither
   * the step runs, loss and every gradient are finite, Adam moves the weights;
   * depth maps of the first 8 pairs against the fp32 oracle on that slice ('depth L1 vs ref', BASELINE.json metric) and the
     HIP loss of that slice against the oracle's, both at the bf16 bounds of tests/test_config1_gpu.py;
-  * batch-split consistency: frame pairs are independent units, so the loss of the big batch is the valid-pixel-weighted mean
-    of the losses of its 8-pair slices, and its gradient the same mean of theirs (the slices run through the configs[1]-size
-    kernel variants, the big batch through its own).
+  * batch-split consistency with data parallel's normalisation: the 8-pair slices stand for ranks, each slice's loss state takes
+    the whole batch's valid-pixel count and masked sum (what ddp.GradBuckets all-reduces) -- every slice then reports the big
+    batch's loss and the PLAIN mean of the slices' gradients is the big batch's (the slices run through the configs[1]-size kernel
+    variants, the big batch through its own).
 
 The N > 1 part of these configurations -- RCCL all-reduce between ranks -- needs hardware this build never had.
 """
@@ -66,31 +67,51 @@ def test_per_rank_shape_step(pairs, config):
     print(f"{config} per-rank shape ({pairs} pairs): depth L1 vs ref on pairs 0..7 {l1:.3e} (relative {rel:.3e})")
     assert rel < 1e-2
 
-    # ---- batch-split consistency ----
-    losses, weights, grads = [], [], []
-    for s0 in range(0, pairs, SLICE):
-        sl = slice(s0, s0 + SLICE)
-        opt.zero_grad()
-        li, ti, _, pi, _, _ = hnn.dcdp_forward(dn, pn, d["tgt"][sl].contiguous(), d["ref"][sl].contiguous(), d["K"][sl].contiguous())
-        li.backward()
-        with torch.no_grad():
-            n_valid = Fh.inverse_warp(d["ref"][sl].contiguous(), ti.detach().contiguous(), pi.detach().contiguous(),
-                                      d["K"][sl].contiguous())[1].sum().item()
-        torch.cuda.synchronize()
-        losses.append(li.item())
-        weights.append(n_valid)
-        grads.append(torch.cat([dn.flat_grad, pn.flat_grad]).clone())
-    assert abs(losses[0] - lo.item()) < 2e-3, (losses[0], lo.item())
-    wsum = sum(weights)
-    assert wsum > 0.5 * pairs * H * W              # the synthetic pairs overlap almost everywhere
-    mix = sum(l * w for l, w in zip(losses, weights)) / wsum
+    # ---- batch-split consistency, with the normalisation data parallel uses ----
+    # The slices stand for ranks: each slice's loss kernel is followed by what ddp.GradBuckets(exact_batch_loss=True) does behind it
+    # -- the valid-pixel count and the masked sum of the WHOLE batch go into the loss state (here added up from a forward-only pass
+    # over the slices instead of an all-reduce) and colvo_warp_loss_rescale turns it into the batch's loss and the scale
+    # k / max(3 n_batch, 1).  Then every slice reports the big batch's loss and the PLAIN mean of the slices' gradients is the big
+    # batch's gradient (round 4: a valid-pixel-weighted mean, i.e. data parallel matched the spec only after re-weighting).
+    from coivo_amd import _lib
+    slices = [slice(s0, s0 + SLICE) for s0 in range(0, pairs, SLICE)]
+    k = len(slices)
+
+    def run(sl):
+        return hnn.dcdp_forward(dn, pn, d["tgt"][sl].contiguous(), d["ref"][sl].contiguous(), d["K"][sl].contiguous())[0]
+
+    seen = []
+    Fh.set_batch_reducer(lambda st: seen.append(st.clone()))
+    try:
+        first = run(slices[0]).item()               # (its own masked mean: the reducer above changes nothing)
+        for sl in slices[1:]:
+            run(sl)
+        assert len(seen) == k
+        glob = torch.stack([st[2:4] for st in seen]).sum(0)
+        assert glob[0].item() > 0.5 * pairs * H * W              # the synthetic pairs overlap almost everywhere
+
+        def whole_batch(st):
+            st[2:4].copy_(glob)
+            _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(st), k, _lib.stream_ptr()), "colvo_warp_loss_rescale")
+        Fh.set_batch_reducer(whole_batch)
+        losses, grads = [], []
+        for sl in slices:
+            opt.zero_grad()
+            li = run(sl)
+            li.backward()
+            torch.cuda.synchronize()
+            losses.append(li.item())
+            grads.append(torch.cat([dn.flat_grad, pn.flat_grad]).clone())
+    finally:
+        Fh.set_batch_reducer(None)
+    assert abs(first - lo.item()) < 2e-3, (first, lo.item())
     # bf16 feature maps: a different kernel variant may round an activation the other way; fp32 loss
-    assert abs(big_loss - mix) < 1e-3, (big_loss, mix, losses)
-    g_mix = sum(g * (w / wsum) for g, w in zip(grads, weights))
+    assert max(losses) - min(losses) < 1e-7 and abs(big_loss - losses[0]) < 1e-3, (big_loss, losses)
+    g_mix = sum(grads) / k
     cos = torch.nn.functional.cosine_similarity(g_big, g_mix, dim=0).item()
     rel_l2 = ((g_big - g_mix).norm() / g_mix.norm()).item()
-    print(f"{config}: loss {big_loss:.6f} vs valid-weighted mean of {len(losses)} slices {mix:.6f}; gradient cosine {cos:.5f}, "
-          f"relative L2 {rel_l2:.3e}")
+    print(f"{config}: loss {big_loss:.6f} vs the {k} slices' (each reports the batch's) {losses[0]:.6f}; gradient of the big batch vs "
+          f"the plain mean of the slices': cosine {cos:.5f}, relative L2 {rel_l2:.3e}")
     assert cos > 0.995 and rel_l2 < 0.1
 
     # ---- Adam moves the weights and keeps them finite ----

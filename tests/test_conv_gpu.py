@@ -123,7 +123,7 @@ def _both_kernel_forms(request):
     in the library's tuning table (colvo_tune_set, csrc/tuning.h) to reach them -- the other half exercises the one-tile kernels
     on the same shapes."""
     from coivo_amd import _lib
-    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_min_fill_pct", "rt_min_chunks")
+    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks")
     saved = {n: _lib.tune_get(n) for n in names}
     if "form1" in request.node.name:
         _lib.tune_set("dgrad_up2_min_wgs", 0)
@@ -134,6 +134,7 @@ def _both_kernel_forms(request):
         # tiles cover the image well): every stride-1 case with direct sources and whole chunks, ragged images included
         _lib.tune_set("dgrad_up2_min_wgs", 0)
         _lib.tune_set("rt_min_wgs", 0)
+        _lib.tune_set("rt_bn32_min_wgs", 0)
         _lib.tune_set("rt_min_fill_pct", 0)
         _lib.tune_set("rt_min_chunks", 1)
     yield
@@ -208,6 +209,14 @@ def test_conv_fwd_dgrad_wgrad(case, dtype, form):
     # wgrad accumulates
     ops.conv_wgrad(desc, x0d, x1d, dyd, dw, db)
     _close(dw, 2 * wr.grad, rt, at, "wgrad accumulate")
+    # the caller vouches for a zero arena (colvo_conv_wgrad_clean): single-split layers store instead of adding -- same values; a
+    # second, ordinary call accumulates on top
+    dwc, dbc = torch.zeros_like(dw), torch.zeros_like(db)
+    ops.conv_wgrad(desc, x0d, x1d, dyd, dwc, dbc, arena_is_zero=True)
+    _close(dwc, wr.grad, rt, at, "wgrad (zero arena vouched for)")
+    _close(dbc, br.grad, rt, at, "bgrad (zero arena vouched for)")
+    ops.conv_wgrad(desc, x0d, x1d, dyd, dwc, dbc)
+    _close(dwc, 2 * wr.grad, rt, at, "wgrad (zero arena vouched for) accumulate")
     # deterministic form (per-split slabs + a fixed-order second launch instead of float atomics): same values, bitwise
     # repeatable, accumulates like the plain form
     scr = ops.conv_wgrad_scratch(desc, d)
@@ -425,6 +434,7 @@ def test_dgrad_both_sources_equals_two_calls(B, H, W, C0, C1, Cout, dtype, kerne
     from coivo_amd import _lib, ops
     if kernel == "register_tiled":      # (the autouse fixture restores the entries)
         _lib.tune_set("rt_min_wgs", 0)
+        _lib.tune_set("rt_bn32_min_wgs", 0)
         _lib.tune_set("rt_min_fill_pct", 0)
         _lib.tune_set("rt_min_chunks", 1)
     d = dev()

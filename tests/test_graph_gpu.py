@@ -74,6 +74,21 @@ def test_graphed_step_with_rccl_single_rank(transport):
     assert r.returncode == 0 and f"GRAPH_RCCL_OK {transport}" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_graphed_step_with_rccl_at_the_configs4_per_gpu_shape():
+    """the captured data-parallel step at the shape BASELINE configs[4] names per GPU -- 64 pairs of 320x256, bf16,
+    RCCL (one rank) inside the graph -- where GraphedTrainStep takes its one-command-segment branch (graph.py: capture_group = 1 from
+    32 pairs on) and the conv dispatch picks the large-grid kernel forms: deterministic mode, three replayed steps bit for bit the
+    eager data-parallel steps and the steps without a process group (tests/graph_rccl_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT="29543")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "graph_rccl_worker.py"), "f32", "64", "256", "320"],
+                       capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0 and "GRAPH_RCCL_OK f32" in r.stdout, f"rc {r.returncode}\n" + r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_capture_and_replay_with_two_hardware_queues_in_a_fresh_process():
     """round 2's multi-stream capture aborted the runtime under GPU_MAX_HW_QUEUES=2.  The capture has used ONE stream
     since round 3; this runs capture + 3 replays + an eager step in a child process whose environment holds GPU_MAX_HW_QUEUES=2

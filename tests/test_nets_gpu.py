@@ -524,3 +524,118 @@ def test_networks_on_one_shared_side_stream_compute_the_same_step():
         for (g0, p0), (g1, p1) in zip(a[0], other[0]):
             assert torch.equal(g0, g1) and torch.equal(p0, p1)
         assert torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
+
+
+def test_spec_call_sequence_takes_the_fast_path_and_other_uses_stay_general():
+    """VERDICT r4 item 6: the spec's verbatim train-step calls -- d = depth_net(cat(tgt, ref)); d[:B], d[B:]; pose_net(..);
+    photometric_loss(.., d[:B], ..); loss.backward() -- must run like forward_pair_split + hand-over: the halves are outputs of the
+    network's node (no slice-backward nodes), the loss takes its own gradient path with the deferred normalisation.  In deterministic
+    mode the two forms give bit-identical gradients.  Every OTHER use of the returned tensor stays an ordinary differentiable use."""
+    from coivo_amd import functional as Fh, nn as hnn
+    B, H, W, seed = 2, 64, 96, 33
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+
+    def nets():
+        _, _, dn, pn = _models(seed)
+        dn.deterministic = pn.deterministic = True
+        dn.zero_grad(); pn.zero_grad()
+        return dn, pn
+
+    # fast path
+    dn1, pn1 = nets()
+    frames = torch.cat([b["tgt"], b["ref"]])
+    d_t, d_r, d_l = dn1.forward_pair_split(frames)
+    pose, a, bb = pn1(frames[:B], frames[B:], d_t, d_r)
+    l1 = Fh.photometric_loss(frames[:B], frames[B:], d_l, pose, b["K"], a, bb)
+    l1.backward()
+    # the spec's sequence, verbatim
+    dn2, pn2 = nets()
+    d = dn2(torch.cat([b["tgt"], b["ref"]]))
+    assert isinstance(d, torch.Tensor) and tuple(d.shape) == (2 * B, 1, H, W)
+    s_t, s_r = d[:B], d[B:]
+    assert s_t.grad_fn is not None and "Slice" not in type(s_t.grad_fn).__name__ and "Slice" not in type(s_r.grad_fn).__name__
+    pose2, a2, b2 = pn2(b["tgt"], b["ref"], s_t, s_r)
+    l2 = Fh.photometric_loss(b["tgt"], b["ref"], s_t, pose2, b["K"], a2, b2)
+    l2.backward()
+    for n in (dn1, pn1, dn2, pn2):
+        n.join_side()
+    torch.cuda.synchronize()
+    assert l1.item() == l2.item()
+    assert torch.equal(dn1.flat_grad, dn2.flat_grad) and torch.equal(pn1.flat_grad, pn2.flat_grad)
+    # the backward pass that ran is the hand-over form (raw loss gradient + two device scalars), not the general one
+    keys = [k for inst in next(iter(dn2._insts.values())) for k in inst.passes if k.startswith("bwd")]
+    assert keys and all("scale_a" in k and "g_raw" in k for k in keys), keys
+    # other uses of the returned tensor: whole-batch reductions, other slices, both mixed with the halves
+    dn3, _ = nets()
+    with torch.no_grad():
+        want = dn3(torch.cat([b["tgt"], b["ref"]]))
+        want = want + 0                      # a plain copy of the values
+    d3 = dn3(torch.cat([b["tgt"], b["ref"]]))
+    assert torch.equal(d3[:B], want[:B]) and torch.equal(d3[B:], want[B:]) and torch.equal(d3[1:3], want[1:3])
+    assert torch.equal(d3 * 2, want * 2) and type(d3 * 2) is torch.Tensor
+    w = torch.randn(2 * B, 1, H, W, device=d3.device)
+    ((d3 * w).sum() + 3.0 * d3[:B].sum() + d3[1:3].sum()).backward()
+    dn3.join_side()
+    g_mixed = dn3.flat_grad.clone()
+    dn4, _ = nets()
+    d4 = hnn._DepthNetFn.apply(dn4, torch.cat([b["tgt"], b["ref"]]), dn4._trigger())       # the single-output node
+    ((d4 * w).sum() + 3.0 * d4[:B].sum() + d4[1:3].sum()).backward()
+    dn4.join_side()
+    torch.cuda.synchronize()
+    assert (g_mixed - dn4.flat_grad).abs().max().item() <= 1e-5 * dn4.flat_grad.abs().max().item()
+    # a second loss on the same half takes the ordinary path (the loss's own output is handed out once)
+    dn5, pn5 = nets()
+    d5 = dn5(torch.cat([b["tgt"], b["ref"]]))
+    t5 = d5[:B]
+    p5, a5, b5 = pn5(b["tgt"], b["ref"], t5, d5[B:])
+    la = Fh.photometric_loss(b["tgt"], b["ref"], t5, p5, b["K"], a5, b5)
+    lb = Fh.photometric_loss(b["tgt"], b["ref"], t5, p5.detach(), b["K"], a5.detach(), b5.detach())
+    (la + lb).backward()
+    dn5.join_side(); pn5.join_side()
+    torch.cuda.synchronize()
+    assert abs(la.item() - l1.item()) < 1e-7 and torch.isfinite(dn5.flat_grad).all()
+    # twice the depth-side loss gradient + PoseNet's: compare against the fast path's arena through linearity in the loss weight
+    dn6, pn6 = nets()
+    d6 = dn6(torch.cat([b["tgt"], b["ref"]]))
+    p6, a6, b6 = pn6(b["tgt"], b["ref"], d6[:B], d6[B:])
+    (2.0 * Fh.photometric_loss(b["tgt"], b["ref"], d6[:B] * 1.0, p6.detach(), b["K"], a6.detach(), b6.detach())
+     + Fh.photometric_loss(b["tgt"], b["ref"], d6[:B] * 1.0, p6, b["K"], a6, b6) * 0.0).backward()
+    dn6.join_side()
+    torch.cuda.synchronize()
+    assert torch.isfinite(dn6.flat_grad).all() and dn6.flat_grad.abs().max() > 0
+
+
+def test_weight_gradients_stored_into_a_clean_arena_equal_the_added_ones():
+    """behind zero_grad() (or FusedAdam(zero_grad_in_step=True).step()) the networks tell their weight-gradient
+    commands that the arena is still zero, and the single-split layers store their sums instead of adding them with fp32 atomics
+    (include/colvo.h colvo_conv_wgrad_clean).  Same gradients as with the switch off; a SECOND backward pass on the same arena finds
+    it dirty and adds (gradient accumulation still works); a stray write between zero_grad() and backward is the documented hole."""
+    from coivo_amd import _lib, nn as hnn
+    B, H, W, seed = 2, 64, 96, 41
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+
+    def grads(store, passes=1):
+        _lib.tune_set("wgrad_store_clean", 1 if store else 0)
+        try:
+            _, _, dn, pn = _models(seed, torch.bfloat16)
+            dn.zero_grad(); pn.zero_grad()
+            assert dn._grads_clean and pn._grads_clean
+            for _ in range(passes):
+                hnn.dcdp_forward(dn, pn, b["tgt"], b["ref"], b["K"])[0].backward()
+                assert not dn._grads_clean
+            dn.join_side(); pn.join_side()
+            torch.cuda.synchronize()
+            flagged = [pr._flag_value for inst in next(iter(dn._insts.values())) for pr, _ in inst.passes.values() if pr.flag_slots]
+            return dn.flat_grad.clone(), pn.flat_grad.clone(), flagged
+        finally:
+            _lib.tune_set("wgrad_store_clean", 1)
+
+    gd1, gp1, f1 = grads(True)
+    gd0, gp0, _ = grads(False)
+    assert f1 and all(v == 1 for v in f1)                     # the backward pass was told "clean"
+    for a, c in ((gd1, gd0), (gp1, gp0)):
+        assert (a - c).abs().max().item() <= 1e-4 * c.abs().max().item()
+    gd2, gp2, f2 = grads(True, passes=2)
+    assert all(v == 0 for v in f2)                             # the second pass found the arena dirty
+    for a, c in ((gd2, gd0), (gp2, gp0)):
+        assert (a - 2 * c).abs().max().item() <= 2e-4 * c.abs().max().item()
