@@ -50,6 +50,12 @@ namespace tune {
                              "19.0 -> 18.8 at 16 (1280) with the step 0.7 % slower")                                                    \
     X(rt_min_fill_pct, 60, "... and only where the 16x16 tiling covers at most 100/this times the image (32x40 maps: 83 %, 16x20: 62 %)") \
     X(rt_min_chunks, 2, "... and the layer has at least this many 32-channel chunks")                                                 \
+    X(rt_wgs_per_cu, 0, "... 0: one tile per workgroup (default).  n > 0: persistent grid of n workgroups per CU (+1 for the 32-channel "  \
+                        "form), each walking consecutive tiles with the next tile's loads in flight under the current tile's MFMAs -- "  \
+                        "measured SLOWER at 64 frames (us, one tile -> persistent: enc2b 35.7 -> 39.4, enc3b 32.6 -> 39.3, iconv4 52.0 "  \
+                        "-> 64.0, iconv3 52.0 -> 57.6, iconv2 55.7 -> 59.1; 32 pairs 3.40 -> 3.45 ms per step): a static split of "      \
+                        "768-1280 tiles over 512 slots leaves a quarter of them idle where the hardware's own dispatcher fills them")     \
+    X(rt_tiles_per_wg, 0, "... tests: force this many consecutive tiles per workgroup (0: from rt_wgs_per_cu)")                       \
     X(xcd_remap, 1, "XCD-contiguous 1-D grids (step +4.3 % without)")                                                               \
     X(lds_aware_tiles, 1, "tile shapes / padded LDS row pitch chosen against ds_read_b128 bank conflicts")                          \
     X(lds_tile_max_pad, 8, "... at most this many padding pixels per patch row")                                                    \

@@ -81,7 +81,7 @@ def test_config1_bf16_depth_l1_and_loss(oracle_step):
             f.write(line + "\n")
     # about 3 x what the bench line reports for this batch ('depth_l1_vs_oracle': mean_rel 1.1e-3 in rounds 3-4); round 4 allowed 1e-2
     assert rel < 3.5e-3
-    assert abs(loss.item() - o32["loss"]) < 1e-3
+    assert abs(loss.item() - o32["loss"]) < 3e-4          # (observed 4.4e-5 on a loss of 0.049; round 4 allowed 2e-3)
     og = dict(o32["grads"])
     for net, tag, names in ((dn, "depth.", ("enc3b.weight", "iconv3.weight", "up1.weight", "head.weight")),
                             (pn, "pose.", ("conv2.weight", "conv6.weight"))):

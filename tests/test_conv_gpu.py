@@ -123,7 +123,7 @@ def _both_kernel_forms(request):
     in the library's tuning table (colvo_tune_set, csrc/tuning.h) to reach them -- the other half exercises the one-tile kernels
     on the same shapes."""
     from coivo_amd import _lib
-    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks")
+    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg")
     saved = {n: _lib.tune_get(n) for n in names}
     if "form1" in request.node.name:
         _lib.tune_set("dgrad_up2_min_wgs", 0)
@@ -137,6 +137,10 @@ def _both_kernel_forms(request):
         _lib.tune_set("rt_bn32_min_wgs", 0)
         _lib.tune_set("rt_min_fill_pct", 0)
         _lib.tune_set("rt_min_chunks", 1)
+        # ... bf16 runs with workgroups that WALK three consecutive tiles (across channel tiles, tile rows and images; the last
+        # workgroup a shorter walk), f32 runs with one tile per workgroup, the production setting
+        params = getattr(getattr(request.node, "callspec", None), "params", {})
+        _lib.tune_set("rt_tiles_per_wg", 3 if params.get("dtype") == torch.bfloat16 else 0)
     yield
     for n, v in saved.items():
         _lib.tune_set(n, v)
