@@ -113,6 +113,7 @@ SIGNATURES = {
     "colvo_pose_head_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp]),
     "colvo_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
     "colvo_adam_step_t": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
+    "colvo_cast_f32_bf16": (_i, [_vp, _vp, _sz, _i, _vp]),
     "colvo_zero": (_i, [_vp, _sz, _vp]),
     "colvo_frames_u8_to_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "colvo_read_npy_u8_frames": (_i, [_vp, _i, _i, _i, _vp, _i]),

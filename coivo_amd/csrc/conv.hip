@@ -1200,18 +1200,26 @@ __global__ __launch_bounds__(NT, 2) void k_conv_q(const ConvK a) {
 // setup, weight staging, two exposed memory round trips) times ~10^4 workgroups.  Here a workgroup stages its weight
 // slab ONCE, then loops over output tiles (grid-stride), prefetching the next tile's patch into registers while the
 // current tile's MFMAs and epilogue run.  The fp32 output staging tile aliases the patch region.
-template <typename T, int BN, int NG>
+// S2 (round 5): the same for STRIDE-2 single-chunk layers (enc2a, PoseNet's conv2 / conv3 at large batch).  The one-tile kernel
+// spends such a workgroup's life on its set-up -- nine staged granules per thread, each with its own address arithmetic, for ONE
+// chunk: 42 % of the wave cycles are instruction issue at 9 % MFMA-pipe busy (profiles/r5_conv_pmc_b64.json) -- and MIOpen's
+// implicit GEMM beats it there (enc2a at 64 frames 54.9 vs 32.4 us, profiles/r5_conv_layers_b64.csv).  Here the per-thread patch
+// coordinates are tile-invariant, the 17 x 33-pixel patch of the NEXT tile is in flight (nine registers) under the current tile's
+// MFMAs, the pixel pitch is the stride-2 one (conv_common.h pitch_bytes_s2) and a 64-wide channel tile reads every input pixel once.
+template <typename T, int BN, int NG, bool S2 = false>
 __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, uint32_t m_tpi, uint32_t m_tx) {
     constexpr int G = TT<T>::G, ES = TT<T>::ES;
     constexpr int NGR = 9 * NG;
     constexpr int STEPS = (NGR + 3) / 4;
     constexpr int WROW = wrow_bytes(STEPS * 4);
-    constexpr int PIXP = pitch_bytes(NG * 16);
+    constexpr int PIXP = S2 ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
+    constexpr int SS = S2 ? 2 : 1;
     constexpr int NF = BN / 16;
     constexpr int OUTP = BN + 4;
     constexpr int WTOT = BN * STEPS * 4;
     constexpr int WIT = (WTOT + NT - 1) / NT;
-    constexpr int PPF = 3;                          // stride 1: patch <= 10 x 18 pixels x NG <= 768 granules
+    // staged patch granules per thread -- stride 1: <= 10 x 18 pixels x NG <= 768; stride 2: <= 17 x 33 x NG <= 2304 (host-checked)
+    constexpr int PPF = S2 ? (17 * 33 * NG + NT - 1) / NT : 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sW = smem;
     char* sP = smem + BN * WROW;
@@ -1220,7 +1228,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.y * BN;
-    const int PH = a.toh + 2, PW = a.tow + 2;
+    const int PH = (a.toh - 1) * SS + 3, PW = (a.tow - 1) * SS + 3;
     const int npix = a.toh * a.tow;
     const int ptotal = PH * PW * NG;
     const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -1252,7 +1260,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
         int p = wave * 32 + mf * 16 + l15;
         if (p >= npix) p = 0;
         const int oy = mdiv(p, a.m_tow), ox = p - oy * a.tow;
-        pbase[mf] = (oy * a.pwp + ox) * PIXP;
+        pbase[mf] = ((oy * SS) * a.pwp + ox * SS) * PIXP;
     }
     // patch granules of this thread: (pixel, granule) inside the patch are tile-invariant
     int ppy[PPF], ppx[PPF], pcg[PPF];
@@ -1288,7 +1296,7 @@ __global__ __launch_bounds__(NT) void k_conv3x3_res(const ConvK a, int ntiles, u
     };
     u32x4 pv[PPF];
     auto load_p = [&](const TileO& o) {
-        const int iy0 = o.oy0 - 1, ix0 = o.ox0 - 1;
+        const int iy0 = o.oy0 * SS - 1, ix0 = o.ox0 * SS - 1;
         const int soff = o.b * img_in;
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
@@ -1459,22 +1467,61 @@ int launch_conv(const ConvK& k, int B, hipStream_t s) {
     return launch_conv_tail<T, BN, NG, DEPTH, false>(k, B, s);
 }
 
-template <typename T, int BN, int NG>
+template <typename T, int BN, int NG, bool S2 = false>
 int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     constexpr int STEPS = (9 * NG + 3) / 4;
-    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = pitch_bytes(NG * 16);
-    const int PH = k.toh + 2;
+    constexpr int WROW = wrow_bytes(STEPS * 4), PIXP = S2 ? pitch_bytes_s2(NG * 16) : pitch_bytes(NG * 16);
+    const int PH = (k.toh - 1) * (S2 ? 2 : 1) + 3;
     const size_t p_or_out = std::max((size_t)PH * k.pwp * PIXP, (size_t)BM * (BN + 4) * 4);
     const size_t lds = (size_t)BN * WROW + p_or_out;
+    COLVO_CHECK_ARG(lds <= 160 * 1024, "conv (weights-resident): tile needs %zu bytes of LDS", lds);
+    static bool configured = false;             // per instantiation
+    if (lds > 48 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_res<T, BN, NG, S2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("conv: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        configured = true;
+    }
     const int ntiles = k.tiles_x * k.tiles_y * B;
-    const int res_wg_per_cu = (int)TUNE(res_wg_per_cu);   // tuning knob
-    int gx = 256 * res_wg_per_cu;               // workgroups per CU, each walking ntiles / gx tiles
+    // workgroups per CU, each walking ntiles / gx tiles (stride 2: as many as its LDS footprint lets a CU hold)
+    const int per_cu = S2 ? std::max(1, std::min((int)TUNE(res_wg_per_cu), (int)(160 * 1024 / lds))) : (int)TUNE(res_wg_per_cu);
+    int gx = 256 * per_cu;
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
-    colvo::launch((k_conv3x3_res<T, BN, NG>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
+    colvo::launch((k_conv3x3_res<T, BN, NG, S2>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
                        mdiv_magic(k.tiles_x));
     COLVO_CHECK_LAUNCH("k_conv3x3_res");
     return 0;
+}
+
+// stride-2 single-chunk layers on large grids: weights-resident persistent kernel with the next tile's patch in flight (see
+// k_conv3x3_res).  -1: the layer does not qualify.
+template <typename T>
+int try_launch_conv_res_s2(const ConvK& k, int B, int ng, hipStream_t s) {
+    if (!TUNE(res_s2) || k.g.stride != 2 || k.nsplit != 0 || k.pool2 || k.g.C[1] != 0 || k.g.mode[0] != MODE_DIRECT) return -1;
+    if (k.g.C[0] != ng * TT<T>::G || k.accumulate || k.mask) return -1;       // one chunk; forward only (its input gradient is k_dgrad_s2)
+    const long long src_bytes = (long long)B * k.g.Hs[0] * k.g.Ws[0] * k.g.C[0] * TT<T>::ES;
+    const long long out_bytes = (long long)B * k.Ho * k.Wo * k.N * TT<T>::ES;
+    const long long tpi = (long long)k.tiles_x * k.tiles_y;
+    if (src_bytes >= 0x40000000LL || out_bytes >= 0x40000000LL || tpi < 2 || k.tiles_x < 2 || tpi * tpi * B >= 0x100000000LL) return -1;
+    if (tpi * B < TUNE(res_s2_min_tiles)) return -1;
+    const long ptotal = (long)((k.toh - 1) * 2 + 3) * ((k.tow - 1) * 2 + 3) * ng;
+    if (ptotal > (long)((17 * 33 * ng + NT - 1) / NT) * NT) return -1;        // (what the kernel's register prefetch holds)
+    if (k.N >= 64) {
+        switch (ng) {
+            case 4: return launch_conv_res<T, 64, 4, true>(k, B, s);
+            case 2: return launch_conv_res<T, 64, 2, true>(k, B, s);
+            default: return -1;
+        }
+    }
+    if (k.N >= 32) {
+        switch (ng) {
+            case 4: return launch_conv_res<T, 32, 4, true>(k, B, s);
+            case 2: return launch_conv_res<T, 32, 2, true>(k, B, s);
+            default: return -1;
+        }
+    }
+    return -1;
 }
 
 template <typename T, int BN>
@@ -1565,6 +1612,10 @@ int launch_conv_t(ConvK k, int B, bool even, hipStream_t s) {
         }
     }
     set_tile(k, pick_tile(k.Ho, k.Wo, k.g.stride, even, 128, true));
+    if (k.g.stride == 2) {
+        const int r = try_launch_conv_res_s2<T>(k, B, ng, s);
+        if (r >= 0) return r;
+    }
     // Output-channel tile: 64 wide by default; when that grid would leave CUs idle (deep, low-resolution layers at small
     // batch) use 32 -- twice the workgroups, each staging half the weight slab per chunk (the chunk is LDS-bound).
     const long tiles = (long)k.tiles_x * k.tiles_y * B;

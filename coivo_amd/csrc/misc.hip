@@ -1432,6 +1432,48 @@ extern "C" int colvo_zero_multi(void* const* ptrs, const size_t* bytes, int coun
     return 0;
 }
 
+// ---- gradient transport in bf16 (ddp.GradBuckets(transport_dtype=bfloat16)): fp32 slice <-> bf16 staging slice ----
+// (round 4 staged through Tensor.copy_, i.e. at::native kernels inside the data-parallel step; same RNE rounding here)
+__global__ __launch_bounds__(NT) void k_cast_f32_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * NT * 4;
+    for (size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const float4 v = *reinterpret_cast<const float4*>(src + i);
+            uint2 o;
+            o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+            o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+            *reinterpret_cast<uint2*>(dst + i) = o;
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+        }
+    }
+}
+__global__ __launch_bounds__(NT) void k_cast_bf16_f32(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * NT * 4;
+    for (size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n) {
+            const uint2 v = *reinterpret_cast<const uint2*>(src + i);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(bf2f((uint16_t)(v.x & 0xFFFFu)), bf2f((uint16_t)(v.x >> 16)),
+                                                              bf2f((uint16_t)(v.y & 0xFFFFu)), bf2f((uint16_t)(v.y >> 16)));
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = bf2f(src[j]);
+        }
+    }
+}
+
+extern "C" int colvo_cast_f32_bf16(const float* src, void* dst, size_t n, int to_bf16, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(src && dst, "colvo_cast_f32_bf16: null pointer argument");
+    // (to_bf16 = 0: `src` is the bf16 buffer and `dst` the fp32 one -- the argument order stays source, destination)
+    COLVO_CHECK_ARG((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "colvo_cast_f32_bf16: buffers must be 16-byte aligned");
+    if (n == 0) return 0;
+    unsigned blocks = nblk((n + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    if (to_bf16) colvo::launch(k_cast_f32_bf16, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, src, (uint16_t*)dst, n);
+    else colvo::launch(k_cast_bf16_f32, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, (const uint16_t*)src, (float*)dst, n);
+    COLVO_CHECK_LAUNCH("k_cast_f32_bf16");
+    return 0;
+}
+
 extern "C" int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream) {
     COLVO_CHECK_ARG(ptr || bytes == 0, "colvo_zero: null pointer argument");
     if (bytes == 0) return 0;

@@ -28,6 +28,9 @@ namespace tune {
     X(depth2_min_chunks, 8, "... if the layer has at least this many 32-channel chunks")                                           \
     X(res_wg_per_cu, 4, "weights-resident persistent kernel (single-chunk layers): workgroups per CU")                              \
     X(res_min_tiles, 2048, "... selected from this many 128-pixel tiles on")                                                        \
+    X(res_s2, 1, "... its stride-2 form for single-chunk stride-2 layers (enc2a, PoseNet conv2 / conv3; round 5)")                   \
+    X(res_s2_min_tiles, 512, "... selected from this many 128-pixel tiles on (enc2a: 16 frames = 640 tiles 15.4 -> 13.3 us, 64 frames "   \
+                             "55.3 -> 35.7 us; MIOpen 13.3 / 32.4)")                                                                    \
     X(wide, 0, "512-thread / 256-pixel tiles: 10-20 % slower at 16 images, pays at several workgroups per CU; off")                 \
     X(wide_min_wgs, 192, "... minimum grid when on")                                                                                \
     X(wide_min_chunks, 2, "... minimum chunk count when on")                                                                        \

@@ -100,6 +100,20 @@ class GradBuckets:
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
 
+    @staticmethod
+    def _cast(src: torch.Tensor, dst: torch.Tensor, to_transport: bool) -> None:
+        """fp32 gradient slice <-> transport-dtype staging slice.  bf16 on the GPU: the library's own kernel (round 4 used
+        Tensor.copy_, i.e. at::native kernels inside the data-parallel step); anything else (CPU rehearsals, other dtypes): copy_."""
+        bf = dst if to_transport else src
+        f32 = src if to_transport else dst
+        if (src.is_cuda and bf.dtype == torch.bfloat16 and f32.dtype == torch.float32 and src.data_ptr() % 16 == 0
+                and dst.data_ptr() % 16 == 0):
+            from . import _lib
+            _lib.check(_lib.load().colvo_cast_f32_bf16(_lib.ptr(src), _lib.ptr(dst), src.numel(), int(to_transport), _lib.stream_ptr()),
+                       "colvo_cast_f32_bf16")
+        else:
+            dst.copy_(src)
+
     def _all_reduce(self, t: torch.Tensor):
         return self._pg.allreduce([t], self._sum)
 
@@ -169,7 +183,7 @@ class GradBuckets:
         sl = st.module.flat_grad[lo:hi]
         if st.staging is not None:
             buf = st.staging[lo:hi]
-            buf.copy_(sl)                # conversion on the stream the hook runs on; the collective is ordered after it
+            self._cast(sl, buf, True)    # conversion on the stream the hook runs on; the collective is ordered after it
             self._pending.append((self._all_reduce(buf), sl, buf))
         else:
             self._pending.append((self._all_reduce(sl), None, None))
@@ -188,7 +202,7 @@ class GradBuckets:
         for work, sl, buf in self._pending:
             work.wait()
             if buf is not None:
-                sl.copy_(buf)
+                self._cast(buf, sl, False)
         self._pending.clear()
         for st in self.states:
             st.next, st.low, st.calls = 1, st.module.flat_grad.numel(), 0

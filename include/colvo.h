@@ -356,6 +356,10 @@ int colvo_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * hipGraph: the captured t would repeat at every replay -- use colvo_adam_step there. */
 int colvo_adam_step_t(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                       float lr, float beta1, float beta2, float eps, float grad_scale, int t, colvo_stream_t stream);
+/* fp32 <-> bf16 (round to nearest even) over n elements, 16-byte aligned buffers: the staging copies of a reduced-precision gradient
+ * transport (ddp.GradBuckets).  to_bf16 != 0: src fp32 -> dst bf16; 0: src bf16 -> dst fp32 (src is declared const float* for both). */
+int colvo_cast_f32_bf16(const float* src, void* dst, size_t n, int to_bf16, colvo_stream_t stream);
+
 /* Zero `bytes` bytes of device memory on `stream` (the gradient arenas, once per step). */
 int colvo_zero(void* ptr, size_t bytes, colvo_stream_t stream);
 /* Both networks' arenas in ONE launch each (a dependent launch costs ~2.7 us on MI355X before it does anything and the small

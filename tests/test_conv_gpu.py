@@ -75,6 +75,10 @@ CASES = [
     (2, 16, 20, 256, 256, False, False, 256, 1),  # concat, 16 chunks from two sources
     (2, 16, 20, 256, 0, False, False, 256, 1),    # 8 chunks
     (1, 8, 10, 288, 0, False, False, 64, 1),      # 9 (bf16) / 18 (f32) chunks: odd count on the two-chunk ring
+    # stride 2, ONE chunk (32 bf16 / 16 f32 channels): the stride-2 form of the weights-resident persistent kernel in the form2 runs
+    (3, 32, 48, 32, 0, False, False, 64, 2),      # 64-wide channel tile (bf16), several tiles per image and per workgroup
+    (2, 40, 56, 16, 0, False, False, 32, 2),      # f32: one chunk of 16; bf16: two-granule chunks; ragged tiles (20 x 28 outputs)
+    (5, 16, 32, 32, 0, False, False, 48, 2),      # N = 48 in a 64-wide (bf16) tile: rows beyond N read as zero
     # stride 1, direct sources: the register-tiled kernel (k_conv_rt) in the form2 runs -- 16 x 16 tiles x 64 / 32 channels
     (2, 32, 48, 64, 0, False, False, 64, 1),      # exact tiles, one 64-wide channel tile, 2 chunks
     (1, 48, 32, 64, 64, False, False, 128, 1),    # concat 64 + 64 (two-output input gradient, 64-wide tiles), two N tiles
@@ -123,7 +127,7 @@ def _both_kernel_forms(request):
     in the library's tuning table (colvo_tune_set, csrc/tuning.h) to reach them -- the other half exercises the one-tile kernels
     on the same shapes."""
     from coivo_amd import _lib
-    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg")
+    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg", "res_s2_min_tiles")
     saved = {n: _lib.tune_get(n) for n in names}
     if "form1" in request.node.name:
         _lib.tune_set("dgrad_up2_min_wgs", 0)
@@ -137,6 +141,7 @@ def _both_kernel_forms(request):
         _lib.tune_set("rt_bn32_min_wgs", 0)
         _lib.tune_set("rt_min_fill_pct", 0)
         _lib.tune_set("rt_min_chunks", 1)
+        _lib.tune_set("res_s2_min_tiles", 2)       # the stride-2 form of the weights-resident persistent kernel (single-chunk layers)
         # ... bf16 runs with workgroups that WALK three consecutive tiles (across channel tiles, tile rows and images; the last
         # workgroup a shorter walk), f32 runs with one tile per workgroup, the production setting
         params = getattr(getattr(request.node, "callspec", None), "params", {})
