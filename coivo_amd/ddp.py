@@ -74,8 +74,10 @@ class GradBuckets:
             # Four hardware queues are served at a time (streams.py): main + ONE shared weight-gradient stream + the library's
             # auxiliary one + RCCL's.  (Round 3 kept a side stream per network and switched the auxiliary one off instead: the
             # one-rank RCCL step 1.55 ms, now 1.39; developer switch COLVO_DDP_OWN_SIDE=1.)
+            self._shared_modules = None
             if _lib.dev_env("COLVO_DDP_OWN_SIDE") is None:
                 nn.share_side_stream(modules)
+                self._shared_modules = list(modules)
             if _lib.dev_env("COLVO_DDP_KEEP_AUX") is None:        # developer A/B switch (COLVO_DEV=1)
                 self._queue_claim = streams.claim_external_queue("rccl")
         self.transport_dtype = transport_dtype
@@ -96,7 +98,8 @@ class GradBuckets:
         # the Python wrapper's argument checks, rank lookups and logging hooks are ~10 us per call on the host, and an 8-pair step
         # issues seven of them from inside its backward pass, where the host is the bottleneck (one-rank RCCL step at 8 pairs 1.39 ms
         # against 1.30 plain; at 32 / 64 pairs the overhead is 2.2 / 1.6 %).
-        self._pg = process_group if process_group is not None else dist.distributed_c10d._get_default_group()
+        # (the group object is looked up per call, not kept: a reference held here outlives destroy_process_group() and the backend's
+        # threads are then torn down at interpreter exit -- "terminate called without an active exception", one gloo worker in three)
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
 
@@ -115,7 +118,8 @@ class GradBuckets:
             dst.copy_(src)
 
     def _all_reduce(self, t: torch.Tensor):
-        return self._pg.allreduce([t], self._sum)
+        pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
+        return pg.allreduce([t], self._sum)
 
     # ---- the spec's batch normalisation under data parallelism ------------------------------------ #
     def _install_reducer(self, on: bool) -> None:
@@ -228,6 +232,10 @@ class GradBuckets:
             st.module.grad_ready_hook = None
         self.attached = False
         self._install_reducer(False)
+        if getattr(self, "_shared_modules", None):
+            from . import nn
+            nn.unshare_side_stream(self._shared_modules)      # each network back on its own weight-gradient stream
+            self._shared_modules = None
         if self._queue_claim is not None:
             self._queue_claim.release()
             self._queue_claim = None

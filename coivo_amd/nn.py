@@ -94,9 +94,28 @@ def share_side_stream(modules) -> Optional["torch.cuda.Stream"]:
             m.join_side()
             if m._side is not None:
                 shared.wait_stream(m._side)        # (work a hook may still have in flight there)
+            if not hasattr(m, "_side_before_sharing"):
+                m._side_before_sharing = m._side   # what unshare_side_stream() gives back (created early: it keeps its hardware queue)
             m._side = shared
     streams.networks_share_side_stream(True)
     return shared
+
+
+def unshare_side_stream(modules) -> None:
+    """Undo share_side_stream(): every network gets the side stream it had before (ddp.GradBuckets.detach() left the
+    networks on one stream and the policy's flag set; streams.configure() / reset() cleared the flag while the networks still shared).
+    A network that had none yet creates its own at its next backward pass."""
+    from . import streams
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for m in modules:
+        if isinstance(m, _ArenaModule) and hasattr(m, "_side_before_sharing"):
+            m.join_side()
+            old = m.__dict__.pop("_side_before_sharing")
+            if old is not None and m._side is not None and old is not m._side:
+                old.wait_stream(m._side)           # (work still in flight on the shared stream stays ahead of this network's next pass)
+            m._side = old
+    streams.networks_share_side_stream(False)
 
 
 class _ArenaModule(nn.Module):

@@ -515,6 +515,20 @@ def test_networks_on_one_shared_side_stream_compute_the_same_step():
             out.append((dn.flat_grad.clone(), pn.flat_grad.clone()))
             opt.step()
         torch.cuda.synchronize()
+        if share_at == 1:
+            # un-sharing (what GradBuckets.detach() does) gives every network its own stream back and clears the policy's
+            # flag -- the queue budget follows the real stream layout again -- and the next step still computes the same
+            own_before = pn.__dict__.get("_side_before_sharing")
+            hnn.unshare_side_stream([dn, pn])
+            assert dn._side is not pn._side and (own_before is None or pn._side is own_before)
+            claim = streams.claim_external_queue("test")
+            assert streams.aux_side_streams() == 0                 # a side stream per network again: no room beside the auxiliary one
+            claim.release()
+            opt.zero_grad()
+            hnn.dcdp_forward(dn, pn, None, None, d["K"], frames=frames)[0].backward()
+            dn.join_side(); pn.join_side()
+            torch.cuda.synchronize()
+            assert torch.isfinite(dn.flat_grad).all() and dn.flat_grad.abs().max() > 0
         streams.reset()
         return out, dn.flat_param.clone(), pn.flat_param.clone(), (dn, pn)
 
