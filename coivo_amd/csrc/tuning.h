@@ -46,9 +46,11 @@ namespace tune {
                           "workgroups of 256x320 frames it loses 3-6 % of the pass)")                                               \
     X(quad_max_chunks, 4, "... and at most this many chunks (deeper layers keep the two-chunk ring)")                               \
     X(conv_rt, 1, "register-tiled stride-1 kernel (k_conv_rt, csrc/conv_rt.hip: 16x16 pixels x 64/32 channels, 4x4 fragments per wave)") \
-    X(rt_min_wgs, 512, "... from this many of its workgroups on (64 frames, us fwd / dgrad, one-tile -> this: enc2b 42.4 / 52.6 -> 35.6 / "  \
+    X(rt_min_wgs, 1024, "... from this many of its workgroups on (64 frames, us fwd / dgrad, one-tile -> this: enc2b 42.4 / 52.6 -> 35.6 / "  \
                        "41.9, iconv3 65.9 / 52.3 -> 52.8 / 42.3, iconv4 61.8 / 43.6 -> 51.9 / 35.4, enc3b 36.6 / 43.4 -> 32.3 / 35.5, "   \
-                       "enc4b 37.2 / 42.1 -> 35.4 / 38.2; at 16 frames its 128-320-workgroup grids lose 0.5-1.8 us per layer)")          \
+                       "enc4b 37.2 / 42.1 -> 35.4 / 38.2; at 16 frames its 128-320-workgroup grids lose 0.5-1.8 us per layer; 512 -> 1024: "   \
+                       "the 640 workgroups of iconv3's two input gradients at 16 frames = 1.25 rounds of the 512 slots, step -0.6...1 % "  \
+                       "at 8 pairs, level at 32 / 64 where it moves iconv4's 768)")                                                    \
     X(rt_bn32_min_wgs, 2048, "... the 32-channel form (iconv2 forward) from this many on: 75.9 -> 59.5 us at 64 frames (5120 workgroups), "  \
                              "19.0 -> 18.8 at 16 (1280) with the step 0.7 % slower")                                                    \
     X(rt_min_fill_pct, 60, "... and only where the 16x16 tiling covers at most 100/this times the image (32x40 maps: 83 %, 16x20: 62 %)") \
