@@ -63,15 +63,18 @@ constexpr int DH = PH + 2, DW = PW + 2;                                      // 
 // through v_mov copies at the join -- reads of MFMA results in front of the guard (tools/isa_check_mfma.py).
 // Three workgroups per CU (168 VGPRs; the MODE 2 form would spill): with the grid at 3 x 256 the HEAD form's step is 0.7 % shorter
 // than with two (1.392 against 1.403 ms, same box; 768 workgroups at two per CU: 1.420 -- the third waits for a slot)
+#ifndef COLVO_BWD16_HEAD_WGS
+#define COLVO_BWD16_HEAD_WGS 3
+#endif
 template <int MODE>
-__global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a) {
+__global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WGS : 4) void k_bwd16(const Bwd16K a) {
     constexpr bool HEAD = MODE >= 1, headw = MODE == 2;
     __shared__ __attribute__((aligned(16))) char sG[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sX[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sW[16 * WROWB];
     __shared__ float sdb[NT];
-    __shared__ __attribute__((aligned(16))) float sD[HEAD ? DH * DW : 4];       // d(pre) around the patch
-    __shared__ __attribute__((aligned(16))) float sWh[HEAD ? 9 * 16 : 4];       // head weights [tap][c]
+    __shared__ __attribute__((aligned(16))) uint32_t sDs[HEAD ? DH * DW : 4];   // d(pre) around the patch, split: bf16 hi | bf16 lo << 16
+    __shared__ __attribute__((aligned(16))) float sD[MODE == 2 ? DH * DW : 4];  // ... and as fp32 for the head's own weight gradient
     __shared__ __attribute__((aligned(16))) char sY[MODE == 2 ? NPIX * PIXB : 16];   // the layer's output patch (head weight gradient)
     float hb = 0.0f;                                                            // (dWh itself: acc[5], rows c = 4 kg + r, column t = l15)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,9 +88,6 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
         st16(sW + ci * WROWB + tap * 32 + half * 16, v);
     }
 
-    if constexpr (HEAD) {
-        if (tid < 9 * 16) sWh[tid] = a.head_w[tid];
-    }
     const int t_begin = blockIdx.x * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -147,50 +147,93 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
             if (s_which[it] == 0) {
-                if constexpr (!HEAD) st16(sG + s_lds[it], pv[it]);
-                else if constexpr (headw) st16(sY + s_lds[it], pv[it]);
+                st16(sG + s_lds[it], pv[it]);                     // HEAD: the layer's output y -- make_g() turns it into the gradient in place
+                if constexpr (headw) st16(sY + s_lds[it], pv[it]);
             }
             else if (s_which[it] == 1) st16(sX + s_lds[it], pv[it]);
         }
         if constexpr (HEAD) {
-            if (tid < DH * DW) sD[tid] = dpv;
+            if (tid < DH * DW) {
+                const uint16_t hi = f2bf(dpv);
+                sDs[tid] = (uint32_t)hi | ((uint32_t)f2bf(dpv - bf2f(hi)) << 16);
+                if constexpr (headw) sD[tid] = dpv;
+            }
         }
     };
-    // (this thread's granules all have channel half tid & 1: its 9 x 8 head weights live in registers -- from LDS they were 72 more
-    // LDS reads per granule in a kernel that is VALU / LDS-issue bound)
-    float whr[9][8];
+    // HEAD: the gradient g[p][c] = (y[p][c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t] on the 180 patch pixels, rounded to bf16 as
+    // csrc/misc.hip k_depth_head_dgrad16 stores it -- BY MFMA (round 5).  Round 4 made it on the VALU, a thread per staged granule: 9
+    // d(pre) reads and 72 fp32 FMAs per granule from 72 registers of head weights -- 195 of the tile loop's 324 VALU instructions in a
+    // kernel that is issue-bound, and the registers that kept the MFMA phases from being pipelined.  As a product it is tiny:
+    // [16 c] x [K = 9 taps] per pixel; both factors are fp32, so each is split into bf16 hi + lo and K carries the three products that
+    // matter -- k = 0..8 hi_w hi_d, 9..17 hi_w lo_d, 18..26 lo_w hi_d (27..31 zero): the sum is the fp32 product to ~2^-16 relative
+    // (lo_w lo_d and the second-order remainders are dropped), far inside the bf16 rounding the result gets.  ONE MFMA per 16 patch
+    // pixels, 3 per wave and tile; the weight operand lives in 4 registers; the d(pre) operand is gathered from the split patch in
+    // LDS (8 reads + 4 v_perm per fragment); y is read from / g written to the SAME 8 bytes of sG by the same lane.
+    //   The 180 patch pixels are cut into 12 fragments of FIFTEEN (lane 15 of a fragment idles): fragment 3 w + j of wave w is the 5 x 3
+    //   block (rows 5 (w >> 1) .., columns 9 (w & 1) + 3 j ..) of the 10 x 18 patch, lane l15 its pixel (l15 / 3, l15 % 3) -- so that a
+    //   lane's LDS addresses are the same registers for j = 0, 1, 2 with the fragment as an immediate offset (with 16 consecutive pixels
+    //   per fragment the row wrap differs from lane to lane: 24 address additions per tile).
+    u32x4 hA = u32x4{0u, 0u, 0u, 0u};
+    int g_da[8];                                                   // byte address in sDs of this lane's 8 k-slots, fragment j = 0
+    uint32_t g_sel[4];
+    int g_ya = 0;                                                  // byte address in sG of this lane's 4 channels, fragment j = 0
+    const bool g_on = l15 < 15;
     if constexpr (HEAD) {
+        const int lp = l15 < 15 ? l15 : 14;                        // (the idle lane repeats its neighbour's reads)
+        const int gpy = 5 * (wave >> 1) + lp / 3, gpx = 9 * (wave & 1) + lp % 3;
+        g_ya = (gpy * PW + gpx) * PIXB + kg * 8;
+        uint32_t hv[4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int i2 = 0; i2 < 4; ++i2) {
+            uint32_t pair = 0u, sel = 0u;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) whr[t][j] = a.head_w[t * 16 + (tid & 1) * 8 + j];
-    }
-    // HEAD: the gradient granules of this thread from its y granules (still in registers) and the d(pre) patch in LDS:
-    // g[c] = (y[c] > 0) * sum_t head_w[t][c] * dpre[p + 1 - t], rounded to bf16 as csrc/misc.hip k_depth_head_dgrad16 stores it
-    auto make_g = [&]() {
-#pragma unroll
-        for (int it = 0; it < PPF; ++it) {
-            if (s_which[it] != 0) continue;
-            float d[9];
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) d[ky * 3 + kx] = sD[(s_py[it] + 2 - ky) * DW + s_px[it] + 2 - kx];
-            const unsigned yw[4] = {pv[it][0], pv[it][1], pv[it][2], pv[it][3]};
-            unsigned ow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v0 = 0.0f, v1 = 0.0f;
-#pragma unroll
-#ifdef COLVO_BWD16_LDS_WH           // developer A/B build only: head weights from LDS instead of registers
-                for (int t = 0; t < 9; ++t) { v0 += d[t] * sWh[t * 16 + s_half[it] * 8 + 2 * j]; v1 += d[t] * sWh[t * 16 + s_half[it] * 8 + 2 * j + 1]; }
-#else
-                for (int t = 0; t < 9; ++t) { v0 += d[t] * whr[t][2 * j]; v1 += d[t] * whr[t][2 * j + 1]; }
-#endif
-                const float y0 = bf2f((uint16_t)(yw[j] & 0xffffu)), y1 = bf2f((uint16_t)(yw[j] >> 16));
-                ow[j] = (unsigned)f2bf(y0 > 0.0f ? v0 : 0.0f) | ((unsigned)f2bf(y1 > 0.0f ? v1 : 0.0f) << 16);
+            for (int e = 0; e < 2; ++e) {
+                const int k = 8 * kg + 2 * i2 + e;
+                const int kk = k > 26 ? 26 : k;
+                const int part = kk / 9, t = kk - 9 * part;
+                const float w = a.head_w[t * 16 + l15];
+                const uint16_t hi = f2bf(w);
+                const uint16_t lo = f2bf(w - bf2f(hi));
+                const uint32_t val = k < 27 ? (uint32_t)(part == 2 ? lo : hi) : 0u;
+                pair |= val << (16 * e);
+                const int ky = t / 3, kx = t - 3 * ky;
+                g_da[2 * i2 + e] = ((gpy + 2 - ky) * DW + gpx + 2 - kx) * 4;
+                // v_perm_b32 byte selectors: element e comes from source word e (0: bytes 0..3, 1: bytes 4..7 of the pair), its hi half
+                // (bytes 0, 1) or, for the hi_w lo_d products, its lo half (bytes 2, 3)
+                const uint32_t b = 4u * e + (part == 1 ? 2u : 0u);
+                sel |= (b | ((b + 1u) << 8)) << (16 * e);
             }
-            st16(sG + s_lds[it], u32x4{ow[0], ow[1], ow[2], ow[3]});
+            hv[i2] = pair;
+            g_sel[i2] = sel;
+        }
+        hA = u32x4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    auto make_g = [&]() {
+        u32x4 bfr[3];
+        u32x2 yv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            uint32_t wd[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wd[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sDs) + g_da[i] + 12 * j);
+            bfr[j] = u32x4{__builtin_amdgcn_perm(wd[1], wd[0], g_sel[0]), __builtin_amdgcn_perm(wd[3], wd[2], g_sel[1]),
+                           __builtin_amdgcn_perm(wd[5], wd[4], g_sel[2]), __builtin_amdgcn_perm(wd[7], wd[6], g_sel[3])};
+            yv[j] = *reinterpret_cast<const u32x2*>(sG + g_ya + 3 * PIXB * j);
+        }
+        f32x4 gacc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            gacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hA), __builtin_bit_cast(bf16x8, bfr[j]), gacc[j], 0, 0, 0);
+        mfma_result_guard<bf16_t>(gacc);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            // bf16 > 0  <=>  its bits, read as a signed 16-bit integer, are > 0
+            const bool p0 = (int32_t)(yv[j][0] << 16) > 0, p1 = (int32_t)(yv[j][0] & 0xffff0000u) > 0;
+            const bool p2 = (int32_t)(yv[j][1] << 16) > 0, p3 = (int32_t)(yv[j][1] & 0xffff0000u) > 0;
+            u32x2 o;
+            o[0] = pack2bf(p0 ? gacc[j][0] : 0.0f, p1 ? gacc[j][1] : 0.0f);
+            o[1] = pack2bf(p2 ? gacc[j][2] : 0.0f, p3 ? gacc[j][3] : 0.0f);
+            if (g_on) *reinterpret_cast<u32x2*>(sG + g_ya + 3 * PIXB * j) = o;
         }
     };
 
@@ -217,13 +260,13 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
         __syncthreads();
         store_tile();
         __syncthreads();
+        const TileC here = cur;
+        tile_next(cur);
+        if (t + 1 < t_end) load_tile(cur);                         // in flight during everything below
         if constexpr (HEAD) {
             make_g();
             __syncthreads();
         }
-        const TileC here = cur;
-        tile_next(cur);
-        if (t + 1 < t_end) load_tile(cur);                         // in flight during the MFMAs below
 
         if (a.db) {
             float s0 = 0.0f;
@@ -257,8 +300,8 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
                     // pixels p0[h] .. p0[h] + 3 lie in one tile row (runs of 4 never cross a multiple of 16)
                     const float* dr = sD + ((p0[h] >> 4) + 3 - ky) * DW + (p0[h] & 15) + 3 - kx;    // sD(py + 2 - ky, px + 2 - kx), patch = tile + 1
                     const float d0 = l15 < 9 ? dr[0] : 0.0f, d1 = l15 < 9 ? dr[1] : 0.0f, d2 = l15 < 9 ? dr[2] : 0.0f, d3 = l15 < 9 ? dr[3] : 0.0f;
-                    bw[2 * h] = (unsigned)f2bf(d0) | ((unsigned)f2bf(d1) << 16);
-                    bw[2 * h + 1] = (unsigned)f2bf(d2) | ((unsigned)f2bf(d3) << 16);
+                    bw[2 * h] = pack2bf(d0, d1);
+                    bw[2 * h + 1] = pack2bf(d2, d3);
                 }
                 const u32x4 bd = u32x4{bw[0], bw[1], bw[2], bw[3]};
                 acc[2 + FPW] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[2 + FPW], 0, 0, 0);
@@ -268,45 +311,66 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
                 }
             }
         }
-        // ---- input gradient: 5 k-steps of two taps each ----
+        // ---- input gradient (5 k-steps of two taps x 2 pixel fragments) and weight gradient (4 k-steps of 32 tile pixels x 3 taps) as ONE
+        // pinned software pipeline: the operands of step n + 1 are requested before the MFMAs of step n.  (Round 4 left the order to
+        // hipcc, which sank every LDS read to just in front of the MFMA that needs it -- 22 exposed LDS round trips per tile with three
+        // waves per SIMD to hide them -- and turned the wave-uniform `tap < 9` of the third weight-gradient fragment into a branch per
+        // MFMA.  Now every wave runs all three fragments; the third accumulator of waves 1..3 is scratch and never flushed.) ----
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            u32x4 dwv[2], dgv[2][2];
+            s16x8 waf[2], wbf[2][FPW];
+            auto dreads = [&](int s, u32x4& wv, u32x4 (&gv)[2]) {
+                const int tap = 2 * s + (kg >> 1);                 // 9: the zero tap
+                const int tp = tap > 8 ? 8 : tap;                  // its patch address: any valid one
+                const int ky = tp / 3, kx = tp - 3 * ky;
+                wv = ld16(sW + w_base + tap * 32);
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int tap = 2 * s + (kg >> 1);                     // 9: the zero tap
-            const int tp = tap > 8 ? 8 : tap;                      // its patch address: any valid one
-            const int ky = tp / 3, kx = tp - 3 * ky;
-            const u32x4 wv = ld16(sW + w_base + tap * 32);
+                for (int mf = 0; mf < 2; ++mf) gv[mf] = ld16(sG + g_base[mf] + (ky * PW + kx) * PIXB);
+            };
+            auto wreads = [&](int ks, s16x8& af, s16x8 (&bf)[FPW]) {
+                int go[2], xo[2];
 #pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
-                const u32x4 gv = ld16(sG + g_base[mf] + (ky * PW + kx) * PIXB);
-                acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, gv), acc[mf], 0, 0, 0);
-            }
-        }
-        // ---- weight gradient: 4 k-steps of 32 tile pixels, fragment = tap ----
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
+                    const int oy = p >> 4, ox = p & 15;
+                    go[h] = ((oy + 1) * PW + ox + 1) * PIXB + 4 * pp * 2;
+                    xo[h] = (oy * PW + ox) * PIXB + 4 * pp * 2;
+                }
+                const s16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[0]));
+                const s16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[1]));
+                af = s16x8{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            int go[2], xo[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
-                const int oy = p >> 4, ox = p & 15;
-                go[h] = ((oy + 1) * PW + ox + 1) * PIXB + 4 * pp * 2;
-                xo[h] = (oy * PW + ox) * PIXB + 4 * pp * 2;
-            }
-            const s16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[0]));
-            const s16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[1]));
-            const s16x8 af = s16x8{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
-#pragma unroll
-            for (int fi = 0; fi < FPW; ++fi) {
-                const int tap = wave + 4 * fi;
-                if (tap < 9) {                                      // wave-uniform
+                for (int fi = 0; fi < FPW; ++fi) {
+                    const int tap = min(wave + 4 * fi, 8);          // wave-uniform; waves 1..3 repeat tap 8 into their scratch accumulator
                     const int to = ((tap / 3) * PW + (tap % 3)) * PIXB;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + to));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + to));
-                    const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc[2 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[2 + fi], 0, 0, 0);
+                    bf[fi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
+            };
+            dreads(0, dwv[0], dgv[0]);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                if (s + 1 < 5) dreads(s + 1, dwv[(s + 1) & 1], dgv[(s + 1) & 1]);
+                else wreads(0, waf[0], wbf[0]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+                    acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, dwv[s & 1]), __builtin_bit_cast(bf16x8, dgv[s & 1][mf]),
+                                                                      acc[mf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) wreads(ks + 1, waf[(ks + 1) & 1], wbf[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int fi = 0; fi < FPW; ++fi)
+                    acc[2 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, waf[ks & 1]), __builtin_bit_cast(bf16x8, wbf[ks & 1][fi]),
+                                                                          acc[2 + fi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- dx of this tile: mask by x > 0 (from the staged patch), 4 channels = 8 bytes per lane ----
@@ -329,8 +393,8 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : 3) void k_bwd16(const Bwd16K a)
                 }
                 if (gy < a.H && gx < a.W) {
                     u32x2 o;
-                    o[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-                    o[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+                    o[0] = pack2bf(v[0], v[1]);
+                    o[1] = pack2bf(v[2], v[3]);
                     *reinterpret_cast<u32x2*>(a.dx + (((long long)here.b * a.H + gy) * a.W + gx) * 32 + kg * 8) = o;
                 }
             }
@@ -454,8 +518,8 @@ __global__ __launch_bounds__(NT, 4) void k_head_wgrad_mfma(const HeadWgradK a) {
             // dpre[q + 1 - t] for the run's 4 pixels: patch coordinates (oy + 1 + 1 - ky, ox + 1 + 1 - kx)
             const float* dr = sD + ((p0[h] >> 4) + 2 - ky) * PW + (p0[h] & 15) + 2 - kx;
             const float d0 = l15 < 9 ? dr[0] : 0.0f, d1 = l15 < 9 ? dr[1] : 0.0f, d2 = l15 < 9 ? dr[2] : 0.0f, d3 = l15 < 9 ? dr[3] : 0.0f;
-            bw[2 * h] = (unsigned)f2bf(d0) | ((unsigned)f2bf(d1) << 16);
-            bw[2 * h + 1] = (unsigned)f2bf(d2) | ((unsigned)f2bf(d3) << 16);
+            bw[2 * h] = pack2bf(d0, d1);
+            bw[2 * h + 1] = pack2bf(d2, d3);
         }
         const u32x4 bd = u32x4{bw[0], bw[1], bw[2], bw[3]};
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[0], 0, 0, 0);
@@ -614,12 +678,17 @@ extern "C" int colvo_conv_bwd_fused_ok(const ColvoConvDesc* d) {
            d->Ho == d->Hi && d->Wo == d->Wi && bytes < 0x40000000LL && TUNE(bwd16) != 0;
 }
 
-static int bwd16_grid(const ColvoConvDesc* d, int* tiles_per_wg) {
+// MODE as in k_bwd16 (0: dy given, 1: HEAD form, 2: HEAD form + the head's weight gradient)
+static int bwd16_grid(const ColvoConvDesc* d, int mode, int* tiles_per_wg) {
     const int ntiles = d->B * ((d->Wi + TOW - 1) / TOW) * ((d->Hi + TOH - 1) / TOH);
-    // grid: bwd16_wgs workgroups (3 per CU) at 16 frames, more from 40 tiles per workgroup on (64 frames of 256x320: 1024, measured
-    // 3.64 against 3.67 ms per step with 512), at most four times as many -- every workgroup ends with 2320 atomics on the same addresses
+    // grid: bwd16_wgs workgroups at 16 frames, more from 40 tiles per workgroup on, at most four times as many -- every workgroup ends
+    // with 2320 atomics on the same addresses.  Beyond bwd16_wgs the grid is a WHOLE number of rounds of the workgroups the chip holds
+    // (256 CUs x 4 / 3 / 2 by the form's registers): until round 5 the HEAD form ran 1024 workgroups at 64 frames on 768 slots -- a
+    // second round on a third of the chip; counters: the same wave cycles as the plain form in 1.7 x the time -- 226 us against 125
     int wgs = (int)TUNE(bwd16_wgs);
-    wgs = std::max(wgs, std::min(4 * wgs, ntiles / 40));
+    const int slots = 256 * (mode == 2 ? 2 : mode == 1 ? COLVO_BWD16_HEAD_WGS : 4);
+    const int want = std::min(4 * wgs, ntiles / 40);
+    if (want > wgs) wgs = std::max(1, (want + slots / 2) / slots) * slots;
     if (wgs > ntiles) wgs = ntiles;
     const int tpw = (ntiles + wgs - 1) / wgs;
     if (tiles_per_wg) *tiles_per_wg = tpw;
@@ -628,7 +697,7 @@ static int bwd16_grid(const ColvoConvDesc* d, int* tiles_per_wg) {
 
 extern "C" int colvo_conv_bwd_fused_head_rows(const ColvoConvDesc* d) {
     if (!colvo_conv_bwd_fused_ok(d)) return 0;
-    return 4 * bwd16_grid(d, nullptr);
+    return 4 * bwd16_grid(d, 2, nullptr);
 }
 
 extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, const void* w_bwd, const void* x, int relu_mask, void* dx,
@@ -643,7 +712,7 @@ extern "C" int colvo_conv_bwd_fused(const ColvoConvDesc* d, const void* dy, cons
     k.B = d->B; k.H = d->Hi; k.W = d->Wi; k.relu_mask = relu_mask;
     k.tiles_x = (k.W + TOW - 1) / TOW; k.tiles_y = (k.H + TOH - 1) / TOH;
     k.ntiles = k.B * k.tiles_x * k.tiles_y;
-    const int wgs = bwd16_grid(d, &k.tiles_per_wg);
+    const int wgs = bwd16_grid(d, head_partials ? 2 : head_dpre ? 1 : 0, &k.tiles_per_wg);
     k.dpre = head_dpre; k.head_w = head_w; k.head_partials = head_partials;
     if (head_partials) colvo::launch(k_bwd16<2>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);
     else if (head_dpre) colvo::launch(k_bwd16<1>, dim3((unsigned)wgs), dim3(NT), 0, (hipStream_t)stream, k);

@@ -138,7 +138,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, const float* sOut,
             }
             u32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+            for (int k = 0; k < 4; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
             st16(a.out + off, o);
         }
     }
@@ -262,7 +262,7 @@ struct Epi {
                     }
                     u32x2 o;
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) o[k] = (uint32_t)f2bf(v[2 * k]) | ((uint32_t)f2bf(v[2 * k + 1]) << 16);
+                    for (int k = 0; k < 2; ++k) o[k] = pack2bf(v[2 * k], v[2 * k + 1]);
                     __builtin_amdgcn_raw_buffer_store_b64(o, rout, off[mf][nf], soff, 0);
                 }
             }

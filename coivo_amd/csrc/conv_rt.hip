@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT, (NF == 2 && TT<T>::ES == 2) ? 3 : 2) void k_con
                         }
                         u32x2 o;
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) o[q] = (uint32_t)f2bf(v[2 * q]) | ((uint32_t)f2bf(v[2 * q + 1]) << 16);
+                        for (int q = 0; q < 2; ++q) o[q] = pack2bf(v[2 * q], v[2 * q + 1]);
                         __builtin_amdgcn_raw_buffer_store_b64(o, rout, obase + noff[nf], 0, 0);
                     }
                 }

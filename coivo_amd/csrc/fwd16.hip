@@ -11,8 +11,8 @@
 //   depth[p]  = 1 / (lo + (hi - lo) sigmoid(hb + sum_{t, c} hw[t][c] y[p + t - 1][c]))
 //
 // Layout per workgroup (256 threads = 4 waves, a tile = 8 rows x 16 columns of outputs):
-//   sU  input patch [12 x 20 pixels][16 ci] bf16, 32 B per pixel       sW  w [16 co][10 taps][16 ci] (tap 9 = zeros), row pitch 352 B
-//   sY  y on [10 x 18 positions][16 co] bf16
+//   sU  input patch [12 x 20 pixels][16 ci] bf16, 32 B per pixel       sY  y on [10 x 18 positions][16 co] bf16
+//   weights (layer: [16 co][10 taps][16 ci], tap 9 = zeros; head: see below): MFMA operands resident in registers (round 5)
 //   layer:  position fragments of 16 consecutive patch positions (12 fragments cover 192 >= 180), wave w owns fragments 3w .. 3w + 2;
 //           5 k-steps of two taps; operands swapped as in k_conv3x3 (accumulator = 4 consecutive channels of one position)
 //   head:   an MFMA of the same shape (16 pixels x K = 9 taps x 16 channels) against a weight operand whose row 0 is the bf16 rounding
@@ -29,7 +29,7 @@ namespace {
 constexpr int TOH = 8, TOW = 16;
 constexpr int YH = TOH + 2, YW = TOW + 2, NY = YH * YW;       // 180 positions of y
 constexpr int UH = TOH + 4, UW = TOW + 4, NU = UH * UW;       // 240 input-patch pixels
-constexpr int PIXB = 32, WROWB = 352;
+constexpr int PIXB = 32;
 
 struct Fwd16K {
     const char* x;        // [B][H][W][16] bf16
@@ -45,32 +45,34 @@ struct Fwd16K {
     int tiles_x, tiles_y, ntiles, tiles_per_wg;
 };
 
-__global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
+__global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
     __shared__ __attribute__((aligned(16))) char sU[NU * PIXB];
     __shared__ __attribute__((aligned(16))) char sY[(NY + 12) * PIXB];        // (+ 12: the dummy positions 180 .. 191 of the last fragment)
-    __shared__ __attribute__((aligned(16))) char sW[16 * WROWB];
-    // head weights as an MFMA operand: [16 rows][10 taps][16 c] bf16 like sW; row 0 = the bf16 rounding of the fp32 weights, row 1 = the
-    // bf16 rounding of what that left over (hi + lo carries 16 mantissa bits: the sum of the two rows' products is the fp32-weight
-    // product to 2^-17), rows 2..15 zero
-    __shared__ __attribute__((aligned(16))) char sWh[16 * WROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
 
-    for (int i = tid; i < 16 * 10 * 2; i += NT) {                 // weights -> sW [co][10][ci], tap 9 zero
-        const int half = i & 1, tap = (i >> 1) % 10, co = i / 20;
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (tap < 9) v = ld16(a.w + ((co * 9 + tap) * 16 + half * 8) * 2);
-        st16(sW + co * WROWB + tap * 32 + half * 16, v);
-    }
-    for (int i = tid; i < 16 * WROWB / 4; i += NT) reinterpret_cast<uint32_t*>(sWh)[i] = 0u;
-    __syncthreads();
-    if (tid < 9 * 16) {
-        const int tq = tid >> 4, c = tid & 15;
-        const float wv = a.head_w[tid];
-        const uint16_t hi = f2bf(wv);
-        const uint16_t lo = f2bf(wv - bf2f(hi));
-        *reinterpret_cast<uint16_t*>(sWh + 0 * WROWB + tq * 32 + c * 2) = hi;
-        *reinterpret_cast<uint16_t*>(sWh + 1 * WROWB + tq * 32 + c * 2) = lo;
+    // Weight operands: RESIDENT IN REGISTERS for the whole walk, read straight from memory -- k-step s covers the taps 2 s and 2 s + 1
+    // (tap 9 = zeros), lane (l15, kg) holds row l15, tap 2 s + (kg >> 1), channels 8 (kg & 1) .. + 7.  (Round 4 staged both operands in
+    // LDS and re-read them per tile: 10 of the tile's 35 fragment reads, each in front of the MFMA that waits for it.)
+    //   layer: row = output channel.   head: row 0 = the bf16 rounding of the fp32 head weights, row 1 = the bf16 rounding of what that
+    //   left over (hi + lo carries 16 mantissa bits: the two rows' products sum to the fp32-weight product to 2^-17), rows 2..15 zero.
+    u32x4 wfr[5], hfr[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + (kg >> 1);
+        const int tq = tap > 8 ? 8 : tap;
+        const u32x4 wv = ld16(a.w + ((l15 * 9 + tq) * 16 + (kg & 1) * 8) * 2);
+        wfr[s] = tap < 9 ? wv : u32x4{0u, 0u, 0u, 0u};
+        const float* hw = a.head_w + tq * 16 + (kg & 1) * 8;
+        uint32_t hv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float w0 = hw[2 * q], w1 = hw[2 * q + 1];
+            const uint16_t hi0 = f2bf(w0), hi1 = f2bf(w1);
+            const uint16_t lo0 = f2bf(w0 - bf2f(hi0)), lo1 = f2bf(w1 - bf2f(hi1));
+            hv[q] = l15 == 0 ? ((uint32_t)hi0 | ((uint32_t)hi1 << 16)) : ((uint32_t)lo0 | ((uint32_t)lo1 << 16));
+        }
+        hfr[s] = (tap < 9 && l15 < 2) ? u32x4{hv[0], hv[1], hv[2], hv[3]} : u32x4{0u, 0u, 0u, 0u};
     }
     const float hb = a.head_b[0];
     // bias of this lane's 4 output channels (4 kg .. 4 kg + 3)
@@ -79,9 +81,15 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
     const int t_begin = blockIdx.x * a.tiles_per_wg;
     const int t_end = min(a.ntiles, t_begin + a.tiles_per_wg);
     const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const long long img_bytes = (long long)a.H * a.W * 16 * 2;
-    const long long tot_bytes = img_bytes * a.B;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(tot_bytes < 0x7fffffffLL ? tot_bytes : 0x7fffffffLL), 0x00020000);
+    const int img_px = a.H * a.W;
+    const long long img_bytes = (long long)img_px * 16 * 2;
+    const long long tot_bytes = img_bytes * a.B;                              // < 1 GiB (colvo_conv_head_fused_ok)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)tot_bytes, 0x00020000);
+    // outputs through buffer descriptors too: 32-bit offsets, and a position that must not be written gets OOB_OFF (the store is dropped)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)tot_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.depth, 0, (int)(tot_bytes >> 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pose_in ? a.pose_in : a.y), 0,
+                                                                        a.pose_in ? (int)(tot_bytes >> 2) : 0, 0x00020000);
 
     // staging: 480 granules (patch pixel, channel half) over 256 threads
     constexpr int NGRAN = NU * 2, PPF = (NGRAN + NT - 1) / NT;     // 2
@@ -117,7 +125,6 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
             pv[it] = bld16(rx, inb ? ((vy * a.W + vx) * 16 + s_half[it] * 8) * 2 : OOB_OFF, base);
         }
     };
-
     // per-lane constants: the three position fragments of this wave
     int u_base[3], y_lds[3], pos_y[3], pos_x[3];
 #pragma unroll
@@ -130,7 +137,16 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
         pos_x[j] = px;
         u_base[j] = (py * UW + px) * PIXB + (kg & 1) * 16;        // input patch pixel of tap (0, 0)
     }
-    const int w_base = l15 * WROWB + (kg & 1) * 16;
+    // tap offsets of this lane's k-slots (patch / y grid)
+    int u_tap[5], y_tap[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + (kg >> 1);
+        const int tp = tap > 8 ? 8 : tap;
+        const int ky = tp / 3, kx = tp - 3 * ky;
+        u_tap[s] = (ky * UW + kx) * PIXB;
+        y_tap[s] = (ky * YW + kx) * PIXB;
+    }
     // head: an MFMA like the layer's -- fragment mf = tile row 2 wave + mf, 16 pixels; D rows 0 / 1 (lanes kg == 0) = hi / lo sums
     int hy_base[2];
 #pragma unroll
@@ -147,68 +163,79 @@ __global__ __launch_bounds__(NT, 2) void k_fwd16_head(const Fwd16K a) {
         tile_next(cur);
         if (t + 1 < t_end) load_tile(cur);
 
+        // ---- the layer: 5 k-steps x 3 position fragments; the fragments of step s + 1 are requested BEFORE the MFMAs of step s and the
+        // order is pinned (left alone hipcc sinks every read to just in front of its MFMA: read, wait out the LDS round trip, one MFMA) ----
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        {
+            u32x4 ub[2][3];
 #pragma unroll
-        for (int s = 0; s < 5; ++s) {
-            const int tap = 2 * s + (kg >> 1);
-            const int tp = tap > 8 ? 8 : tap;
-            const int ky = tp / 3, kx = tp - 3 * ky;
-            const u32x4 wv = ld16(sW + w_base + tap * 32);
+            for (int j = 0; j < 3; ++j) ub[0][j] = ld16(sU + u_base[j] + u_tap[0]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const u32x4 uv = ld16(sU + u_base[j] + (ky * UW + kx) * PIXB);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, uv), acc[j], 0, 0, 0);
+            for (int s = 0; s < 5; ++s) {
+                if (s + 1 < 5) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) ub[(s + 1) & 1][j] = ld16(sU + u_base[j] + u_tap[s + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfr[s]), __builtin_bit_cast(bf16x8, ub[s & 1][j]),
+                                                                     acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         mfma_result_guard<bf16_t>(acc);
         const int oyt = here.ty * TOH, oxt = here.tx * TOW;
+        const int ybase = (int)((long long)here.b * img_bytes);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int gy = oyt - 1 + pos_y[j], gx = oxt - 1 + pos_x[j];
             const bool inimg = ((unsigned)gy < (unsigned)a.H) && ((unsigned)gx < (unsigned)a.W);
-            u32x2 o = u32x2{0u, 0u};
-            if (inimg) {
-                const float v0 = fmaxf(acc[j][0] + bv[0], 0.0f), v1 = fmaxf(acc[j][1] + bv[1], 0.0f);
-                const float v2 = fmaxf(acc[j][2] + bv[2], 0.0f), v3 = fmaxf(acc[j][3] + bv[3], 0.0f);
-                o[0] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
-                o[1] = (uint32_t)f2bf(v2) | ((uint32_t)f2bf(v3) << 16);
-            }
-            *reinterpret_cast<u32x2*>(sY + y_lds[j]) = o;          // zero outside the image: the head's zero padding
+            const float v0 = fmaxf(acc[j][0] + bv[0], 0.0f), v1 = fmaxf(acc[j][1] + bv[1], 0.0f);
+            const float v2 = fmaxf(acc[j][2] + bv[2], 0.0f), v3 = fmaxf(acc[j][3] + bv[3], 0.0f);
+            u32x2 o;
+            o[0] = inimg ? (pack2bf(v0, v1)) : 0u;      // zero outside the image: the head's zero padding
+            o[1] = inimg ? (pack2bf(v2, v3)) : 0u;
+            *reinterpret_cast<u32x2*>(sY + y_lds[j]) = o;
             const bool centre = pos_y[j] >= 1 && pos_y[j] <= TOH && pos_x[j] >= 1 && pos_x[j] <= TOW;
-            if (centre && inimg) *reinterpret_cast<u32x2*>(a.y + (((long long)here.b * a.H + gy) * a.W + gx) * 32 + kg * 8) = o;
+            __builtin_amdgcn_raw_buffer_store_b64(o, ry, (centre && inimg) ? (gy * a.W + gx) * 32 + kg * 8 : OOB_OFF, ybase, 0);
         }
         __syncthreads();
-        // ---- head on the 128 centre pixels: 5 k-steps of two taps, 2 MFMAs each ----
+        // ---- head on the 128 centre pixels: 5 k-steps of two taps, 2 MFMAs each, same pipeline ----
         {
             f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            u32x4 yb[2][2];
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) yb[0][mf] = ld16(sY + hy_base[mf] + y_tap[0]);
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
-                const int tap = 2 * s + (kg >> 1);
-                const int tp = tap > 8 ? 8 : tap;
-                const int ky = tp / 3, kx = tp - 3 * ky;
-                const u32x4 wv = ld16(sWh + w_base + tap * 32);
+                if (s + 1 < 5) {
 #pragma unroll
-                for (int mf = 0; mf < 2; ++mf) {
-                    const u32x4 yv = ld16(sY + hy_base[mf] + (ky * YW + kx) * PIXB);
-                    hacc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), __builtin_bit_cast(bf16x8, yv), hacc[mf], 0, 0, 0);
+                    for (int mf = 0; mf < 2; ++mf) yb[(s + 1) & 1][mf] = ld16(sY + hy_base[mf] + y_tap[s + 1]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mf = 0; mf < 2; ++mf)
+                    hacc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hfr[s]), __builtin_bit_cast(bf16x8, yb[s & 1][mf]),
+                                                                       hacc[mf], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             mfma_result_guard<bf16_t>(hacc);
-            if (kg == 0) {
-#pragma unroll
-                for (int mf = 0; mf < 2; ++mf) {
-                    const float pre = hb + (hacc[mf][0] + hacc[mf][1]);
-                    const int gy = oyt + 2 * wave + mf, gx = oxt + l15;
-                    if (gy < a.H && gx < a.W) {
-                        const float sig = 1.0f / (1.0f + expf(-pre));
-                        const float dep = 1.0f / (a.lo + (a.hi - a.lo) * sig);
-                        a.depth[((long long)here.b * a.H + gy) * a.W + gx] = dep;
-                        if (a.pose_in) {
-                            const int Bh = a.B >> 1, pair = here.b < Bh ? here.b : here.b - Bh;
-                            *reinterpret_cast<uint16_t*>(a.pose_in + ((((long long)pair * a.H + gy) * a.W + gx) * 8 + 6 + (here.b >= Bh)) * 2) = f2bf(dep);
-                        }
-                    }
-                }
+            // The two fragments' sums sit in the lanes kg == 0 of two registers; one row swap (v_permlane16_swap: lanes 16..31 of the
+            // first <-> lanes 0..15 of the second) puts fragment 1 next to fragment 0, and the sigmoid / depth arithmetic (two fp32
+            // divisions, an exp: ~50 VALU instructions) runs ONCE with 32 live lanes instead of twice with 16
+            const float s0 = hacc[0][0] + hacc[0][1], s1 = hacc[1][0] + hacc[1][1];
+            const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(uint32_t, s0), __builtin_bit_cast(uint32_t, s1), false, false);
+            const float pre = hb + __builtin_bit_cast(float, (uint32_t)sw[0]);                  // lanes kg = 0 / 1: fragment 0 / 1
+            const int gy = oyt + 2 * wave + (kg & 1), gx = oxt + l15;
+            const bool ok = kg < 2 && gy < a.H && gx < a.W;
+            const float sig = 1.0f / (1.0f + expf(-pre));
+            const float dep = 1.0f / (a.lo + (a.hi - a.lo) * sig);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, dep), rd, ok ? (gy * a.W + gx) * 4 : OOB_OFF, here.b * img_px * 4, 0);
+            if (a.pose_in) {
+                const int Bh = a.B >> 1, pair = here.b < Bh ? here.b : here.b - Bh;
+                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(dep), rp, ok ? ((gy * a.W + gx) * 8 + 6 + (here.b >= Bh)) * 2 : OOB_OFF,
+                                                      pair * img_px * 16, 0);
             }
         }
     }
@@ -241,8 +268,11 @@ extern "C" int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, cons
     k.B = d->B; k.H = d->Hi; k.W = d->Wi;
     k.tiles_x = (k.W + TOW - 1) / TOW; k.tiles_y = (k.H + TOH - 1) / TOH;
     k.ntiles = k.B * k.tiles_x * k.tiles_y;
+    // grid: fwd16_wgs workgroups, about one per 8 tiles beyond that -- in WHOLE rounds of the 1024 workgroups the chip holds (4 per CU at
+    // the kernel's 124 registers; round 4's 88 registers held 5 per CU and its 1280 workgroups at 16 frames were one round)
     int wgs = (int)TUNE(fwd16_wgs);
-    wgs = std::max(wgs, std::min(8 * wgs, k.ntiles / 8));
+    const int slots = 1024, want = std::min(8 * wgs, k.ntiles / 8);
+    if (want > wgs) wgs = std::max(1, (want + slots / 2) / slots) * slots;
     if (wgs > k.ntiles) wgs = k.ntiles;
     k.tiles_per_wg = (k.ntiles + wgs - 1) / wgs;
     wgs = (k.ntiles + k.tiles_per_wg - 1) / k.tiles_per_wg;

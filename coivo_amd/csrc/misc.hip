@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NT) void k_pack_nchw8(Planes src, int HW, void* __r
     if constexpr (ES == 2) {
         u4 w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = (unsigned)f2bf(v[2 * k]) | ((unsigned)f2bf(v[2 * k + 1]) << 16);
+        for (int k = 0; k < 4; ++k) w[k] = pack2bf(v[2 * k], v[2 * k + 1]);
         *reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(dst) + o) = w;
     } else {
         u4 w0, w1;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(NT) void k_depth_head_dgrad16(const void* __restric
             for (int j = 0; j < 4; ++j) {
                 const int c = 8 * q + 2 * j;
                 const float x0 = bf2f((uint16_t)(xw[j] & 0xffffu)), x1 = bf2f((uint16_t)(xw[j] >> 16));
-                ow[j] = (unsigned)f2bf(x0 > 0.0f ? v[c] : 0.0f) | ((unsigned)f2bf(x1 > 0.0f ? v[c + 1] : 0.0f) << 16);
+                ow[j] = pack2bf(x0 > 0.0f ? v[c] : 0.0f, x1 > 0.0f ? v[c + 1] : 0.0f);
             }
             out[q] = uint4{ow[0], ow[1], ow[2], ow[3]};
         }
@@ -1440,8 +1440,8 @@ __global__ __launch_bounds__(NT) void k_cast_f32_bf16(const float* __restrict__ 
         if (i + 4 <= n) {
             const float4 v = *reinterpret_cast<const float4*>(src + i);
             uint2 o;
-            o.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-            o.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+            o.x = pack2bf(v.x, v.y);
+            o.y = pack2bf(v.z, v.w);
             *reinterpret_cast<uint2*>(dst + i) = o;
         } else {
             for (size_t j = i; j < n; ++j) dst[j] = f2bf(src[j]);
