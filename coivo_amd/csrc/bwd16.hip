@@ -64,7 +64,7 @@ constexpr int DH = PH + 2, DW = PW + 2;                                      // 
 // Three workgroups per CU (168 VGPRs; the MODE 2 form would spill): with the grid at 3 x 256 the HEAD form's step is 0.7 % shorter
 // than with two (1.392 against 1.403 ms, same box; 768 workgroups at two per CU: 1.420 -- the third waits for a slot)
 #ifndef COLVO_BWD16_HEAD_WGS
-#define COLVO_BWD16_HEAD_WGS 3
+#define COLVO_BWD16_HEAD_WGS 4
 #endif
 template <int MODE>
 __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WGS : 4) void k_bwd16(const Bwd16K a) {
@@ -99,16 +99,18 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
     // ---- staging: 2 x 360 granules (patch pixel, channel half) over 256 threads: 3 per thread ----
     constexpr int NGRAN = 2 * NPIX * 2;                            // 720
     constexpr int PPF = (NGRAN + NT - 1) / NT;                     // 3
-    int s_which[PPF], s_py[PPF], s_px[PPF], s_lds[PPF], s_half[PPF];
+    // per granule ONE register: py | px << 8 | LDS offset << 16 (< 5760); which tensor and which channel half follow from (it, tid) --
+    // granule i = it * 256 + tid: half = tid & 1 for every it, and `which` is a comparison of tid with a constant
+    int s_pk[PPF];
+    const int s_half = tid & 1;
+    auto s_which = [&](int it) -> int { const int i = it * NT + tid; return i < NPIX * 2 ? 0 : i < NGRAN ? 1 : 2; };   // 2: no granule
 #pragma unroll
     for (int it = 0; it < PPF; ++it) {
         const int i = it * NT + tid;
-        const int which = i / (NPIX * 2), rem = i - which * (NPIX * 2);
-        const int pix = rem >> 1, half = rem & 1;
+        const int rem = i < NPIX * 2 ? i : i - NPIX * 2;
+        const int pix = (rem >> 1) < NPIX ? (rem >> 1) : 0;
         const int py = pix / PW, px = pix - py * PW;
-        s_which[it] = (i < NGRAN) ? which : 2;                    // 2: no granule
-        s_py[it] = py; s_px[it] = px; s_half[it] = half;
-        s_lds[it] = pix * PIXB + half * 16;
+        s_pk[it] = py | (px << 8) | ((pix * PIXB + s_half * 16) << 16);
     }
     struct TileC { int b, ty, tx; };
     auto tile_next = [&](TileC& c) {
@@ -136,21 +138,22 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
         }
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
-            const int vy = oy0 + s_py[it], vx = ox0 + s_px[it];
+            const int vy = oy0 + (s_pk[it] & 0xff), vx = ox0 + ((s_pk[it] >> 8) & 0xff);
             const bool inb = ((unsigned)vy < (unsigned)a.H) && ((unsigned)vx < (unsigned)a.W);
-            const int off = inb ? ((vy * a.W + vx) * 16 + s_half[it] * 8) * 2 : OOB_OFF;
-            if (s_which[it] == 0) pv[it] = bld16(rdy, off, base);
-            else pv[it] = bld16(rx, s_which[it] == 1 ? off : OOB_OFF, base);
+            const int off = inb ? ((vy * a.W + vx) * 16 + s_half * 8) * 2 : OOB_OFF;
+            if (s_which(it) == 0) pv[it] = bld16(rdy, off, base);
+            else pv[it] = bld16(rx, s_which(it) == 1 ? off : OOB_OFF, base);
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < PPF; ++it) {
-            if (s_which[it] == 0) {
-                st16(sG + s_lds[it], pv[it]);                     // HEAD: the layer's output y -- make_g() turns it into the gradient in place
-                if constexpr (headw) st16(sY + s_lds[it], pv[it]);
+            const int lds = (int)((unsigned)s_pk[it] >> 16);
+            if (s_which(it) == 0) {
+                st16(sG + lds, pv[it]);                           // HEAD: the layer's output y -- make_g() turns it into the gradient in place
+                if constexpr (headw) st16(sY + lds, pv[it]);
             }
-            else if (s_which[it] == 1) st16(sX + s_lds[it], pv[it]);
+            else if (s_which(it) == 1) st16(sX + lds, pv[it]);
         }
         if constexpr (HEAD) {
             if (tid < DH * DW) {
@@ -165,46 +168,48 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
     // d(pre) reads and 72 fp32 FMAs per granule from 72 registers of head weights -- 195 of the tile loop's 324 VALU instructions in a
     // kernel that is issue-bound, and the registers that kept the MFMA phases from being pipelined.  As a product it is tiny:
     // [16 c] x [K = 9 taps] per pixel; both factors are fp32, so each is split into bf16 hi + lo and K carries the three products that
-    // matter -- k = 0..8 hi_w hi_d, 9..17 hi_w lo_d, 18..26 lo_w hi_d (27..31 zero): the sum is the fp32 product to ~2^-16 relative
-    // (lo_w lo_d and the second-order remainders are dropped), far inside the bf16 rounding the result gets.  ONE MFMA per 16 patch
-    // pixels, 3 per wave and tile; the weight operand lives in 4 registers; the d(pre) operand is gathered from the split patch in
-    // LDS (8 reads + 4 v_perm per fragment); y is read from / g written to the SAME 8 bytes of sG by the same lane.
+    // matter per tap -- hi_w hi_d, hi_w lo_d, lo_w hi_d: the sum is the fp32 product to ~2^-16 relative (lo_w lo_d and the second-order
+    // remainders are dropped), far inside the bf16 rounding the result gets.  ONE MFMA per fragment of patch pixels, 3 per wave and
+    // tile; the weight operand lives in 4 registers; y is read from / g written to the SAME 8 bytes of sG by the same lane.
+    //   K layout: lane group kg = 0, 1, 2 holds tap ROW kg (taps a, b, c = 3 kg + 0, 1, 2): slots hh_a hh_b hh_c hl_a hl_b hl_c lh_a lh_b;
+    //   group 3 holds the three left-over lh_c and five zero slots.  A lane's eight d(pre) operands then come from THREE words of the
+    //   split patch (one row segment; group 3: one word per row) and four v_perm_b32 with the same constant selectors in every lane --
+    //   3 LDS reads per fragment where a slot-by-slot gather took 8 (counters of that form: LDS busy 45 % of the kernel, 16 M
+    //   bank-conflict cycles more than the plain form).
     //   The 180 patch pixels are cut into 12 fragments of FIFTEEN (lane 15 of a fragment idles): fragment 3 w + j of wave w is the 5 x 3
     //   block (rows 5 (w >> 1) .., columns 9 (w & 1) + 3 j ..) of the 10 x 18 patch, lane l15 its pixel (l15 / 3, l15 % 3) -- so that a
-    //   lane's LDS addresses are the same registers for j = 0, 1, 2 with the fragment as an immediate offset (with 16 consecutive pixels
-    //   per fragment the row wrap differs from lane to lane: 24 address additions per tile).
+    //   lane's LDS addresses are the same registers for j = 0, 1, 2 with the fragment as an immediate offset.
     u32x4 hA = u32x4{0u, 0u, 0u, 0u};
-    int g_da[8];                                                   // byte address in sDs of this lane's 8 k-slots, fragment j = 0
-    uint32_t g_sel[4];
+    int g_da[3] = {0, 0, 0};                                       // byte addresses in sDs of this lane's three words, fragment j = 0
     int g_ya = 0;                                                  // byte address in sG of this lane's 4 channels, fragment j = 0
     const bool g_on = l15 < 15;
     if constexpr (HEAD) {
         const int lp = l15 < 15 ? l15 : 14;                        // (the idle lane repeats its neighbour's reads)
         const int gpy = 5 * (wave >> 1) + lp / 3, gpx = 9 * (wave & 1) + lp % 3;
         g_ya = (gpy * PW + gpx) * PIXB + kg * 8;
+        // d(pre) of tap (ky, kx) for patch pixel (py, px) sits at sDs[(py + 2 - ky) * DW + px + 2 - kx]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int ky = kg < 3 ? kg : i, kx = kg < 3 ? i : 2;
+            g_da[i] = ((gpy + 2 - ky) * DW + gpx + 2 - kx) * 4;
+        }
         uint32_t hv[4];
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) {
-            uint32_t pair = 0u, sel = 0u;
+            uint32_t pair = 0u;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int k = 8 * kg + 2 * i2 + e;
-                const int kk = k > 26 ? 26 : k;
-                const int part = kk / 9, t = kk - 9 * part;
+                const int i = 2 * i2 + e;                          // slot of this lane's group
+                // group 0..2: slot i = (part i / 3, tap 3 kg + i % 3) for i < 6, (lo_w, tap 3 kg + i - 6) for i = 6, 7;  group 3: lo_w of tap 3 i + 2
+                const bool used = kg < 3 || i < 3;
+                const int t = kg < 3 ? 3 * kg + (i < 6 ? i % 3 : i - 6) : (i < 3 ? 3 * i + 2 : 8);
+                const bool low = kg == 3 || i >= 6;                // the lo_w hi_d products
                 const float w = a.head_w[t * 16 + l15];
                 const uint16_t hi = f2bf(w);
                 const uint16_t lo = f2bf(w - bf2f(hi));
-                const uint32_t val = k < 27 ? (uint32_t)(part == 2 ? lo : hi) : 0u;
-                pair |= val << (16 * e);
-                const int ky = t / 3, kx = t - 3 * ky;
-                g_da[2 * i2 + e] = ((gpy + 2 - ky) * DW + gpx + 2 - kx) * 4;
-                // v_perm_b32 byte selectors: element e comes from source word e (0: bytes 0..3, 1: bytes 4..7 of the pair), its hi half
-                // (bytes 0, 1) or, for the hi_w lo_d products, its lo half (bytes 2, 3)
-                const uint32_t b = 4u * e + (part == 1 ? 2u : 0u);
-                sel |= (b | ((b + 1u) << 8)) << (16 * e);
+                pair |= (used ? (uint32_t)(low ? lo : hi) : 0u) << (16 * e);
             }
             hv[i2] = pair;
-            g_sel[i2] = sel;
         }
         hA = u32x4{hv[0], hv[1], hv[2], hv[3]};
     }
@@ -213,11 +218,14 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
         u32x2 yv[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            uint32_t wd[8];
+            uint32_t w[3];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wd[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sDs) + g_da[i] + 12 * j);
-            bfr[j] = u32x4{__builtin_amdgcn_perm(wd[1], wd[0], g_sel[0]), __builtin_amdgcn_perm(wd[3], wd[2], g_sel[1]),
-                           __builtin_amdgcn_perm(wd[5], wd[4], g_sel[2]), __builtin_amdgcn_perm(wd[7], wd[6], g_sel[3])};
+            for (int i = 0; i < 3; ++i) w[i] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sDs) + g_da[i] + 12 * j);
+            // v_perm_b32(s0, s1, sel): bytes 0..3 = s1, 4..7 = s0; a word is (hi = bytes 0, 1 | lo = bytes 2, 3)
+            bfr[j] = u32x4{__builtin_amdgcn_perm(w[1], w[0], 0x05040100u),      // hh_a hh_b   (group 3: lh_c of rows 0, 1)
+                           __builtin_amdgcn_perm(w[0], w[2], 0x07060100u),      // hh_c hl_a   (group 3: lh_c of row 2, -)
+                           __builtin_amdgcn_perm(w[2], w[1], 0x07060302u),      // hl_b hl_c
+                           __builtin_amdgcn_perm(w[1], w[0], 0x05040100u)};     // lh_a lh_b: hi_d again
             yv[j] = *reinterpret_cast<const u32x2*>(sG + g_ya + 3 * PIXB * j);
         }
         f32x4 gacc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -249,9 +257,10 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
     // acc[0..1]: the input gradient of the current tile (cleared every tile); acc[2..4]: the weight gradient, carried over all tiles.
     // ONE array so that one mfma_result_guard closes every chain at the end of a tile: hipcc rotates the carried accumulators
     // through v_mov copies at the loop edge -- reads of MFMA results that must not come early (tools/isa_check_mfma.py)
-    f32x4 acc[2 + FPW + 1];                                        // (+ 1: the HEAD form's head weight gradient, see `acch`)
+    constexpr int NACC = 2 + FPW + (headw ? 1 : 0);                // (+ 1: MODE 2's head weight gradient)
+    f32x4 acc[NACC];
 #pragma unroll
-    for (int fi = 0; fi < 2 + FPW + 1; ++fi) acc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int fi = 0; fi < NACC; ++fi) acc[fi] = f32x4{0.f, 0.f, 0.f, 0.f};
     float dbacc = 0.0f;
     const int db_co = tid & 15, db_ph = tid >> 4;                  // 16 phases x 8 pixels
 
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
                     bw[2 * h + 1] = pack2bf(d2, d3);
                 }
                 const u32x4 bd = u32x4{bw[0], bw[1], bw[2], bw[3]};
-                acc[2 + FPW] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[2 + FPW], 0, 0, 0);
+                acc[NACC - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ay), __builtin_bit_cast(bf16x8, bd), acc[NACC - 1], 0, 0, 0);
                 if (lane < 32) {                                      // bias: this wave's 32 pixels
                     const int p = 32 * wave + lane;
                     hb += sD[((p >> 4) + 2) * DW + (p & 15) + 2];
@@ -320,7 +329,9 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
             u32x4 dwv[2], dgv[2][2];
-            s16x8 waf[2], wbf[2][FPW];
+            // (the weight gradient's third tap fragment is not double-buffered: it is requested at the head of its own step, behind the
+            // next step's operands, and waits out two MFMAs -- four registers that decide between three and four workgroups per CU)
+            s16x8 waf[2], wbf[2][FPW - 1], wb2;
             auto dreads = [&](int s, u32x4& wv, u32x4 (&gv)[2]) {
                 const int tap = 2 * s + (kg >> 1);                 // 9: the zero tap
                 const int tp = tap > 8 ? 8 : tap;                  // its patch address: any valid one
@@ -329,26 +340,31 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf) gv[mf] = ld16(sG + g_base[mf] + (ky * PW + kx) * PIXB);
             };
-            auto wreads = [&](int ks, s16x8& af, s16x8 (&bf)[FPW]) {
-                int go[2], xo[2];
+            auto wtap = [&](int ks, int fi) -> s16x8 {
+                int xo[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
-                    const int oy = p >> 4, ox = p & 15;
-                    go[h] = ((oy + 1) * PW + ox + 1) * PIXB + 4 * pp * 2;
-                    xo[h] = (oy * PW + ox) * PIXB + 4 * pp * 2;
+                    xo[h] = ((p >> 4) * PW + (p & 15)) * PIXB + 4 * pp * 2;
+                }
+                const int tap = min(wave + 4 * fi, 8);              // wave-uniform; waves 1..3 repeat tap 8 into their scratch accumulator
+                const int to = ((tap / 3) * PW + (tap % 3)) * PIXB;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + to));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + to));
+                return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            auto wreads = [&](int ks, s16x8& af, s16x8 (&bf)[FPW - 1]) {
+                int go[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 32 * ks + 16 * (kg >> 1) + 8 * h + 4 * (kg & 1) + q;
+                    go[h] = (((p >> 4) + 1) * PW + (p & 15) + 1) * PIXB + 4 * pp * 2;
                 }
                 const s16x4 glo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[0]));
                 const s16x4 ghi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sG + go[1]));
                 af = s16x8{glo[0], glo[1], glo[2], glo[3], ghi[0], ghi[1], ghi[2], ghi[3]};
 #pragma unroll
-                for (int fi = 0; fi < FPW; ++fi) {
-                    const int tap = min(wave + 4 * fi, 8);          // wave-uniform; waves 1..3 repeat tap 8 into their scratch accumulator
-                    const int to = ((tap / 3) * PW + (tap % 3)) * PIXB;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[0] + to));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sX + xo[1] + to));
-                    bf[fi] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
+                for (int fi = 0; fi < FPW - 1; ++fi) bf[fi] = wtap(ks, fi);
             };
             dreads(0, dwv[0], dgv[0]);
 #pragma unroll
@@ -364,12 +380,15 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+                wb2 = wtap(ks, FPW - 1);
                 if (ks + 1 < 4) wreads(ks + 1, waf[(ks + 1) & 1], wbf[(ks + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int fi = 0; fi < FPW; ++fi)
+                for (int fi = 0; fi < FPW - 1; ++fi)
                     acc[2 + fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, waf[ks & 1]), __builtin_bit_cast(bf16x8, wbf[ks & 1][fi]),
                                                                           acc[2 + fi], 0, 0, 0);
+                acc[2 + FPW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, waf[ks & 1]), __builtin_bit_cast(bf16x8, wb2),
+                                                                           acc[2 + FPW - 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WG
             float* row = a.head_partials + ((size_t)blockIdx.x * 4 + wave) * (9 * 16 + 1);
             if (l15 < 9) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) row[l15 * 16 + 4 * kg + r] = acc[2 + FPW][r];
+                for (int r = 0; r < 4; ++r) row[l15 * 16 + 4 * kg + r] = acc[NACC - 1][r];
             }
             const float hbs = wave_sum(hb);
             if (lane == 0) row[9 * 16] = hbs;
