@@ -29,7 +29,7 @@ namespace {
 constexpr int TOH = 8, TOW = 16;
 constexpr int YH = TOH + 2, YW = TOW + 2, NY = YH * YW;       // 180 positions of y
 constexpr int UH = TOH + 4, UW = TOW + 4, NU = UH * UW;       // 240 input-patch pixels
-constexpr int PIXB = 32;
+constexpr int PIXB = 32, WROWB = 352;
 
 struct Fwd16K {
     const char* x;        // [B][H][W][16] bf16
@@ -48,6 +48,9 @@ struct Fwd16K {
 __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
     __shared__ __attribute__((aligned(16))) char sU[NU * PIXB];
     __shared__ __attribute__((aligned(16))) char sY[(NY + 12) * PIXB];        // (+ 12: the dummy positions 180 .. 191 of the last fragment)
+    // head weights as an MFMA operand, [16 rows][10 taps][16 c] bf16, row pitch 352 B (conflict-free ds_read_b128 of 16 rows): read per
+    // tile inside the head's pipeline -- resident they cost the 20 registers the second tile of loads in flight needs
+    __shared__ __attribute__((aligned(16))) char sWh[16 * WROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
 
@@ -56,24 +59,25 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
     // LDS and re-read them per tile: 10 of the tile's 35 fragment reads, each in front of the MFMA that waits for it.)
     //   layer: row = output channel.   head: row 0 = the bf16 rounding of the fp32 head weights, row 1 = the bf16 rounding of what that
     //   left over (hi + lo carries 16 mantissa bits: the two rows' products sum to the fp32-weight product to 2^-17), rows 2..15 zero.
-    u32x4 wfr[5], hfr[5];
+    u32x4 wfr[5];
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         const int tap = 2 * s + (kg >> 1);
         const int tq = tap > 8 ? 8 : tap;
         const u32x4 wv = ld16(a.w + ((l15 * 9 + tq) * 16 + (kg & 1) * 8) * 2);
         wfr[s] = tap < 9 ? wv : u32x4{0u, 0u, 0u, 0u};
-        const float* hw = a.head_w + tq * 16 + (kg & 1) * 8;
-        uint32_t hv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float w0 = hw[2 * q], w1 = hw[2 * q + 1];
-            const uint16_t hi0 = f2bf(w0), hi1 = f2bf(w1);
-            const uint16_t lo0 = f2bf(w0 - bf2f(hi0)), lo1 = f2bf(w1 - bf2f(hi1));
-            hv[q] = l15 == 0 ? ((uint32_t)hi0 | ((uint32_t)hi1 << 16)) : ((uint32_t)lo0 | ((uint32_t)lo1 << 16));
-        }
-        hfr[s] = (tap < 9 && l15 < 2) ? u32x4{hv[0], hv[1], hv[2], hv[3]} : u32x4{0u, 0u, 0u, 0u};
     }
+    for (int i = tid; i < 16 * WROWB / 4; i += NT) reinterpret_cast<uint32_t*>(sWh)[i] = 0u;
+    __syncthreads();
+    if (tid < 9 * 16) {
+        const int tq = tid >> 4, c = tid & 15;
+        const float wv = a.head_w[tid];
+        const uint16_t hi = f2bf(wv);
+        const uint16_t lo = f2bf(wv - bf2f(hi));
+        *reinterpret_cast<uint16_t*>(sWh + 0 * WROWB + tq * 32 + c * 2) = hi;
+        *reinterpret_cast<uint16_t*>(sWh + 1 * WROWB + tq * 32 + c * 2) = lo;
+    }
+    const int wh_base = l15 * WROWB + (kg & 1) * 16 + (kg >> 1) * 32;       // + 64 s: this lane's slot of k-step s (tap 2 s + (kg >> 1); tap 9 = zeros)
     const float hb = a.head_b[0];
     // bias of this lane's 4 output channels (4 kg .. 4 kg + 3)
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + 4 * kg);
@@ -114,8 +118,10 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
         const int tr_ = t - cur.b * tiles_per_img;
         cur.ty = tr_ / a.tiles_x; cur.tx = tr_ - cur.ty * a.tiles_x;
     }
-    u32x4 pv[PPF];
-    auto load_tile = [&](const TileC& c) {
+    // TWO tiles of patch loads are in flight per workgroup (15 KB; four workgroups per CU: 62 KB): with one, the kernel moved 2.4-2.7 TB/s
+    // however few instructions the tile took -- 31 KB in flight per CU against a loaded HBM latency of a few microseconds
+    u32x4 pvA[PPF], pvB[PPF];
+    auto load_tile = [&](const TileC& c, u32x4 (&pv)[PPF]) {
         const int oy0 = c.ty * TOH - 2, ox0 = c.tx * TOW - 2;
         const int base = (int)((long long)c.b * img_bytes);
 #pragma unroll
@@ -152,8 +158,14 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) hy_base[mf] = ((2 * wave + mf) * YW + l15) * PIXB + (kg & 1) * 16;
 
-    if (t_begin < t_end) load_tile(cur);
-    for (int t = t_begin; t < t_end; ++t) {
+    TileC ld = cur;                                                // the next tile to request
+    int t_ld = t_begin;
+    auto request = [&](u32x4 (&pv)[PPF]) {
+        if (t_ld < t_end) { load_tile(ld, pv); tile_next(ld); ++t_ld; }
+    };
+    request(pvA);
+    request(pvB);
+    auto tile_body = [&](u32x4 (&pv)[PPF]) {
         __syncthreads();                                           // the previous tile's head has finished reading sY, its MFMAs sU
 #pragma unroll
         for (int it = 0; it < PPF; ++it)
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
         __syncthreads();
         const TileC here = cur;
         tile_next(cur);
-        if (t + 1 < t_end) load_tile(cur);
+        request(pv);                                               // the tile after next, into the registers just stored
 
         // ---- the layer: 5 k-steps x 3 position fragments; the fragments of step s + 1 are requested BEFORE the MFMAs of step s and the
         // order is pinned (left alone hipcc sinks every read to just in front of its MFMA: read, wait out the LDS round trip, one MFMA) ----
@@ -204,19 +216,21 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
         // ---- head on the 128 centre pixels: 5 k-steps of two taps, 2 MFMAs each, same pipeline ----
         {
             f32x4 hacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            u32x4 yb[2][2];
+            u32x4 yb[2][2], hw[2];
+            hw[0] = ld16(sWh + wh_base);
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) yb[0][mf] = ld16(sY + hy_base[mf] + y_tap[0]);
 #pragma unroll
             for (int s = 0; s < 5; ++s) {
                 if (s + 1 < 5) {
+                    hw[(s + 1) & 1] = ld16(sWh + wh_base + 64 * (s + 1));
 #pragma unroll
                     for (int mf = 0; mf < 2; ++mf) yb[(s + 1) & 1][mf] = ld16(sY + hy_base[mf] + y_tap[s + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mf = 0; mf < 2; ++mf)
-                    hacc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hfr[s]), __builtin_bit_cast(bf16x8, yb[s & 1][mf]),
+                    hacc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, hw[s & 1]), __builtin_bit_cast(bf16x8, yb[s & 1][mf]),
                                                                        hacc[mf], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -238,6 +252,10 @@ __global__ __launch_bounds__(NT, 4) void k_fwd16_head(const Fwd16K a) {
                                                       pair * img_px * 16, 0);
             }
         }
+    };
+    for (int t = t_begin; t < t_end; t += 2) {
+        tile_body(pvA);
+        if (t + 1 < t_end) tile_body(pvB);
     }
 }
 
@@ -271,7 +289,7 @@ extern "C" int colvo_conv_head_fused(const ColvoConvDesc* d, const void* x, cons
     // grid: fwd16_wgs workgroups, about one per 8 tiles beyond that -- in WHOLE rounds of the 1024 workgroups the chip holds (4 per CU at
     // the kernel's 124 registers; round 4's 88 registers held 5 per CU and its 1280 workgroups at 16 frames were one round)
     int wgs = (int)TUNE(fwd16_wgs);
-    const int slots = 1024, want = std::min(8 * wgs, k.ntiles / 8);
+    const int slots = 1024, want = std::min(8 * wgs, k.ntiles / std::max(1, (int)TUNE(fwd16_tiles_per_wg)));
     if (want > wgs) wgs = std::max(1, (want + slots / 2) / slots) * slots;
     if (wgs > k.ntiles) wgs = k.ntiles;
     k.tiles_per_wg = (k.ntiles + wgs - 1) / wgs;

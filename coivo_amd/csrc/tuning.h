@@ -86,6 +86,7 @@ namespace tune {
     X(planes_groups, 2, "... 16-block groups a wave walks (its weight set-up is amortised over them)") \
     X(fwd16, 1, "the 16 -> 16 full-resolution layer and the depth head behind it in one pass (k_fwd16_head, csrc/fwd16.hip)")          \
     X(fwd16_wgs, 1024, "... its grid (at least; one workgroup per 8 tiles beyond that)")                                              \
+    X(fwd16_tiles_per_wg, 32, "... tiles per workgroup beyond fwd16_wgs (grid in whole rounds of 1024)")                                       \
     /* ---- heads, fused loss, streams ---- */                                                                                      \
     X(head_wgrad_rows, 1, "tap rows per thread of the depth-head weight gradient (1: three workgroups per pixel range)")            \
     X(head_fwd_lds, 1, "depth-head forward stages its tile in LDS (24.7 -> 18.5 us)")                                               \

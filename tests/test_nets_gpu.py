@@ -330,7 +330,12 @@ def test_grouped_slab_weight_gradients_equal_the_default_form(dtype):
     g2 = run(True)
     for a, c, r in zip(g0[:2], g1[:2], g2[:2]):
         scale = a.abs().max().item()
-        assert (a - c).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-4) * scale
+        # f32: summation order only.  bf16: the default form runs iconv1's fused backward (k_bwd16, HEAD form), which makes the depth
+        # head's input gradient by split-bf16 MFMA (2^-16 relative) before rounding it to bf16; the grouped form runs the separate
+        # head kernel (fp32 FMAs, then the same rounding) -- a fraction of a percent of those bf16 values differ by one ulp, and the
+        # weight gradients that sum over them by ~1e-3 of the largest element (measured 1.2e-3).  A dropped pixel-range split would
+        # be off by its share of the sum: 3 % and up.
+        assert (a - c).abs().max().item() <= (2e-5 if dtype == torch.float32 else 4e-3) * scale
         assert torch.equal(c, r)                           # slabs + fixed-order reduction: no run-to-run wobble
     seen, dn = g1[2], g1[3]
     spans = [L.span for L in dn._layers()]
