@@ -23,6 +23,8 @@
 // current one (as k_wgrad3x3 does).  The grid is capped (tuning: bwd16_wgs) because every workgroup ends with 2304 + 16 atomics on the
 // SAME addresses.
 //
+// The two products run as one pinned software pipeline (operands of step n + 1 requested before the MFMAs of step n); the HEAD form makes
+// its gradient patch by MFMA from the split d(pre) patch (make_g below).
 // Built WITH -mllvm -amdgpu-mfma-vgpr-form (coivo_amd/build.py): the input-gradient accumulators are read every tile.
 #define COLVO_ACC_CONSTRAINT "+v"
 #include "conv_common.h"
@@ -61,13 +63,14 @@ constexpr int DH = PH + 2, DW = PW + 2;                                      // 
 // MODE 0: dy given.  1: HEAD form (dy made from the layer's output and the depth head's d(pre)).  2: HEAD form + the head's own weight
 // gradient.  Compile-time, not a kernel argument: a run-time branch around an MFMA makes hipcc merge the carried accumulators
 // through v_mov copies at the join -- reads of MFMA results in front of the guard (tools/isa_check_mfma.py).
-// Three workgroups per CU (168 VGPRs; the MODE 2 form would spill): with the grid at 3 x 256 the HEAD form's step is 0.7 % shorter
-// than with two (1.392 against 1.403 ms, same box; 768 workgroups at two per CU: 1.420 -- the third waits for a slot)
+// Workgroups per CU by the form's registers (round 5: 106 / 120 / 134 VGPRs): four, four, three -- bwd16_grid() sizes the grid in whole
+// rounds of them.  (Round 4's HEAD form needed 168 registers = three per CU; four instead of three measured level in the step,
+// 3.354 against 3.356 ms at 32 pairs, and 5 % faster alone at 64 frames.)
 #ifndef COLVO_BWD16_HEAD_WGS
 #define COLVO_BWD16_HEAD_WGS 4
 #endif
 template <int MODE>
-__global__ __launch_bounds__(NT, MODE == 2 ? 2 : MODE == 1 ? COLVO_BWD16_HEAD_WGS : 4) void k_bwd16(const Bwd16K a) {
+__global__ __launch_bounds__(NT, MODE == 2 ? 3 : MODE == 1 ? COLVO_BWD16_HEAD_WGS : 4) void k_bwd16(const Bwd16K a) {
     constexpr bool HEAD = MODE >= 1, headw = MODE == 2;
     __shared__ __attribute__((aligned(16))) char sG[NPIX * PIXB];
     __shared__ __attribute__((aligned(16))) char sX[NPIX * PIXB];
@@ -705,7 +708,7 @@ static int bwd16_grid(const ColvoConvDesc* d, int mode, int* tiles_per_wg) {
     // (256 CUs x 4 / 3 / 2 by the form's registers): until round 5 the HEAD form ran 1024 workgroups at 64 frames on 768 slots -- a
     // second round on a third of the chip; counters: the same wave cycles as the plain form in 1.7 x the time -- 226 us against 125
     int wgs = (int)TUNE(bwd16_wgs);
-    const int slots = 256 * (mode == 2 ? 2 : mode == 1 ? COLVO_BWD16_HEAD_WGS : 4);
+    const int slots = 256 * (mode == 2 ? 3 : mode == 1 ? COLVO_BWD16_HEAD_WGS : 4);
     const int want = std::min(4 * wgs, ntiles / 40);
     if (want > wgs) wgs = std::max(1, (want + slots / 2) / slots) * slots;
     if (wgs > ntiles) wgs = ntiles;
