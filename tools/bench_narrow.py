@@ -42,7 +42,7 @@ def main():
     bh = torch.tensor([0.3], device=dev)
     y = torch.empty(B, H, W, 16, device=dev, dtype=dt)
     depth = torch.empty(B, 1, H, W, device=dev)
-    pose_in = torch.zeros(B // 2, H, W, 8, device=dev, dtype=dt) if B % 2 == 0 else None
+    pose_in = torch.zeros(B // 2, H, W, 8, device=dev, dtype=dt) if B % 2 == 0 and not os.environ.get("NARROW_NO_POSE") else None
     px = B * H * W
     t = timed(lambda: ops.conv_head_fused(d, x, w, bias, wh, bh, y, depth, pose_in), n)
     by = px * (32 + 32 + 4 + (2 if pose_in is not None else 0))
