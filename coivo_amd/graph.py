@@ -119,7 +119,10 @@ class GraphedTrainStep:
         _lib.check(lib.colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
         _lib.check(lib.colvo_set_capture_carry(int(self.carry)), "colvo_set_capture_carry")
         _lib.check(lib.colvo_graph_stats_reset(), "colvo_graph_stats_reset")
-        self._check_process_group_environment()
+        if self._check_process_group_environment():
+            import time
+            torch.cuda.synchronize()            # every eager collective has finished on the GPU ...
+            time.sleep(0.25)                    # ... and the process group's watchdog (100 ms period) has taken it off its list
         g = torch.cuda.CUDAGraph()
         nspace = int(_lib.dev_env("COLVO_GRAPH_SPACER_STREAMS", "0"))       # (developer probe: streams created in front of the capture)
         self._spacers = [torch.cuda.Stream() for _ in range(nspace)]
@@ -153,26 +156,27 @@ class GraphedTrainStep:
         restore()          # capture itself does not execute, but keep the state exactly as the caller left it
         torch.cuda.synchronize()
 
-    def _check_process_group_environment(self) -> None:
-        """A captured step with RCCL collectives inside wants TORCH_NCCL_CUDA_EVENT_CACHE=0 in the environment BEFORE the process group
-        is created.  Round 5, tests/graph_rccl_worker.py, one run in two: the process group's watchdog thread ended the process with
-        'operation not permitted on an event last recorded in a capturing stream' from WorkNCCL::isCompleted() -- an event query on
-        an EAGER collective.  torch keeps captured collectives away from the watchdog, but it recycles their events through a
-        cache; an event recorded on RCCL's stream while that stream was part of a capture keeps its captured mark in this HIP runtime
-        when an eager collective re-records it, and the watchdog's query then fails.  Without the cache every eager collective gets
-        fresh events.  (A hypothesis from one stack trace; the setting costs an event creation per collective.)"""
-        import os
-        import warnings
+    def _check_process_group_environment(self) -> bool:
+        """True when the step carries RCCL collectives (an attached GradBuckets on an nccl group).
+
+        torch's ProcessGroupNCCL keeps every EAGER collective on a list its watchdog thread walks every 100 ms, asking each one's end
+        event whether it has completed; captured collectives never enter that list.  This HIP runtime refuses hipEventQuery on an
+        event whose stream is being captured at that moment ('operation not permitted on an event last recorded in a capturing
+        stream'), the refusal is an exception on the watchdog thread, and torch ends the process.  So an eager collective that is
+        still on the list -- finished on the GPU milliseconds ago, not yet reaped -- when RCCL's stream joins a capture kills the
+        process if the watchdog wakes inside that window: round 5 saw it twice in about a dozen runs of tests/graph_rccl_worker.py
+        (eager data-parallel steps right in front of the capture; the 64-pair shape, whose capture takes ~0.1 s, more often), the
+        second time WITH the event cache off -- which retires the round's first hypothesis (a recycled event keeping its captured
+        mark; TORCH_NCCL_CUDA_EVENT_CACHE=0 is still what bench.py and the tests export: fresh events per collective cost nothing
+        measurable).  capture() therefore drains the device and sleeps two watchdog periods before it begins: the list is empty when
+        the capture starts, and nothing eager is issued until it ends."""
         if self.ddp is None:
-            return
+            return False
         try:
             import torch.distributed as dist
-            nccl = dist.is_initialized() and dist.get_backend(self.ddp.group) == "nccl"
+            return bool(dist.is_initialized() and dist.get_backend(self.ddp.group) == "nccl")
         except Exception:           # noqa: BLE001
-            nccl = False
-        if nccl and os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "1").strip().lower() not in ("0", "false", "off", "no", "n"):
-            warnings.warn("hipGraph capture with RCCL collectives inside: export TORCH_NCCL_CUDA_EVENT_CACHE=0 before "
-                          "init_process_group (GraphedTrainStep._check_process_group_environment says why)", RuntimeWarning, stacklevel=3)
+            return False
 
     def close(self) -> None:
         """Destroy the captured graph NOW, at a defined point, and return the library to its pre-capture state.
