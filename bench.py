@@ -29,8 +29,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--rccl-single" in sys.argv:
     # initialisation, so it has to be in the environment before torch is imported.  A value the user exported is left alone
     # (coivo_amd.streams warns about 3..7); the effective value is reported in the JSON line (`hw_queues`).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # a captured step (configs[4]) holds RCCL collectives: fresh events for every eager collective instead of recycled ones that
-    # may carry a captured mark (coivo_amd/graph.py _check_process_group_environment); read when the process group is created
+    # a captured step (configs[4]) holds RCCL collectives: fresh events for every eager collective instead of recycled ones (kept from
+    # round 5's first reading of a watchdog failure; what actually guards the capture is the quiet period in GraphedTrainStep.capture(),
+    # coivo_amd/graph.py _check_process_group_environment); read when the process group is created
     os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
 
 import torch
