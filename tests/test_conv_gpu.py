@@ -263,6 +263,37 @@ def test_pack_roundtrip_and_relu_bwd(dtype):
     assert torch.equal(dy, ref)
 
 
+def test_pair_conversion_to_bf16_is_torchs_rounding_bit_for_bit():
+    """pack2bf (csrc/common.h: one v_cvt_pk_bf16_f32 per pair, in every bf16 epilogue of the library since round 5) against
+    Tensor.to(bfloat16) through colvo_cast_f32_bf16, whose vector body uses it and whose tail uses the scalar f2bf(): random values over
+    the whole exponent range, exact ties to even in both directions, the largest finite values (rounding to infinity), denormals,
+    signed zeros, infinities and NaNs; a length that leaves a scalar tail; and the way back."""
+    import ctypes as C
+    from coivo_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n = 4 * 4099 + 3
+    x = torch.randn(n, generator=g) * torch.exp(torch.randn(n, generator=g) * 12.0)
+    bits = torch.randint(0, 2 ** 31 - 1, (n,), generator=g, dtype=torch.int64).to(torch.int32)
+    x[: n // 2] = bits[: n // 2].view(torch.float32)                 # arbitrary bit patterns (NaNs, denormals, huge values included)
+    special = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8,
+                            -(1.0 + 2.0 ** -8), 3.3895313892515355e38, 3.4028234663852886e38, 1e-40, -1e-40, 2.0 ** -133])
+    x[-special.numel():] = special
+    xd = x.to(dev())
+    ref = xd.to(torch.bfloat16)
+    out = torch.empty(n, device=dev(), dtype=torch.bfloat16)
+    lib = _lib.load()
+    _lib.check(lib.colvo_cast_f32_bf16(_lib.ptr(xd), _lib.ptr(out), n, 1, _lib.stream_ptr()), "colvo_cast_f32_bf16")
+    torch.cuda.synchronize()
+    a, b = out.view(torch.int16), ref.view(torch.int16)
+    nan = torch.isnan(ref.float())
+    assert torch.equal(torch.isnan(out.float()), nan)
+    assert torch.equal(a[~nan], b[~nan]), f"{int((a[~nan] != b[~nan]).sum())} of {n} values round differently"
+    back = torch.empty(n, device=dev(), dtype=torch.float32)
+    _lib.check(lib.colvo_cast_f32_bf16(_lib.ptr(out), _lib.ptr(back), n, 0, _lib.stream_ptr()), "colvo_cast_f32_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(back[~nan], ref.float()[~nan])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_depth_head(dtype):
     from coivo_amd import ops
