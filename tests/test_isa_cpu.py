@@ -43,3 +43,17 @@ def test_no_rotated_mfma_result_is_read_early(tmp_path, src, min_mfma, min_kerne
         # and for f32 the hardware interlock), and for a rotated MFMA only after the wait states `check` demanded above --
         # the 1024-thread team kernels (128 registers per lane) do contain rotated MFMAs, so make sure they were looked at
         assert nrot < nmfma
+
+
+@pytest.mark.parametrize("src,pat", [("fwd16.hip", "k_fwd16_head"), ("bwd16.hip", "k_bwd16"), ("conv_rt.hip", "k_conv_rt")])
+def test_hand_pipelined_kernels_keep_their_operand_reads_ahead_of_the_mfmas(src, pat):
+    """Round 5: hipcc had sunk every LDS read of k_fwd16_head / k_bwd16 / the first k_conv_rt to just in front of the MFMA that needs it
+    ("ds_read, s_waitcnt lgkmcnt(0), v_mfma": 25 / 22 exposed LDS round trips per tile).  Their operand sets
+    are now requested one step ahead and pinned with sched_barrier; this holds the emitted ISA to it: no MFMA directly behind a FULL
+    drain of the LDS queue that follows a read (counted waits with younger reads in flight are what the pipeline looks like)."""
+    import isa_sunk_reads
+    res = isa_sunk_reads.count(src, pat)
+    assert res, (src, pat)
+    for name, n_mfma, sunk in res:
+        assert n_mfma >= 20, (name, n_mfma)
+        assert sunk == 0, f"{name}: {sunk} of {n_mfma} MFMAs wait for an LDS read issued right in front of them"
