@@ -378,18 +378,36 @@ def main():
             if "device_id" in kw:
                 kw["device_id"] = dev
             dist.init_process_group(plan["backend"], **kw)
-        if dist.is_initialized():
+        host_pg = None
+        if dist.is_initialized() and dist.get_backend() == "nccl":
+            # RCCL runs through its own C ABI on the group's communicator (coivo_amd.ddp._NativeRccl): torch must then keep its own
+            # collectives off that communicator -- they would run on torch's internal stream, a fifth hardware queue beside the
+            # step's four (2.7 x slower steps).  The ranks' host-side synchronisation (barriers around the timed region, the max of
+            # the elapsed times) goes over a gloo side group; where that cannot be made the ProcessGroup path stays as it was.
+            if os.environ.get("COLVO_DDP_TORCH_COLLECTIVES", "0") in ("", "0"):
+                try:
+                    host_pg = dist.new_group(backend="gloo")
+                except Exception as e:          # noqa: BLE001
+                    print(f"[bench] no gloo side group ({type(e).__name__}: {e}): RCCL through ProcessGroup.allreduce", file=sys.stderr)
+        if dist.is_initialized() and host_pg is None:
             # the first collective creates the communicator (and prints the banner): do it here, on a throw-away tensor
             t0_ = torch.zeros(1, device=dev if plan["backend"] != "gloo" or args.rccl_single else "cpu")
             dist.all_reduce(t0_)
             if t0_.is_cuda:
                 torch.cuda.synchronize()
 
+    def rank_barrier():
+        """Every rank has reached this point (host side over gloo when RCCL is driven natively, else the group's own barrier)."""
+        if world > 1:
+            if host_pg is not None:
+                dist.barrier(group=host_pg)
+            else:
+                dist.barrier()
+
     from coivo_amd import build as _colvo_build      # fresh checkout / edited kernels: (re)build in-tree, rank 0 first
     if local_rank == 0:
         _colvo_build.ensure()
-    if world > 1:
-        dist.barrier()
+    rank_barrier()
     from coivo_amd import functional as Fh
     from coivo_amd import nn as hnn
     from coivo_amd import synth
@@ -413,7 +431,7 @@ def main():
     if world > 1 or args.rccl_single:
         ddp = GradBuckets([dn, pn], bucket_bytes=args.bucket_mb << 20,
                           transport_dtype=torch.bfloat16 if args.grad_transport == "bf16" else None,
-                          exact_batch_loss=not args.per_rank_loss)
+                          exact_batch_loss=not args.per_rank_loss, native_collectives=host_pg is not None)
         opt.grad_scale = ddp.grad_scale
     batch = synth.make_batch(B, H, W, seed=1234 + rank, device=dev)
     frames = torch.cat([batch["tgt"], batch["ref"]], dim=0)      # one resident buffer: target frames, then reference
@@ -489,8 +507,9 @@ def main():
         return (time.perf_counter() - t_) / n * 1e3
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        # (device drained first: with the host-side barrier nothing of it is queued behind the step)
+        torch.cuda.synchronize()
+        rank_barrier()
         torch.cuda.synchronize()
 
     if args.graph == "best" and not args.spec_calls:
@@ -560,8 +579,8 @@ def main():
         print("step ms:", " ".join(f"{v:.2f}" for v in ev_raw), file=sys.stderr)
     ev_ms = sorted(ev_raw)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], device=dev if host_pg is None else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_pg)
         elapsed = t.item()
     final_loss = loss.item()
     first_loss = first_loss.item() if first_loss is not None else final_loss
@@ -668,8 +687,7 @@ def main():
     elif not args.no_side_measurements:
         for _ in range(10):
             eager_step()
-    if world > 1:
-        dist.barrier()
+    rank_barrier()
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -721,6 +739,8 @@ def main():
                           "global_batch": world * B, "height": H, "width": W,
                           "parallelism": f"dp{world}" + (" (one rank through the RCCL path)" if args.rccl_single else ""),
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
+                          "collectives": (None if ddp is None else "ncclAllReduce on the group's communicator, called natively"
+                                          if ddp.native_collectives else "ProcessGroup.allreduce"),
                           "batch_loss": (None if ddp is None else "one masked mean over the global batch (valid-pixel count all-reduced)"
                                          if ddp.exact_batch_loss else "mean of the per-rank masked means"),
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
@@ -765,9 +785,9 @@ def main():
         elif world == 1:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    rank_barrier()
     if world > 1 or args.rccl_single:
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -42,6 +42,103 @@ class _ArenaState:
         self.staging = None             # persistent transport-dtype copy of the arena (reduced-precision transport only)
 
 
+class _NativeRccl:
+    """The process group's RCCL communicator, called through RCCL's own C ABI (round 5).
+
+    ProcessGroupNCCL.allreduce costs ~35 us of host time a call -- work object, event pair, stream bookkeeping, watchdog list --
+    and an 8-pair step issues eight collectives from inside its backward pass, where the host is what the GPU waits for: the
+    one-rank RCCL step ran +7...30 % over the plain one depending on the box's host.  torch keeps owning the
+    communicator (creation, rank layout, teardown); `_comm_ptr()` hands its ncclComm_t over once, and a collective is then ONE
+    ctypes call of ncclAllReduce on a stream of ours, ordered by two event operations -- in place, capturable (RCCL supports stream
+    capture), invisible to torch's watchdog (no eager work objects: the hazard GraphedTrainStep.capture() guards against is gone).
+
+    Rules this object lives by:
+      * ONE stream carries every collective of the communicator, in issue order -- exactly what ProcessGroupNCCL's internal stream
+        does -- so NCCL's "operations of one communicator never run concurrently, same order on every rank" holds by construction;
+      * torch must not run collectives of its own on this communicator while the object is in use: they would go to torch's internal
+        stream (concurrency with ours), and that stream would become a FIFTH active hardware queue -- the step then runs 2.7 x slower
+        (streams.py; measured with this very class before it stopped asking torch for a warm-up collective: 3.5 ms instead of 1.3).
+        bench.py therefore synchronises its ranks over a gloo side group; barrier() below is the device-side alternative."""
+
+    _F32, _BF16, _SUM = 7, 9, 0          # ncclFloat32, ncclBfloat16, ncclSum (nccl.h / rccl.h)
+
+    def __init__(self, group):
+        import ctypes as C
+        dev = torch.device("cuda", torch.cuda.current_device())
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        backend = pg._get_backend(dev)
+        if not hasattr(backend, "_comm_ptr"):
+            raise RuntimeError("this torch build does not expose ProcessGroupNCCL._comm_ptr()")
+        try:
+            comm = int(backend._comm_ptr())
+        except Exception:           # noqa: BLE001 -- no communicator yet (init_process_group without device_id): create it, no collective
+            comm = 0
+        if not comm:
+            backend.eager_connect_single_device(dev)
+            comm = int(backend._comm_ptr())
+        if not comm:
+            raise RuntimeError("ProcessGroupNCCL._comm_ptr() returned NULL")
+        self.comm = comm
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = C.CDLL(path if os.path.exists(path) else "librccl.so")         # the copy torch itself has loaded
+        self._fn = lib.ncclAllReduce
+        self._fn.restype = C.c_int
+        self._fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self._err = lib.ncclGetErrorString
+        self._err.restype = C.c_char_p
+        self._err.argtypes = [C.c_int]
+        self.world = dist.get_world_size(group)
+        self.stream = torch.cuda.Stream(device=dev)           # the collectives' own queue (the one streams.py budgets for RCCL)
+        self._ev = torch.cuda.Event()                         # "everything the collective reads has been enqueued" (re-recorded per call)
+        self._ev_back = torch.cuda.Event()
+        self.dirty = False                                    # collectives issued on `stream` since the last join()
+        # self-check with known values, before anything depends on it (also the communicator's first collective)
+        self._probe = torch.full((8,), 1.5, device=dev)
+        self.all_reduce(self._probe)
+        self.join()
+        torch.cuda.synchronize()
+        if not torch.equal(self._probe.cpu(), torch.full((8,), 1.5 * self.world)):
+            raise RuntimeError(f"native ncclAllReduce self-check failed: {self._probe.tolist()} (world {self.world})")
+
+    def _call(self, t: torch.Tensor) -> None:
+        code = self._F32 if t.dtype == torch.float32 else self._BF16 if t.dtype == torch.bfloat16 else None
+        if code is None or not t.is_contiguous():
+            raise TypeError(f"native all-reduce of a {t.dtype} / non-contiguous tensor")
+        rc = self._fn(t.data_ptr(), t.data_ptr(), t.numel(), code, self._SUM, self.comm, self.stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"ncclAllReduce failed: {self._err(rc).decode('utf-8', 'replace')} ({rc})")
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """In-place sum over the ranks on the collectives' stream, ordered after everything enqueued on the CURRENT stream so far;
+        join() makes a stream wait for it."""
+        self._ev.record()                                     # on the current stream
+        self.stream.wait_event(self._ev)
+        self._call(t)
+        self.dirty = True
+
+    def all_reduce_now(self, t: torch.Tensor) -> None:
+        """In-place sum the CURRENT stream waits for at once (the two-float loss state between forward and backward)."""
+        was = self.dirty
+        self.all_reduce(t)
+        self._ev_back.record(self.stream)
+        torch.cuda.current_stream().wait_event(self._ev_back)
+        self.dirty = was            # (what was pending for join() before still is: join() may run on another stream)
+
+    def join(self) -> None:
+        """The current stream waits for every collective issued so far."""
+        if self.dirty:
+            self._ev_back.record(self.stream)
+            torch.cuda.current_stream().wait_event(self._ev_back)
+            self.dirty = False
+
+    def barrier(self) -> None:
+        """Every rank has reached this point and this rank's device is idle (a one-element all-reduce, then a host wait)."""
+        self._probe.fill_(1.0)
+        self.all_reduce(self._probe)
+        self.join()
+        torch.cuda.synchronize()
+
+
 class GradBuckets:
     """Bucketed, overlapped gradient all-reduce over the flat arenas of `modules`.
 
@@ -50,13 +147,19 @@ class GradBuckets:
     """
 
     def __init__(self, modules: Sequence, process_group=None, bucket_bytes: int = 16 << 20,
-                 transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20, exact_batch_loss: bool = True):
+                 transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20, exact_batch_loss: bool = True,
+                 native_collectives: bool = False):
         """exact_batch_loss (default): the photometric loss is normalised by the valid-pixel count of the WHOLE batch, as the spec
         does (oracle/SPEC.md section 5), not per rank: functional.photometric_loss all-reduces two floats (valid pixels, masked sum)
         right after its forward kernel and every rank scales its raw gradients by world / max(3 n_global, 1) -- data parallel then
         IS the spec's big-batch step (tests/ddp_gpu_worker.py compares with the oracle's plain batch loss).  False: the mean of the
         per-rank masked means (rounds 1-4), which differs when the ranks' valid-pixel counts do; saves one tiny collective between
-        forward and backward.  The widened objective (dcdp_full_loss) keeps per-rank normalisers either way."""
+        forward and backward.  The widened objective (dcdp_full_loss) keeps per-rank normalisers either way.
+        native_collectives=True: RCCL called through its own C ABI on the group's communicator (_NativeRccl: half the host cost per
+        collective) instead of through ProcessGroup.allreduce -- for an nccl group with GPU arenas, unless COLVO_DDP_TORCH_COLLECTIVES=1
+        is exported.  An opt-in because it binds the CALLER: no torch collective may run on this group from before the attach to the
+        detach (it would add torch's internal stream as a fifth hardware queue: steps 2.7 x slower; see _NativeRccl) -- barriers and
+        logging reductions go over a gloo side group or GradBuckets.barrier().  bench.py opts in when its gloo group exists."""
         if not dist.is_initialized():
             raise RuntimeError("GradBuckets needs an initialised torch.distributed process group")
         self.group = process_group
@@ -102,6 +205,19 @@ class GradBuckets:
         # threads are then torn down at interpreter exit -- "terminate called without an active exception", one gloo worker in three)
         self._sum = dist.AllreduceOptions()
         self._sum.reduceOp = dist.ReduceOp.SUM
+        # ... and on the GPU, past torch altogether: RCCL's own entry point on the group's communicator (_NativeRccl).
+        # COLVO_DDP_TORCH_COLLECTIVES=1 (or native_collectives=False) keeps the ProcessGroup calls; a torch build without _comm_ptr()
+        # falls back with a warning.
+        self._native = None
+        if (native_collectives and os.environ.get("COLVO_DDP_TORCH_COLLECTIVES", "0") in ("", "0")
+                and dist.get_backend(process_group) == "nccl"
+                and any(getattr(m, "flat_grad", None) is not None and m.flat_grad.is_cuda for m in modules)):
+            try:
+                self._native = _NativeRccl(process_group)
+            except Exception as e:          # noqa: BLE001 -- the torch path is complete on its own
+                import warnings
+                warnings.warn(f"GradBuckets: native RCCL path unavailable ({type(e).__name__}: {e}); using ProcessGroup.allreduce",
+                              RuntimeWarning, stacklevel=2)
 
     @staticmethod
     def _cast(src: torch.Tensor, dst: torch.Tensor, to_transport: bool) -> None:
@@ -134,8 +250,24 @@ class GradBuckets:
         from . import _lib
         # (also with one rank: `bench.py --rccl-single` then prices this collective like the bucket ones, and the state comes back
         # bit for bit -- a one-rank sum is the identity and the rescale repeats the forward's own arithmetic)
-        self._all_reduce(state[2:4]).wait()                                           # (the caller's stream waits for it)
+        if self._native is not None:
+            self._native.all_reduce_now(state[2:4])
+        else:
+            self._all_reduce(state[2:4]).wait()                                       # (the caller's stream waits for it)
         _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(state), self.world, _lib.stream_ptr()), "colvo_warp_loss_rescale")
+
+    def barrier(self) -> None:
+        """All ranks here, this rank's device idle -- without a torch collective on the group when the native path is on."""
+        if self._native is not None:
+            self._native.barrier()
+        else:
+            dist.barrier(group=self.group)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+
+    @property
+    def native_collectives(self) -> bool:
+        return self._native is not None
 
     @property
     def grad_scale(self) -> float:
@@ -185,12 +317,15 @@ class GradBuckets:
 
     def _launch_bucket(self, st: _ArenaState, lo: int, hi: int) -> None:
         sl = st.module.flat_grad[lo:hi]
+        buf = None
         if st.staging is not None:
             buf = st.staging[lo:hi]
             self._cast(sl, buf, True)    # conversion on the stream the hook runs on; the collective is ordered after it
-            self._pending.append((self._all_reduce(buf), sl, buf))
+        if self._native is not None:
+            self._native.all_reduce(sl if buf is None else buf)
+            self._pending.append((None, sl if buf is not None else None, buf))
         else:
-            self._pending.append((self._all_reduce(sl), None, None))
+            self._pending.append((self._all_reduce(sl if buf is None else buf), sl if buf is not None else None, buf))
 
     # ---- step side ----------------------------------------------------------------------------- #
     def finish(self) -> None:
@@ -203,8 +338,11 @@ class GradBuckets:
             while st.next < len(st.bounds):     # layers that reported out of order / never reported
                 self._launch(st, st.bounds[st.next], st.bounds[st.next - 1])
                 st.next += 1
+        if self._native is not None:
+            self._native.join()
         for work, sl, buf in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
             if buf is not None:
                 self._cast(buf, sl, False)
         self._pending.clear()

@@ -43,8 +43,12 @@ def main():
     frames = torch.cat([b["tgt"], b["ref"]])
     dn1, pn1, opt1 = setup(seed)
     dn2, pn2, opt2 = setup(seed)
-    ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport)
-    ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport)
+    # (RCCL called natively on the group's communicator, ddp._NativeRccl: this worker runs no torch collective on the group; `... torch`
+    #  as the last argument keeps ProcessGroup.allreduce)
+    native = sys.argv[-1] != "torch"
+    ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
+    ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
+    assert ddp1.native_collectives == native and ddp2.native_collectives == native
     step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
     assert step.capture_group == (1 if B >= 32 else 2)
     eager, graphed = [], []

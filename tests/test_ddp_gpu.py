@@ -85,13 +85,19 @@ def test_rccl_path_with_one_rank():
               "--steps", "30", "--warmup", "5",
               "--graph", "off"]        # (the one-GPU default `best` runs 23 more steps before the warm-up: different final loss)
     out = {}
-    for tag, extra in (("plain", []), ("rccl", ["--rccl-single"]), ("rccl_bf16", ["--rccl-single", "--grad-transport", "bf16"])):
-        r = subprocess.run(common + extra, capture_output=True, text=True, env=env, timeout=300, cwd=root)
+    # rccl: RCCL called natively on the group's communicator (ddp._NativeRccl, the default since round 5); rccl_torch: the same step
+    # through ProcessGroup.allreduce (COLVO_DDP_TORCH_COLLECTIVES=1), the fallback
+    for tag, extra, e in (("plain", [], {}), ("rccl", ["--rccl-single"], {}), ("rccl_bf16", ["--rccl-single", "--grad-transport", "bf16"], {}),
+                          ("rccl_torch", ["--rccl-single"], {"COLVO_DDP_TORCH_COLLECTIVES": "1"})):
+        r = subprocess.run(common + extra, capture_output=True, text=True, env=dict(env, **e), timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = json.loads(r.stdout.strip().split("\n")[-1])
         assert out[tag]["deterministic_weight_gradients"]
     assert out["rccl"]["final_loss"] == out["plain"]["final_loss"], (out["rccl"]["final_loss"], out["plain"]["final_loss"])
-    assert out["rccl"]["first_loss"] == out["plain"]["first_loss"] == out["rccl_bf16"]["first_loss"]
+    assert out["rccl_torch"]["final_loss"] == out["plain"]["final_loss"], (out["rccl_torch"]["final_loss"], out["plain"]["final_loss"])
+    assert out["rccl"]["first_loss"] == out["plain"]["first_loss"] == out["rccl_bf16"]["first_loss"] == out["rccl_torch"]["first_loss"]
+    assert "natively" in out["rccl"]["config"]["collectives"] and "natively" in out["rccl_bf16"]["config"]["collectives"]
+    assert out["rccl_torch"]["config"]["collectives"] == "ProcessGroup.allreduce" and out["plain"]["config"]["collectives"] is None
     # bf16 transport rounds every gradient element to bf16 before Adam.  WHAT it does to the arena is pinned exactly by
     # test_bf16_gradient_transport_is_exactly_a_bf16_rounding below; what that does to a 35-step trajectory is not derivable -- to
     # first order the loss change D = |first_loss - final_loss| moves by O(2^-8 D), but ReLU / validity decisions that flip on the
@@ -101,6 +107,7 @@ def test_rccl_path_with_one_rank():
         (out["rccl_bf16"]["final_loss"], out["plain"]["final_loss"], D)
     assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
     assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
+    assert out["rccl_torch"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
 
 
 def test_bf16_gradient_transport_is_exactly_a_bf16_rounding():
