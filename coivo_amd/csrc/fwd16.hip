@@ -12,14 +12,16 @@
 //
 // Layout per workgroup (256 threads = 4 waves, a tile = 8 rows x 16 columns of outputs):
 //   sU  input patch [12 x 20 pixels][16 ci] bf16, 32 B per pixel       sY  y on [10 x 18 positions][16 co] bf16
-//   weights (layer: [16 co][10 taps][16 ci], tap 9 = zeros; head: see below): MFMA operands resident in registers (round 5)
+//   sWh the head's weight operand [16 rows][10 taps][16 c] (see below), read inside the head's pipeline
+//   the layer's weights ([16 co][10 taps][16 ci], tap 9 = zeros): five MFMA operand fragments per lane, resident in registers (round 5)
 //   layer:  position fragments of 16 consecutive patch positions (12 fragments cover 192 >= 180), wave w owns fragments 3w .. 3w + 2;
 //           5 k-steps of two taps; operands swapped as in k_conv3x3 (accumulator = 4 consecutive channels of one position)
 //   head:   an MFMA of the same shape (16 pixels x K = 9 taps x 16 channels) against a weight operand whose row 0 is the bf16 rounding
 //           of the fp32 head weights and row 1 what that rounding left over: hi + lo sums = the fp32-weight product to 2^-17.  (The
 //           first version evaluated the head on the VALU, two threads per pixel: 280 of the kernel's ~480 issue slots per wave and
 //           tile -- the kernel was issue-bound at 33.6 us in the step for 89 MB of traffic.)
-// A workgroup walks `tiles_per_wg` consecutive tiles with the next tile's patch in flight during the MFMAs.
+// A workgroup walks `tiles_per_wg` consecutive tiles with the next TWO tiles' patches in flight (two register sets); the operand
+// fragments of k-step s + 1 are requested before the MFMAs of step s and the order is pinned (round 5: DESIGN.md section 3.2).
 #define COLVO_ACC_CONSTRAINT "+v"
 #include "conv_common.h"
 
