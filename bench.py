@@ -386,6 +386,8 @@ def main():
             # the elapsed times) goes over a gloo side group; where that cannot be made the ProcessGroup path stays as it was.
             if os.environ.get("COLVO_DDP_TORCH_COLLECTIVES", "0") in ("", "0"):
                 try:
+                    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+                        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: do not depend on the host name resolving
                     host_pg = dist.new_group(backend="gloo")
                 except Exception as e:          # noqa: BLE001
                     print(f"[bench] no gloo side group ({type(e).__name__}: {e}): RCCL through ProcessGroup.allreduce", file=sys.stderr)
