@@ -28,7 +28,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-
 # statement with "+v", and an AGPR accumulator would be copied out (= read) in front of that statement
 # (profiles/r2_mfma_hazard.md).  wgrad.hip keeps AGPR accumulators (faster pixel loop) and ties them with "+a".
 FILE_FLAGS = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "bwd16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-              "fwd16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_rt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+              "fwd16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "conv_rt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+              "wgrad_rt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _deps():

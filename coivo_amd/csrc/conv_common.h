@@ -55,6 +55,17 @@ struct ConvK {
 // conv_rt.hip: register-tiled stride-1 kernel for large grids (forward and input gradient); -1: the layer does not qualify
 int try_launch_conv_rt(const ConvK& k, int B, int dtype, hipStream_t s);
 
+// wgrad_rt.hip: register-tiled weight gradient (bf16, stride 1).  wgrad.hip asks for a plan (false: the layer does not qualify), sets up
+// the way out that the plan's split count calls for (atomics / slabs / sole writer), launches, and runs its own second launch if any.
+struct WgradRtPlan {
+    int ni, toh, tow, pwl, pimg, ksteps, xinstr;
+    int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
+    int nci0, nci, nco;
+};
+bool wgrad_rt_plan(const ColvoConvDesc* d, WgradRtPlan& p);
+int wgrad_rt_launch(const WgradRtPlan& p, const ColvoConvDesc* d, const void* x0, const void* x1, const void* dy, float* dw, float* db,
+                    float* slabs, float* db_slabs, int det, hipStream_t s);
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;

@@ -1204,10 +1204,20 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
     k.scratch = (const char*)scratch; k.scratch_bytes = scratch ? (long long)scratch_bytes : 0; k.plan_out = plan_out;
     k.slabs_only = slabs_only;
     k.clean = clean;
+    // single up-sampled source in whole 32-channel (bf16) / 16-channel (f32) chunks: the four-class form over source positions
+    const int ck = d->dtype == COLVO_F32 ? 16 : 32;
+    const bool up2_form = TUNE(wgrad_up2) && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->Cout >= 16;
     {
-        // single up-sampled source in whole 32-channel (bf16) / 16-channel (f32) chunks: the four-class form over source positions
-        const int ck = d->dtype == COLVO_F32 ? 16 : 32;
-        if (TUNE(wgrad_up2) && d->up0 && d->C1 == 0 && d->stride == 1 && d->C0 % ck == 0 && d->Cout >= 16) {
+        // bf16 stride-1 layers: the register-tiled form (csrc/wgrad_rt.hip); the ways out are set up here exactly as for the kernels below
+        WgradRtPlan rp;
+        if ((!up2_form || TUNE(wgrad_rt_over_up2)) && wgrad_rt_plan(d, rp)) {
+            { int err; if (wgrad_prepare(k, rp.nsplit, &err)) return err; }
+            if (int e = wgrad_rt_launch(rp, d, x0, d->C1 ? x1 : nullptr, dy, dw, db, k.slabs, k.db_slabs, k.det, (hipStream_t)stream)) return e;
+            return wgrad_finish(k, rp.nsplit, (hipStream_t)stream);
+        }
+    }
+    {
+        if (up2_form) {
             const int Hs = d->Hi / 2, Ws = d->Wi / 2;
             const Tile t = pick_tile(Hs, Ws, 1, false);
             if ((t.toh + 2) * (t.tow + 2) * 4 <= 3 * NT) {

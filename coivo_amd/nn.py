@@ -221,8 +221,36 @@ class _ArenaModule(nn.Module):
 
     # True while the gradient arena is known to be all zero (set by optim.FusedAdam(zero_grad_in_step=True).step(), cleared by every
     # backward pass): the optimizer's zero_grad() then skips its launch
-    _grads_clean = False
     _arena_zero_for_pass = False        # _grads_clean as the running backward pass found it (handed to its weight-gradient commands)
+    _clean_flag = False
+    _clean_version = -1
+    _clean_in_capture = False
+
+    # "The gradient arena is all zero."  Setting the flag records the arena's version counter: every torch-side write to a .grad view
+    # (AccumulateGrad for a parameter that is also used outside the fused network, a manual p.grad.add_) bumps it, the library's own
+    # kernels -- raw pointers -- do not; the flag reads True only while the counter is where the clearing left it.  Set while a stream
+    # is being captured (the graph holds the clearing launch, nothing has executed) it holds inside that capture only: a capture that
+    # fails, or ends, leaves it False.  (the flag alone was unguarded, and single-split layers STORE into an arena they
+    # believe to be zero; an eager zero_grad() skips its launch on it.)
+    @property
+    def _grads_clean(self) -> bool:
+        if not self._clean_flag or self.flat_grad is None:
+            return False
+        if self._clean_in_capture:
+            return torch.cuda.is_current_stream_capturing()
+        return self.flat_grad._version == self._clean_version
+
+    @_grads_clean.setter
+    def _grads_clean(self, clean: bool) -> None:
+        self._clean_flag = bool(clean)
+        if clean and self.flat_grad is not None:
+            self._clean_version = self.flat_grad._version
+            self._clean_in_capture = self.flat_grad.is_cuda and torch.cuda.is_current_stream_capturing()
+
+    def _take_arena_zero(self) -> None:
+        """Opens a backward pass: 'the arena is still zero' goes to its weight-gradient commands, and stops being true."""
+        self._arena_zero_for_pass = self._grads_clean
+        self._clean_flag = False
 
     def attach_grads(self) -> None:
         """Point every p.grad at its arena view (zeroing the arena if grads were set to None)."""
@@ -242,7 +270,7 @@ class _ArenaModule(nn.Module):
         if self.flat_grad is not None:
             ops.zero_(self.flat_grad)          # one hipMemsetAsync, no torch fill kernel
             self.attach_grads()
-            self._grads_clean = True           # until a backward pass -- or anything else that writes .grad: unguarded -- touches it
+            self._grads_clean = True           # until a backward pass -- or a torch-side write to .grad (version counter) -- touches it
 
     def mark_params_changed(self) -> None:
         self._manual_version += 1
@@ -512,19 +540,24 @@ class _ArenaModule(nn.Module):
         elif self._join_pending and self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side)
         self._join_pending = False
+        self._stored_pass_open = False
+
+    _stored_pass_open = False            # a backward pass of this network stored (not added) its weight gradients and is not joined yet
 
     def _order_deterministic_pass(self) -> None:
         """Deterministic mode, a SECOND backward pass of this network while the first one's weight gradients may still be running on
         the side streams (deferred join: one network applied twice inside one backward): the one-split write-out of
         colvo_conv_wgrad_det adds to dw / db with a plain read-modify-write -- sole writer within a launch, not across two launches on
         different streams -- so the earlier pass's side work is joined first.  The default (atomic) form needs no order."""
-        if not self.deterministic:
-            return
-        if torch.cuda.is_current_stream_capturing():
-            if self._cap_side_open:          # (carry mode leaves this network's side chain open; policy 3 has two of them)
+        # (ADVICE r5: the same holds for an earlier pass that STORED into the clean arena -- colvo_conv_wgrad_clean -- while this one adds
+        #  with atomics: an add that lands before the store is lost.  Such a pass is joined too.)
+        if self.deterministic or self._stored_pass_open:
+            if torch.cuda.is_current_stream_capturing():
+                if self._cap_side_open:          # (carry mode leaves this network's side chain open; policy 3 has two of them)
+                    self.join_side()
+            elif self._join_pending:
                 self.join_side()
-        elif self._join_pending:
-            self.join_side()
+        self._stored_pass_open = self._arena_zero_for_pass
 
     def _layer_done(self, L: ConvParams) -> None:
         if self._rec is not None:
@@ -610,7 +643,10 @@ class DepthNet(_ArenaModule):
         `d[B:]` with B = half the batch, returns the two halves as OUTPUTS of the network's autograd node (as forward_pair_split
         does) instead of slices of one output: no slice-backward nodes (zero-fill + copy + add each), PoseNet's input can come
         from the pass, and photometric_loss(.., d[:B], ..) finds the loss's own gradient path (functional.photometric_loss)."""
+        # (the pair form exists for the backward pass: under no_grad / inference_mode -- where tensors carry no version counter for
+        #  its tags, and the extra PoseNet-input buffer would only be kept alive -- the plain node runs.  ADVICE r5)
         if (img.dim() == 4 and img.shape[0] % 2 == 0 and img.shape[0] >= 2 and self.use_programs
+                and torch.is_grad_enabled() and not torch.is_inference_mode_enabled()
                 and _lib.dev_env("COLVO_NO_PAIR_FORWARD") is None):
             from .functional import GradHandover
             hand = GradHandover()
@@ -699,7 +735,8 @@ class DepthNet(_ArenaModule):
         img = img.contiguous()
         depth = torch.empty(B, 1, H, W, device=img.device, dtype=torch.float32)
         fuse_top = ops.conv_head_fused_ok(P["iconv1"]) and _lib.dev_env("COLVO_NO_FWD16") is None
-        pose_fill = pair and fuse_top and B % 2 == 0 and _lib.dev_env("COLVO_NO_POSE_FILL") is None
+        pose_fill = (pair and fuse_top and B % 2 == 0 and not torch.is_inference_mode_enabled()      # (its tag reads version counters)
+                     and _lib.dev_env("COLVO_NO_POSE_FILL") is None)
         inst = self._acquire((B, H, W, self.compute_dtype, pose_fill))
 
         def body():
@@ -740,8 +777,7 @@ class DepthNet(_ArenaModule):
         """d_depth [B,1,H,W], or parts = (g_first, g_second, g_raw, scale_a, scale_b[, g_raw_second]): the gradient of the
         first / second half of the images and a (scaled) addend for each half (ops.depth_head_bwd_parts), each may be None."""
         A, P, inst = saved
-        self._arena_zero_for_pass = self._grads_clean
-        self._grads_clean = False
+        self._take_arena_zero()
         self.attach_grads()
         self._order_deterministic_pass()
         B, _, H, W = depth.shape
@@ -1014,8 +1050,7 @@ class PoseNet(_ArenaModule):
 
     def _backward_impl(self, saved, d_pose, d_a, d_b, scale_a=None, scale_b=None):
         A, P, (B, H, W), has_depth, inst, filled = saved
-        self._arena_zero_for_pass = self._grads_clean
-        self._grads_clean = False
+        self._take_arena_zero()
         self.attach_grads()
         self._order_deterministic_pass()
         dev = self.flat_param.device

@@ -84,6 +84,10 @@ CASES = [
     (1, 48, 32, 64, 64, False, False, 128, 1),    # concat 64 + 64 (two-output input gradient, 64-wide tiles), two N tiles
     (2, 40, 56, 32, 32, False, False, 32, 1),     # concat 32 + 32 (two-output input gradient, 32-wide tiles), ragged 16 x 16 tiles
     (1, 33, 17, 96, 0, False, False, 80, 1),      # ragged everything: 3 chunks, N = 80 in 64-wide tiles, one-pixel tile rows / columns
+    # the register-tiled weight gradient (k_wgrad_rt): image groups and long walks
+    (7, 8, 10, 64, 0, False, False, 64, 1),       # 8 x 10 maps: tiles of several whole images, the last group cut short by the batch
+    (2, 64, 80, 32, 32, False, False, 32, 1),     # concat at 1/4 resolution: several tiles per image, two ci tiles from two sources
+    (3, 32, 40, 128, 0, False, False, 128, 1),    # 4 x 4 (co, ci) tiles
 ]
 
 
@@ -127,13 +131,25 @@ def _both_kernel_forms(request):
     in the library's tuning table (colvo_tune_set, csrc/tuning.h) to reach them -- the other half exercises the one-tile kernels
     on the same shapes."""
     from coivo_amd import _lib
-    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg", "res_s2_min_tiles")
+    names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg", "res_s2_min_tiles",
+             "wgrad_rt_min_c", "wgrad_rt_over_up2", "wgrad_rt_wgs", "wgrad_rt_max_px")
     saved = {n: _lib.tune_get(n) for n in names}
+    # The register-tiled weight gradient (k_wgrad_rt, csrc/wgrad_rt.hip; bf16 stride-1 layers): form0 runs it as production does (32 or
+    # more channels everywhere, tiles of up to 640 pixels, pixel-range splits up to 256 workgroups); form1 on EVERY bf16 stride-1 case
+    # (8-, 16-, 24-, 40-channel tensors in 32-wide tiles, up-sampled sources read through its DMA addressing) with tiles of at most 48
+    # pixels and three workgroups per (co, ci) tile -- long walks over both staging buffers, ragged tiles, image groups cut short by the
+    # batch; form2 the same tensors in full-size tiles.
     if "form1" in request.node.name:
+        _lib.tune_set("wgrad_rt_min_c", 8)
+        _lib.tune_set("wgrad_rt_over_up2", 1)
+        _lib.tune_set("wgrad_rt_max_px", 48)
+        _lib.tune_set("wgrad_rt_wgs", 3)
         _lib.tune_set("dgrad_up2_min_wgs", 0)
         _lib.tune_set("quad_min_wgs", 0)
         _lib.tune_set("quad_max_chunks", 64)
     if "form2" in request.node.name:
+        _lib.tune_set("wgrad_rt_min_c", 8)
+        _lib.tune_set("wgrad_rt_over_up2", 1)
         # the register-tiled stride-1 kernel (k_conv_rt, csrc/conv_rt.hip: selected from 1024 workgroups on and where its 16 x 16
         # tiles cover the image well): every stride-1 case with direct sources and whole chunks, ragged images included
         _lib.tune_set("dgrad_up2_min_wgs", 0)

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 @pytest.mark.parametrize("src,min_mfma,min_kernels,agpr_free", [("conv.hip", 5000, 60, True), ("wgrad.hip", 1500, 30, False),
                                                                  ("bwd16.hip", 20, 1, True), ("fwd16.hip", 10, 1, True),
-                                                                 ("conv_rt.hip", 500, 4, True)])
+                                                                 ("conv_rt.hip", 500, 4, True), ("wgrad_rt.hip", 15, 1, True)])
 def test_no_rotated_mfma_result_is_read_early(tmp_path, src, min_mfma, min_kernels, agpr_free):
     import isa_check_mfma
     from coivo_amd import build

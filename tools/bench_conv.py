@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer timing of the conv kernels (forward / dgrad / wgrad) on the DepthNet + PoseNet layer shapes at B images.
-   python tools/bench_conv.py [B=16] [dtype=bf16]"""
+   python tools/bench_conv.py [B=16] [dtype=bf16] [fwdonly|wgradonly]"""
 import os
 import sys
 
@@ -44,6 +44,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.bfloat16
     fwdonly = len(sys.argv) > 3 and sys.argv[3] == "fwdonly"
+    wonly = len(sys.argv) > 3 and sys.argv[3] == "wgradonly"          # (the other two columns then read 1.0)
     dev = torch.device("cuda:0")
     tot = [0.0, 0.0, 0.0]
     gsum = [0.0, 0.0, 0.0]
@@ -64,8 +65,8 @@ def main():
         dw = torch.zeros(cout, 9, cin, device=dev)
         db = torch.zeros(cout, device=dev)
         gf = 2.0 * cout * cin * 9 * d.Ho * d.Wo * b / 1e9
-        tf = timeit(lambda: ops.conv_fwd(d, x0, x1, wf, bias, y))
-        td = 1.0 if fwdonly else timeit(lambda: ops.conv_dgrad(d, 0, dy, wb, x0, dx, False))
+        tf = 1.0 if wonly else timeit(lambda: ops.conv_fwd(d, x0, x1, wf, bias, y))
+        td = 1.0 if (fwdonly or wonly) else timeit(lambda: ops.conv_dgrad(d, 0, dy, wb, x0, dx, False))
         # CONV_BENCH_DET=1: the deterministic form (per-split slabs + the per-layer reduce launch) instead of float atomics
         scr = ops.conv_wgrad_scratch(d, dev) if os.environ.get("CONV_BENCH_DET") else None
         tw = 1.0 if fwdonly else timeit(lambda: ops.conv_wgrad(d, x0, x1, dy, dw, db, scr))
