@@ -76,13 +76,15 @@ namespace tune {
     X(wgrad_wg_hi, 1024, "... and at most this many")                                                                               \
     X(wgrad_short_walk, 32, "... half the floor while a workgroup of the full grid would walk fewer pixel tiles than this (0: off)")                                                                               \
     X(wgrad_store_clean, 1, "single-split layers STORE their sums when the caller vouches for a zero arena (colvo_conv_wgrad_clean)")    \
-    X(wgrad_rt, 1, "register-tiled weight gradient (k_wgrad_rt, csrc/wgrad_rt.hip: a wave owns 32 co x 32 ci x 9 taps, eight waves split K, "   \
-                   "LDS-DMA staging, one 36 KB slab of atomics per workgroup) for bf16 stride-1 layers")                                \
+    X(wgrad_rt, 0, "register-tiled weight gradient (k_wgrad_rt, csrc/wgrad_rt.hip: consumer waves own 32 co x 32 ci x 9 taps on 32x32x16 MFMAs "  \
+                   "and split K four ways, loader waves stage, ONE 36 KB slab of atomics per workgroup) for bf16 stride-1 layers.  OFF: level "  \
+                   "with k_wgrad3x3 alone (64 frames 1287 vs 1290 us over the stack, deep layers -10...17 %, mid layers +5...14 %), and in "   \
+                   "the step +2.6 % / +0.5 % / +0.2 % at 8 / 32 / 64 pairs even on the layers it wins alone (its 150 KB of LDS keep the "      \
+                   "input-gradient chain off its CUs): profiles/r6_wgrad_rt.md")                                                          \
     X(wgrad_rt_min_c, 32, "... whose sources and outputs have at least this many channels (a 32-wide tile of a 16-channel tensor is half empty)") \
     X(wgrad_rt_min_px, 0, "... and at least this many output pixels in the batch")                                                       \
     X(wgrad_rt_wgs, 256, "... grid: pixel-range splits up to this many workgroups (one 512-thread workgroup per CU)")                     \
-    X(wgrad_rt_max_px, 640, "... tile: at most this many pixels (K-steps of 16; two staging buffers of tile + patch must fit 160 KB of LDS)")  \
-    X(wgrad_rt_min_bufs, 3, "... and small enough for this many staging buffers (2..4; the ring keeps buffers - 1 tiles of DMA in flight)")     \
+    X(wgrad_rt_max_px, 640, "... tile: at most this many pixels (K-steps of 16; two staging buffers of tile + patch must fit 156 KB of LDS)")  \
     X(wgrad_rt_over_up2, 0, "... also for single up-sampled sources (instead of the four-class kernel k_wgrad_up2)")                     \
     X(wgrad_teams, 4, "pixel-tile teams per workgroup on the full-resolution layers (1 = off)")                                     \
     X(wgrad_team_max_slabs, 2, "... for layers with at most this many (co tile, chunk) slabs")                                      \

@@ -132,14 +132,15 @@ def _both_kernel_forms(request):
     on the same shapes."""
     from coivo_amd import _lib
     names = ("dgrad_up2_min_wgs", "quad_min_wgs", "quad_max_chunks", "rt_min_wgs", "rt_bn32_min_wgs", "rt_min_fill_pct", "rt_min_chunks", "rt_tiles_per_wg", "res_s2_min_tiles",
-             "wgrad_rt_min_c", "wgrad_rt_over_up2", "wgrad_rt_wgs", "wgrad_rt_max_px")
+             "wgrad_rt", "wgrad_rt_min_c", "wgrad_rt_over_up2", "wgrad_rt_wgs", "wgrad_rt_max_px")
     saved = {n: _lib.tune_get(n) for n in names}
-    # The register-tiled weight gradient (k_wgrad_rt, csrc/wgrad_rt.hip; bf16 stride-1 layers): form0 runs it as production does (32 or
-    # more channels everywhere, tiles of up to 640 pixels, pixel-range splits up to 256 workgroups); form1 on EVERY bf16 stride-1 case
-    # (8-, 16-, 24-, 40-channel tensors in 32-wide tiles, up-sampled sources read through its DMA addressing) with tiles of at most 48
-    # pixels and three workgroups per (co, ci) tile -- long walks over both staging buffers, ragged tiles, image groups cut short by the
-    # batch; form2 the same tensors in full-size tiles.
+    # The register-tiled weight gradient (k_wgrad_rt, csrc/wgrad_rt.hip; bf16 stride-1 layers; measured level alone and a loss in the step,
+    # so production leaves it off -- profiles/r6_wgrad_rt.md -- and form0 is the production dispatch): form1 runs it on EVERY bf16 stride-1
+    # case (8-, 16-, 24-, 40-channel tensors in 32-wide tiles, up-sampled sources read through its staging addresses) with tiles of
+    # at most 48 pixels and three workgroups per (co, ci) tile -- long walks over both staging buffers, ragged tiles, image groups cut
+    # short by the batch; form2 the same tensors in full-size tiles on 256-workgroup grids.
     if "form1" in request.node.name:
+        _lib.tune_set("wgrad_rt", 1)
         _lib.tune_set("wgrad_rt_min_c", 8)
         _lib.tune_set("wgrad_rt_over_up2", 1)
         _lib.tune_set("wgrad_rt_max_px", 48)
@@ -148,6 +149,7 @@ def _both_kernel_forms(request):
         _lib.tune_set("quad_min_wgs", 0)
         _lib.tune_set("quad_max_chunks", 64)
     if "form2" in request.node.name:
+        _lib.tune_set("wgrad_rt", 1)
         _lib.tune_set("wgrad_rt_min_c", 8)
         _lib.tune_set("wgrad_rt_over_up2", 1)
         # the register-tiled stride-1 kernel (k_conv_rt, csrc/conv_rt.hip: selected from 1024 workgroups on and where its 16 x 16
