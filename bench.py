@@ -29,10 +29,9 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1 or "--rccl-single" in sys.argv:
     # initialisation, so it has to be in the environment before torch is imported.  A value the user exported is left alone
     # (coivo_amd.streams warns about 3..7); the effective value is reported in the JSON line (`hw_queues`).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # a captured step (configs[4]) holds RCCL collectives: fresh events for every eager collective instead of recycled ones (kept from
-    # round 5's first reading of a watchdog failure; what actually guards the capture is the quiet period in GraphedTrainStep.capture(),
-    # coivo_amd/graph.py _check_process_group_environment); read when the process group is created
-    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+    # (a captured step, configs[4], holds RCCL collectives: what makes that safe is the native RCCL path -- no ProcessGroupNCCL work
+    #  objects, torch's RCCL stream never in a capture -- coivo_amd/graph.py _process_group_path; round 5's
+    #  TORCH_NCCL_CUDA_EVENT_CACHE=0 default belonged to a hypothesis that was retired and is gone)
 
 import torch
 
@@ -77,6 +76,8 @@ def parse():
     ap.add_argument("--per-rank-loss", action="store_true",
                     help="developer A/B: data parallel with the mean of the per-rank masked means (rounds 1-4) instead of the spec's "
                          "ONE masked mean over the whole batch (one all-reduce of two floats behind the loss kernel, coivo_amd/ddp.py)")
+    ap.add_argument("--blocking-loss-exchange", action="store_true",
+                    help="developer A/B: wait for the two-float all-reduce of the loss normaliser between forward and backward (round 5)")
     ap.add_argument("--grad-transport", choices=["f32", "bf16"], default=None, help="override the configuration's transport dtype")
     ap.add_argument("--spec-calls", action="store_true",
                     help="time the step written as the spec's verbatim call sequence (INTEGRATION.md section 1, first snippet: "
@@ -433,7 +434,11 @@ def main():
     if world > 1 or args.rccl_single:
         ddp = GradBuckets([dn, pn], bucket_bytes=args.bucket_mb << 20,
                           transport_dtype=torch.bfloat16 if args.grad_transport == "bf16" else None,
-                          exact_batch_loss=not args.per_rank_loss, native_collectives=host_pg is not None)
+                          exact_batch_loss=not args.per_rank_loss, native_collectives=host_pg is not None,
+                          # the two-float loss exchange off the critical path (round 6; the plain objective is ONE photometric_loss
+                          # call and the only source of gradients: what the option asks of its caller)
+                          defer_loss_normalisation=not (args.per_rank_loss or args.full_loss or args.blocking_loss_exchange),
+                          optimizer=opt)
         opt.grad_scale = ddp.grad_scale
     batch = synth.make_batch(B, H, W, seed=1234 + rank, device=dev)
     frames = torch.cat([batch["tgt"], batch["ref"]], dim=0)      # one resident buffer: target frames, then reference
@@ -447,6 +452,8 @@ def main():
         nonlocal graphed, graph_error
         from coivo_amd.graph import GraphedTrainStep
         try:
+            # (with the ProcessGroup.allreduce fallback -- COLVO_DDP_TORCH_COLLECTIVES=1 or a torch without _comm_ptr() -- the capture is
+            #  refused by GraphedTrainStep and the run falls back to eager launches, saying so in the JSON line)
             graphed = GraphedTrainStep(dn, pn, opt, B, H, W, ddp=ddp, capture_policy=args.graph_policy,
                                        capture_group=args.graph_group, full_loss=args.full_loss)
             graphed.frames.copy_(frames)
@@ -760,7 +767,12 @@ def main():
                           "grad_transport": args.grad_transport if (world > 1 or args.rccl_single) else None,
                           "collectives": (None if ddp is None else "ncclAllReduce on the group's communicator, called natively"
                                           if ddp.native_collectives else "ProcessGroup.allreduce"),
-                          "batch_loss": (None if ddp is None else "one masked mean over the global batch (valid-pixel count all-reduced)"
+                          # which RCCL, which communicator, and what RCCL itself reports about it (ranks, this rank) -- or why the
+                          # native path asked for is not the one in use
+                          "native_rccl": (None if ddp is None else ddp._native.describe() if ddp.native_collectives
+                                          else {"fallback": ddp.native_fallback}),
+                          "batch_loss": (None if ddp is None else "one masked mean over the global batch (valid-pixel count all-reduced"
+                                         + ("; the exchange overlaps the backward pass, the scale goes into the optimizer)" if ddp._defer else ")")
                                          if ddp.exact_batch_loss else "mean of the per-rank masked means"),
                           "call_sequence": "spec (depth_net(cat), slices, photometric_loss)" if args.spec_calls else
                                            "fast path (forward_pair_split + gradient handover)"},

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("COLVO_LIB_PATH") or os.path.join(_HERE, "lib", "libcolvo.so")
 
 F32, BF16 = 0, 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -62,6 +62,7 @@ SIGNATURES = {
     "colvo_warp_loss_fused_bwd": (_i, [_vp] * 5 + [_i, _i, _i] + [_vp] * 5),
     "colvo_warp_loss_fused_bwd_params": (_i, [_vp] * 4 + [_i] + [_vp] * 4),
     "colvo_warp_loss_rescale": (_i, [_vp, _i, _vp]),
+    "colvo_warp_loss_rescale_to": (_i, [_vp, _i, _vp, _vp]),
     "colvo_inverse_warp": (_i, [_vp] * 4 + [_i] * 4 + [_vp] * 3),
     "colvo_geo_loss_workspace_floats": (_sz, [_i, _i, _i]),
     "colvo_geo_loss_fwd": (_i, [_vp] * 4 + [_i, _i, _i] + [_vp] * 3),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "colvo_adam_step_multi": (_i, [_vp, _i, _f, _f, _f, _f, _f, _i, _vp]),
     "colvo_zero_multi": (_i, [_vp, _vp, _i, _vp]),
     "colvo_adam_pack_step": (_i, [_i, _vp, _i, _i, _f, _f, _f, _f, _f, _vp, _i, _vp]),
+    "colvo_adam_pack_step_scaled": (_i, [_i, _vp, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _i, _vp]),
     "colvo_full_objective_workspace_floats": (_sz, [_i, _i, _i, _i]),
     "colvo_full_objective_fwd": (_i, [_vp] * 8 + [_i] * 4 + [_f] * 3 + [_vp] * 3),
     "colvo_full_objective_bwd": (_i, [_vp] * 3 + [_i] * 4 + [_f, _f] + [_vp] * 6),
@@ -128,6 +130,9 @@ SIGNATURES = {
     "colvo_capture_reset": (_i, [_vp]),
     "colvo_graph_stats": (_i, [_vp, C.POINTER(C.c_longlong), _i]),
     "colvo_graph_stats_reset": (_i, []),
+    "colvo_form_counts": (_i, [C.POINTER(C.c_longlong), _i]),
+    "colvo_form_counts_reset": (None, []),
+    "colvo_form_name": (C.c_char_p, [_i]),
     "colvo_tune_set": (_i, [C.c_char_p, C.c_double]),
     "colvo_tune_get": (_i, [C.c_char_p, C.POINTER(C.c_double)]),
 }
@@ -189,6 +194,18 @@ def tune_get(name: str) -> float:
     v = C.c_double()
     check(load().colvo_tune_get(name.encode(), C.byref(v)), "colvo_tune_get")
     return v.value
+
+
+def form_counts(reset: bool = False) -> dict:
+    """{form name: launches since the last reset} of the kernel forms the library's dispatchers choose by grid size (include/colvo.h
+    colvo_form_counts); reset=True clears the counters after reading."""
+    lib = load()
+    buf = (C.c_longlong * 32)()
+    n = lib.colvo_form_counts(buf, 32)
+    out = {lib.colvo_form_name(i).decode(): int(buf[i]) for i in range(n)}
+    if reset:
+        lib.colvo_form_counts_reset()
+    return out
 
 
 def dev_env(name: str, default=None):

@@ -53,6 +53,12 @@ inline void launch(void (*kernel)(P...), dim3 grid, dim3 block, unsigned lds, hi
     }
 }
 
+// Which kernel FORM a dispatcher chose, counted per process (colvo_form_counts: the tests of the grid-size-selected forms read it --
+// a parity test at a small shape must be able to say that the large-grid kernel is what actually ran).
+enum { FORM_CONV_RT = 0, FORM_WGRAD_FULL_GRID, FORM_WGRAD_HALVED_GRID, FORM_WGRAD_UP2, FORM_WGRAD_RT, FORM_WGRAD_STORE_CLEAN, FORM_CONV_RES_S2,
+       FORM_CONV_Q, FORM_COUNT };
+void form_hit(int id);
+
 // csrc/bwd16.hip: the MFMA form of colvo_conv_dgrad_planes (bf16, stride 2, 16 output channels, two input channels, even extents)
 int launch_dgrad_planes_s2_mfma(const void* g, const float* w, int Cin, int c_begin, int B, int Hi, int Wi, int Ho, int Wo, float* dst,
                                 int accumulate, hipStream_t stream);

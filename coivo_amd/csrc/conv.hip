@@ -1488,6 +1488,7 @@ int launch_conv_res(const ConvK& k, int B, hipStream_t s) {
     int gx = 256 * per_cu;
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, (k.N + BN - 1) / BN, 1);
+    if (S2) form_hit(FORM_CONV_RES_S2);
     colvo::launch((k_conv3x3_res<T, BN, NG, S2>), grid, dim3(NT), lds, s, k, ntiles, mdiv_magic(k.tiles_x * k.tiles_y),
                        mdiv_magic(k.tiles_x));
     COLVO_CHECK_LAUNCH("k_conv3x3_res");
@@ -1671,6 +1672,7 @@ int try_launch_conv_q(const ConvK& k0, int B, hipStream_t s) {
         configured[bn == 32] = true;
     }
     const dim3 grid((unsigned)(tiles * k.ntn));
+    form_hit(FORM_CONV_Q);
     if (bn == 32) colvo::launch((k_conv_q<T, 32>), grid, dim3(NT), lds, s, k);
     else colvo::launch((k_conv_q<T, 16>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_conv_q");

@@ -373,6 +373,7 @@ int try_launch_conv_rt(const ConvK& k0, int B, int dtype, hipStream_t s) {
     k.xcd = (int)TUNE(xcd_remap);
     const long long nwg = (long long)k.tiles_x * k.tiles_y * B * k.ntn;
     if (nwg < (bn64 ? TUNE(rt_min_wgs) : TUNE(rt_bn32_min_wgs)) || nwg >= (1ll << 30)) return -1;
+    form_hit(FORM_CONV_RT);
     if (dtype == COLVO_F32) return bn64 ? launch_conv_rt<float, 4>(k, nwg, s) : launch_conv_rt<float, 2>(k, nwg, s);
     return bn64 ? launch_conv_rt<bf16_t, 4>(k, nwg, s) : launch_conv_rt<bf16_t, 2>(k, nwg, s);
 }

@@ -827,9 +827,12 @@ __global__ __launch_bounds__(NT) void k_adam_multi(AdamArenas as, float lr, floa
 // a plain range of the arena (biases, heads, padding) that only takes the update.  Same arithmetic as k_adam, element for element.
 template <int ES>
 __global__ __launch_bounds__(NT) void k_adam_pack(const ColvoAdamPackEntry* __restrict__ tab, int nentries, float lr, float b1,
-                                                  float b2, float eps, float gscale, const int32_t* __restrict__ step_count,
-                                                  int t_host) {
+                                                  float b2, float eps, float gscale_host, const float* __restrict__ gscale_dev,
+                                                  const int32_t* __restrict__ step_count, int t_host) {
     __shared__ float tile[PK_CO][PK_C + 1];
+    // gscale_dev: a second factor that is only known on the device (data parallel: world / max(3 n_valid of the WHOLE batch, 1), the
+    // normaliser of raw loss gradients whose all-reduce overlapped the backward pass -- colvo_warp_loss_rescale_to)
+    const float gscale = gscale_dev ? gscale_host * *gscale_dev : gscale_host;
     const AdamCoef c = adam_coef(lr, b1, b2, step_count, t_host);
     int l = 0;
     for (int i = 1; i < nentries; ++i)
@@ -1397,11 +1400,17 @@ extern "C" int colvo_adam_step_multi(const ColvoAdamArena* arenas, int count, fl
 
 extern "C" int colvo_adam_pack_step(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
                                     float eps, float grad_scale, int32_t* step_count, int t, colvo_stream_t stream) {
+    return colvo_adam_pack_step_scaled(dtype, table, nentries, nblocks, lr, beta1, beta2, eps, grad_scale, nullptr, step_count, t, stream);
+}
+
+extern "C" int colvo_adam_pack_step_scaled(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
+                                           float eps, float grad_scale, const float* grad_scale_dev, int32_t* step_count, int t,
+                                           colvo_stream_t stream) {
     COLVO_CHECK_ARG(table && nentries >= 1 && nblocks >= 1 && (step_count || t >= 1), "colvo_adam_pack_step: bad arguments");
     COLVO_CHECK_ARG(dtype == COLVO_F32 || dtype == COLVO_BF16, "colvo_adam_pack_step: bad dtype");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_ES(dtype, colvo::launch((k_adam_pack<ES>), dim3(nblocks), dim3(NT), 0, s, (const ColvoAdamPackEntry*)table,
-                                          nentries, lr, beta1, beta2, eps, grad_scale, (const int32_t*)step_count, t));
+                                          nentries, lr, beta1, beta2, eps, grad_scale, grad_scale_dev, (const int32_t*)step_count, t));
     COLVO_CHECK_LAUNCH("k_adam_pack");
     if (step_count) {
         colvo::launch(k_inc_step, dim3(1), dim3(1), 0, s, step_count);

@@ -1800,16 +1800,25 @@ extern "C" int colvo_warp_loss_fused_bwd_params(const float* loss_state, const f
 // Data parallel: loss_state[2] (valid pixels) and loss_state[3] (masked sum) have been added up over `world` ranks -> the loss of
 // the WHOLE batch and the normaliser every rank's raw gradients take so that (1 / world) x the all-reduced gradient is the gradient
 // of that loss: world / max(3 n_global, 1).  The same arithmetic as the finalize kernels (world = 1: bit for bit what they wrote).
-__global__ void k_warp_loss_rescale(float* __restrict__ loss_state, float world) {
+__global__ void k_warp_loss_rescale(float* __restrict__ loss_state, float world, float* __restrict__ scale_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const float denom = fmaxf(3.0f * loss_state[2], 1.0f);
     loss_state[0] = loss_state[3] / denom;
-    loss_state[1] = world == 1.0f ? 1.0f / denom : world / denom;
+    const float sc = world == 1.0f ? 1.0f / denom : world / denom;
+    loss_state[1] = sc;
+    if (scale_out) *scale_out = sc;
 }
 
 extern "C" int colvo_warp_loss_rescale(float* loss_state, int world, colvo_stream_t stream) {
     COLVO_CHECK_ARG(loss_state && world >= 1, "colvo_warp_loss_rescale: null state or world < 1");
-    colvo::launch(k_warp_loss_rescale, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_state, (float)world);
+    colvo::launch(k_warp_loss_rescale, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_state, (float)world, (float*)nullptr);
+    COLVO_CHECK_LAUNCH("k_warp_loss_rescale");
+    return 0;
+}
+
+extern "C" int colvo_warp_loss_rescale_to(float* loss_state, int world, float* scale_out, colvo_stream_t stream) {
+    COLVO_CHECK_ARG(loss_state && scale_out && world >= 1, "colvo_warp_loss_rescale_to: null pointer or world < 1");
+    colvo::launch(k_warp_loss_rescale, dim3(1), dim3(64), 0, (hipStream_t)stream, loss_state, (float)world, scale_out);
     COLVO_CHECK_LAUNCH("k_warp_loss_rescale");
     return 0;
 }

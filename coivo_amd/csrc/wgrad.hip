@@ -616,11 +616,12 @@ inline int wgrad_finish(const WgradK& k, int nsplit, hipStream_t s) {
 // with one workgroup per CU (what round 2-3 tuned for), but in the step three kernels share the CUs and the sum of workgroup lives is
 // what counts: 128 instead of 256 workgroups at 16 frames measured -2.8 % per step (1.3097 -> 1.2726 ms), 96 -> +1 %, 64 -> +9 %;
 // at 64 / 128 frames, where the walks are 4-8 times longer, halving every layer cost 0.4-0.5 %.
+static thread_local bool g_grid_halved = false;     // what the last wgrad_grid_floor() decided (colvo_form_counts)
 static inline int wgrad_grid_floor(int base, int ntiles, int per_split) {
     const int short_walk = (int)TUNE(wgrad_short_walk);
     const int nsplit_at_base = std::max(1, (base + per_split - 1) / per_split);
-    if (short_walk > 0 && ntiles / nsplit_at_base < short_walk) return std::max(1, base / 2);
-    return base;
+    g_grid_halved = short_walk > 0 && ntiles / nsplit_at_base < short_walk;
+    return g_grid_halved ? std::max(1, base / 2) : base;
 }
 
 template <typename T, int MT, int NG, bool TAIL, int KS>
@@ -656,6 +657,8 @@ int launch_wgrad_teams(WgradK k, hipStream_t s) {
 #ifdef COLVO_WTRACE
     wtrace_begin(k, grid.x, s);
 #endif
+    form_hit(g_grid_halved ? FORM_WGRAD_HALVED_GRID : FORM_WGRAD_FULL_GRID);
+    if (k.det == 2) form_hit(FORM_WGRAD_STORE_CLEAN);
     colvo::launch((k_wgrad3x3<T, MT, NG, TAIL, KS>), grid, dim3(NT * KS), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3 (teams)");
 #ifdef COLVO_WTRACE
@@ -717,6 +720,8 @@ int launch_wgrad_tail(WgradK k, hipStream_t s) {
 #ifdef COLVO_WTRACE
     wtrace_begin(k, grid.x, s);
 #endif
+    form_hit(g_grid_halved ? FORM_WGRAD_HALVED_GRID : FORM_WGRAD_FULL_GRID);
+    if (k.det == 2) form_hit(FORM_WGRAD_STORE_CLEAN);
     colvo::launch((k_wgrad3x3<T, MT, NG, TAIL>), grid, dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad3x3");
 #ifdef COLVO_WTRACE
@@ -1040,6 +1045,9 @@ int launch_wgrad_up2(WgradK k, hipStream_t s) {
     nsplit = (k.ntiles + k.tiles_per_split - 1) / k.tiles_per_split;
     k.nsplit = nsplit; k.cot = cot; k.xcd = (int)TUNE(xcd_remap);
     { int err; if (wgrad_prepare(k, nsplit, &err)) return err; }
+    form_hit(FORM_WGRAD_UP2);
+    form_hit(g_grid_halved ? FORM_WGRAD_HALVED_GRID : FORM_WGRAD_FULL_GRID);
+    if (k.det == 2) form_hit(FORM_WGRAD_STORE_CLEAN);
     colvo::launch((k_wgrad_up2<T, MT>), dim3((unsigned)(nsplit * cot * chunks)), dim3(NT), lds, s, k);
     COLVO_CHECK_LAUNCH("k_wgrad_up2");
     return wgrad_finish(k, nsplit, s);
@@ -1212,6 +1220,7 @@ static int wgrad_impl(const ColvoConvDesc* d, const void* x0, const void* x1, co
         WgradRtPlan rp;
         if ((!up2_form || TUNE(wgrad_rt_over_up2)) && wgrad_rt_plan(d, rp)) {
             { int err; if (wgrad_prepare(k, rp.nsplit, &err)) return err; }
+            form_hit(FORM_WGRAD_RT);
             if (int e = wgrad_rt_launch(rp, d, x0, d->C1 ? x1 : nullptr, dy, dw, db, k.slabs, k.db_slabs, k.det, (hipStream_t)stream)) return e;
             return wgrad_finish(k, rp.nsplit, (hipStream_t)stream);
         }

@@ -58,7 +58,9 @@ class _NativeRccl:
       * torch must not run collectives of its own on this communicator while the object is in use: they would go to torch's internal
         stream (concurrency with ours), and that stream would become a FIFTH active hardware queue -- the step then runs 2.7 x slower
         (streams.py; measured with this very class before it stopped asking torch for a warm-up collective: 3.5 ms instead of 1.3).
-        bench.py therefore synchronises its ranks over a gloo side group; barrier() below is the device-side alternative."""
+        bench.py therefore synchronises its ranks over a gloo side group; barrier() below is the device-side alternative;
+      * what is given up: torch's watchdog never sees these collectives, so a hung all-reduce (a dead peer) is neither timed out nor
+        aborted by it -- the job hangs until its launcher's own timeout.  The ProcessGroup.allreduce path keeps that coverage."""
 
     _F32, _BF16, _SUM = 7, 9, 0          # ncclFloat32, ncclBfloat16, ncclSum (nccl.h / rccl.h)
 
@@ -79,14 +81,31 @@ class _NativeRccl:
         if not comm:
             raise RuntimeError("ProcessGroupNCCL._comm_ptr() returned NULL")
         self.comm = comm
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        lib = C.CDLL(path if os.path.exists(path) else "librccl.so")         # the copy torch itself has loaded
+        # The RCCL torch itself has mapped -- not "a" librccl.so: a second copy of the library (another version behind the bare
+        # soname) would be handed torch's ncclComm_t, which is undefined behaviour the self-check below cannot be relied on to catch
+        # (ADVICE r5).  /proc/self/maps names the file; RTLD_NOLOAD opens it only if it is mapped already.  Not found: no native path.
+        self.lib_path = self._loaded_rccl()
+        if self.lib_path is None:
+            raise RuntimeError("no librccl mapped into this process (is torch's nccl backend RCCL?)")
+        lib = C.CDLL(self.lib_path, mode=getattr(os, "RTLD_NOLOAD", 4) | getattr(os, "RTLD_NOW", 2))
         self._fn = lib.ncclAllReduce
         self._fn.restype = C.c_int
         self._fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         self._err = lib.ncclGetErrorString
         self._err.restype = C.c_char_p
         self._err.argtypes = [C.c_int]
+        # What RCCL itself says about the communicator torch handed over, read through the SAME handle the collectives will use: it
+        # must be this group's (a first multi-GPU record then shows that the native path saw N ranks).
+        n, r = C.c_int(-1), C.c_int(-1)
+        for fn, out in ((lib.ncclCommCount, n), (lib.ncclCommUserRank, r)):
+            fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_int)]
+            rc = fn(self.comm, C.byref(out))
+            if rc != 0:
+                raise RuntimeError(f"{fn.__name__} failed: {self._err(rc).decode('utf-8', 'replace')} ({rc})")
+        self.comm_count, self.comm_rank = int(n.value), int(r.value)
+        if (self.comm_count, self.comm_rank) != (dist.get_world_size(group), dist.get_rank(group)):
+            raise RuntimeError(f"the communicator says rank {self.comm_rank} of {self.comm_count}, the process group rank "
+                               f"{dist.get_rank(group)} of {dist.get_world_size(group)}")
         self.world = dist.get_world_size(group)
         self.stream = torch.cuda.Stream(device=dev)           # the collectives' own queue (the one streams.py budgets for RCCL)
         self._ev = torch.cuda.Event()                         # "everything the collective reads has been enqueued" (re-recorded per call)
@@ -99,6 +118,26 @@ class _NativeRccl:
         torch.cuda.synchronize()
         if not torch.equal(self._probe.cpu(), torch.full((8,), 1.5 * self.world)):
             raise RuntimeError(f"native ncclAllReduce self-check failed: {self._probe.tolist()} (world {self.world})")
+        if self.comm_rank == 0:
+            import logging
+            logging.getLogger("coivo_amd.ddp").info("native RCCL path: comm %#x, %d ranks (ncclCommCount), this is rank %d, %s", self.comm,
+                                                    self.comm_count, self.comm_rank, self.lib_path)
+
+    @staticmethod
+    def _loaded_rccl() -> Optional[str]:
+        try:
+            with open("/proc/self/maps") as f:
+                for line in f:
+                    path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                    if "librccl" in os.path.basename(path) and os.path.exists(path):
+                        return path
+        except OSError:
+            pass
+        return None
+
+    def describe(self) -> dict:
+        """What bench.py puts into its JSON line (N > 1): which library, which communicator, what RCCL says about it."""
+        return {"librccl": self.lib_path, "comm": hex(self.comm), "ncclCommCount": self.comm_count, "ncclCommUserRank": self.comm_rank}
 
     def _call(self, t: torch.Tensor) -> None:
         code = self._F32 if t.dtype == torch.float32 else self._BF16 if t.dtype == torch.bfloat16 else None
@@ -148,13 +187,21 @@ class GradBuckets:
 
     def __init__(self, modules: Sequence, process_group=None, bucket_bytes: int = 16 << 20,
                  transport_dtype: Optional[torch.dtype] = None, tail_bytes: int = 1 << 20, exact_batch_loss: bool = True,
-                 native_collectives: bool = False):
+                 native_collectives: bool = False, defer_loss_normalisation: bool = False, optimizer=None):
         """exact_batch_loss (default): the photometric loss is normalised by the valid-pixel count of the WHOLE batch, as the spec
         does (oracle/SPEC.md section 5), not per rank: functional.photometric_loss all-reduces two floats (valid pixels, masked sum)
         right after its forward kernel and every rank scales its raw gradients by world / max(3 n_global, 1) -- data parallel then
         IS the spec's big-batch step (tests/ddp_gpu_worker.py compares with the oracle's plain batch loss).  False: the mean of the
         per-rank masked means (rounds 1-4), which differs when the ranks' valid-pixel counts do; saves one tiny collective between
         forward and backward.  The widened objective (dcdp_full_loss) keeps per-rank normalisers either way.
+        defer_loss_normalisation=True (needs optimizer=the step's FusedAdam; round 6): the two-float exchange is only STARTED behind the
+        loss kernel and waited for in finish().  Between forward and backward no rank waits for another: the backward pass runs on the
+        UNNORMALISED loss gradients (every parameter gradient is linear in the normaliser), the buckets sum those, and finish() hands
+        the optimizer world / max(3 n_global, 1) as a device-side factor of its gradient scale (FusedAdam.grad_scale_dev).  The loss
+        tensor reads the whole batch's value after finish().  An opt-in because it binds the caller: the photometric loss -- ONE call
+        per step, taken through the hand-over path (nn.dcdp_forward, forward_pair_split, the spec's own call sequence) -- must be
+        the only source of parameter gradients in the step (anything else would be scaled along), and finish() / optimizer.step()
+        must follow every backward pass.  Calls that cannot defer (a loss without the hand-over mailboxes) exchange at once, as before.
         native_collectives=True: RCCL called through its own C ABI on the group's communicator (_NativeRccl: half the host cost per
         collective) instead of through ProcessGroup.allreduce -- for an nccl group with GPU arenas, unless COLVO_DDP_TORCH_COLLECTIVES=1
         is exported.  An opt-in because it binds the CALLER: no torch collective may run on this group from before the attach to the
@@ -165,6 +212,15 @@ class GradBuckets:
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.exact_batch_loss = bool(exact_batch_loss)
+        self._opt = optimizer
+        self._defer = bool(defer_loss_normalisation and exact_batch_loss and optimizer is not None
+                           and os.environ.get("COLVO_DDP_BLOCKING_LOSS", "0") in ("", "0"))
+        if defer_loss_normalisation and optimizer is None:
+            raise ValueError("GradBuckets(defer_loss_normalisation=True) needs optimizer=<the step's FusedAdam>")
+        if self._defer and not (hasattr(optimizer, "writes_operand_copies") and optimizer.writes_operand_copies()):
+            raise ValueError("GradBuckets(defer_loss_normalisation=True): the optimizer's one-pass update (colvo_adam_pack_step_scaled) "
+                             "is what takes the device-side scale; it is not available for this set of networks")
+        self._deferred = None                   # (state, work or None) of the exchange started in this step's forward pass
         self._queue_claim = None
         if any(getattr(m, "flat_grad", None) is not None and m.flat_grad.is_cuda for m in modules):
             # The communicator brings a stream of its own: main + weight-gradient side stream + communicator is as many
@@ -196,6 +252,7 @@ class GradBuckets:
             self.states.append(st)
             m.grad_ready_hook = self._make_hook(st)
         self.attached = True
+        self._eager_works = []
         self._install_reducer(True)
         # The collectives go to the backend object directly (ProcessGroup.allreduce) instead of through torch.distributed.all_reduce:
         # the Python wrapper's argument checks, rank lookups and logging hooks are ~10 us per call on the host, and an 8-pair step
@@ -209,6 +266,7 @@ class GradBuckets:
         # COLVO_DDP_TORCH_COLLECTIVES=1 (or native_collectives=False) keeps the ProcessGroup calls; a torch build without _comm_ptr()
         # falls back with a warning.
         self._native = None
+        self.native_fallback = None             # why the native path was asked for and is not in use (bench.py reports it)
         if (native_collectives and os.environ.get("COLVO_DDP_TORCH_COLLECTIVES", "0") in ("", "0")
                 and dist.get_backend(process_group) == "nccl"
                 and any(getattr(m, "flat_grad", None) is not None and m.flat_grad.is_cuda for m in modules)):
@@ -216,6 +274,7 @@ class GradBuckets:
                 self._native = _NativeRccl(process_group)
             except Exception as e:          # noqa: BLE001 -- the torch path is complete on its own
                 import warnings
+                self.native_fallback = f"{type(e).__name__}: {e}"
                 warnings.warn(f"GradBuckets: native RCCL path unavailable ({type(e).__name__}: {e}); using ProcessGroup.allreduce",
                               RuntimeWarning, stacklevel=2)
 
@@ -235,7 +294,24 @@ class GradBuckets:
 
     def _all_reduce(self, t: torch.Tensor):
         pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
-        return pg.allreduce([t], self._sum)
+        w = pg.allreduce([t], self._sum)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._eager_works.append(w)         # (see drain_eager_collectives; captured collectives never reach the watchdog's list)
+            if len(self._eager_works) > 64:
+                self._eager_works = [x for x in self._eager_works if not x.is_completed()]
+        return w
+
+    def drain_eager_collectives(self) -> None:
+        """ProcessGroup.allreduce path: wait for every eager collective this object issued and check that each reports completion
+        (graph.GraphedTrainStep's opt-in guard in front of a capture).  The native path has nothing to drain."""
+        works, self._eager_works = self._eager_works, []
+        for w in works:
+            w.wait()
+        if works and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for w in works:
+            if not w.is_completed():
+                raise RuntimeError("GradBuckets: an eager collective does not report completion after a device synchronisation")
 
     # ---- the spec's batch normalisation under data parallelism ------------------------------------ #
     def _install_reducer(self, on: bool) -> None:
@@ -245,9 +321,32 @@ class GradBuckets:
         elif functional._batch_reducer == self._reduce_loss_state:
             functional.set_batch_reducer(None)
 
-    def _reduce_loss_state(self, state: torch.Tensor) -> None:
-        """state = {loss, 1/max(3n,1), n_valid, masked sum} of this rank's forward (device): -> the whole batch's."""
+    def _reduce_loss_state(self, state: torch.Tensor, can_defer: bool = False):
+        """state = {loss, 1/max(3n,1), n_valid, masked sum} of this rank's forward (device): -> the whole batch's (functional.py)."""
         from . import _lib
+        if can_defer and self._defer:
+            # Start the exchange and go on: the sum of the two floats travels beside the backward pass (RCCL's stream / the process
+            # group's own), finish() waits for it.  The gradients' consumers get a scale of ONE in place of state[1].
+            if self._deferred is not None:
+                raise RuntimeError("GradBuckets(defer_loss_normalisation=True): a second photometric_loss call in one step (the first "
+                                   "one's normaliser is still pending); use one loss call per step or leave the option off")
+            dev = state.device
+            if self._one is None or self._one.device != dev:
+                self._one = torch.ones(1, device=dev)
+                self._norm = torch.ones(1, device=dev)
+            work = None
+            if self._native is not None:
+                self._native.all_reduce(state[2:4])
+                if not torch.cuda.is_current_stream_capturing():
+                    state.record_stream(self._native.stream)
+            else:
+                # a tensor of its own over the same two floats -- NOT a view of `state`: a process group that completes on a thread of
+                # its own (gloo) bumps the version counter of what it reduced some time later, and autograd refuses the loss (a view of
+                # `state`) if "another view of its base" changed in place meanwhile
+                xch = torch.empty(0, device=dev, dtype=state.dtype).set_(state.untyped_storage(), state.storage_offset() + 2, (2,))
+                work = self._all_reduce(xch)
+            self._deferred = (state, work)
+            return self._one
         # (also with one rank: `bench.py --rccl-single` then prices this collective like the bucket ones, and the state comes back
         # bit for bit -- a one-rank sum is the identity and the rescale repeats the forward's own arithmetic)
         if self._native is not None:
@@ -255,6 +354,10 @@ class GradBuckets:
         else:
             self._all_reduce(state[2:4]).wait()                                       # (the caller's stream waits for it)
         _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(state), self.world, _lib.stream_ptr()), "colvo_warp_loss_rescale")
+        return None
+
+    _one = None
+    _norm = None
 
     def barrier(self) -> None:
         """All ranks here, this rank's device idle -- without a torch collective on the group when the native path is on."""
@@ -340,6 +443,17 @@ class GradBuckets:
                 st.next += 1
         if self._native is not None:
             self._native.join()
+        if self._deferred is not None:
+            # the loss normaliser whose exchange was started behind the loss kernel: wait, turn the sums into the global loss and
+            # scale, and post the scale to the optimizer (it multiplies it into grad_scale inside the update kernel, once)
+            from . import _lib
+            state, work = self._deferred
+            self._deferred = None
+            if work is not None:
+                work.wait()
+            _lib.check(_lib.load().colvo_warp_loss_rescale_to(_lib.ptr(state), self.world, _lib.ptr(self._norm), _lib.stream_ptr()),
+                       "colvo_warp_loss_rescale_to")
+            self._opt.grad_scale_dev = self._norm
         for work, sl, buf in self._pending:
             if work is not None:
                 work.wait()

@@ -44,10 +44,14 @@ def _timed(kind, call):
     return r
 
 
-# Data parallel (ddp.GradBuckets(exact_batch_loss=True)): called with the loss state {loss, 1/max(3n,1), n_valid, masked sum} right
-# after the forward kernel; it adds the last two up over the ranks and rescales (include/colvo.h colvo_warp_loss_rescale), so that
-# loss AND gradients are those of the spec's ONE masked mean over the whole batch (oracle/SPEC.md section 5) instead of the mean
-# of per-rank means.  None: single process.
+# Data parallel (ddp.GradBuckets(exact_batch_loss=True)): called as reducer(state, can_defer) with the loss state {loss, 1/max(3n,1),
+# n_valid, masked sum} right after the forward kernel; it adds the last two up over the ranks and rescales (include/colvo.h
+# colvo_warp_loss_rescale), so that loss AND gradients are those of the spec's ONE masked mean over the whole batch (oracle/SPEC.md
+# section 5) instead of the mean of per-rank means.  Returns None when the state holds the global scale on return (the exchange was
+# waited for), or -- only if can_defer: every gradient of this call leaves through the hand-over mailboxes -- a 1-element device
+# tensor to hand the gradients' consumers IN PLACE of state[1]: the reducer has then only STARTED the exchange and applies the
+# global scale itself, later (ddp.GradBuckets(defer_loss_normalisation=True): a scale of one now, the real one in the optimizer).
+# None: single process.
 _batch_reducer = None
 
 
@@ -143,17 +147,21 @@ class _WarpLoss(torch.autograd.Function):
                 _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
                 B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.ptr(d_raw), _lib.ptr(gpart), _lib.ptr(gunit),
                 _lib.stream_ptr())), "colvo_warp_loss_fused")
+            ctx.scale_b = None
             if _batch_reducer is not None:
-                _batch_reducer(state)
+                ctx.scale_b = _batch_reducer(state, ctx.pose_handover is not None)
             ctx.gunit = gunit
-            ctx.save_for_backward(pose, state, d_raw, gpart)
+            # (the state is kept as a plain attribute: a deferred exchange over a process group that completes on a thread of its own
+            #  -- gloo -- bumps its version counter AFTER this point, which save_for_backward would report as an in-place modification)
+            ctx.state = state
+            ctx.save_for_backward(pose, d_raw, gpart)
             ctx.shape = (B, H, W)
             return state[0]
         _lib.check(_timed("fwd", lambda: lib.colvo_warp_loss_fwd(
             _lib.ptr(tgt), _lib.ptr(ref), _lib.ptr(depth), _lib.ptr(pose), _lib.ptr(K), _lib.ptr(lcc_a), _lib.ptr(lcc_b),
             B, H, W, float(ssim_weight), _lib.ptr(ws), _lib.ptr(state), _lib.stream_ptr())), "colvo_warp_loss_fwd")
         if _batch_reducer is not None and any(ctx.needs_input_grad[2:7]):
-            _batch_reducer(state)
+            _batch_reducer(state, False)
         ctx.save_for_backward(tgt, ref, depth, pose, K, lcc_a, lcc_b, state)
         return state[0]
 
@@ -162,14 +170,16 @@ class _WarpLoss(torch.autograd.Function):
         lib = _lib.load()
         g = grad_loss.to(torch.float32).contiguous().reshape(1)
         if ctx.fused:
-            pose, state, d_raw, gpart = ctx.saved_tensors
+            pose, d_raw, gpart = ctx.saved_tensors
+            state = ctx.state
             B, H, W = ctx.shape
             if ctx.pose_handover is not None:
                 # everything is handed over unnormalised: this backward launches nothing
                 gu = ctx.gunit
                 d_pose, d_a, d_b = gu[:6 * B].view(B, 6), gu[6 * B:7 * B].view(B, 1), gu[7 * B:].view(B, 1)
-                ctx.handover.post((d_raw,), g, state[1:2])
-                ctx.pose_handover.post((d_pose, d_a, d_b), g, state[1:2])
+                sb = state[1:2] if ctx.scale_b is None else ctx.scale_b     # (deferred data-parallel normalisation: a scale of one)
+                ctx.handover.post((d_raw,), g, sb)
+                ctx.pose_handover.post((d_pose, d_a, d_b), g, sb)
                 if _timing is not None:
                     _timed("bwd", lambda: 0)
                 return None, None, d_raw, d_pose, None, d_a, d_b, None, None, None

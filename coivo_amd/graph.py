@@ -39,7 +39,7 @@ class GraphedTrainStep:
 
     def __init__(self, depth_net, pose_net, optimizer, B: int, H: int, W: int, ddp=None, ssim_weight: float = 0.85,
                  warmup: int = 2, capture_policy: int = 2, capture_group: Optional[int] = None, full_loss: bool = False,
-                 carry: bool = True):
+                 carry: bool = True, allow_process_group_capture: bool = False):
         dev = depth_net.flat_param.device
         self.depth_net, self.pose_net, self.opt, self.ddp = depth_net, pose_net, optimizer, ddp
         # segments of the weight-gradient chain: one command each from 32 pairs on (the eager schedule node for node: replay 7.35
@@ -49,6 +49,7 @@ class GraphedTrainStep:
             capture_group = 1 if B >= 32 else 2
         self.capture_policy, self.capture_group, self.carry = int(capture_policy), int(capture_group), bool(carry)
         self.B, self.ssim_weight, self.full_loss = B, ssim_weight, bool(full_loss)
+        self.allow_process_group_capture = bool(allow_process_group_capture)
         self.frames = torch.zeros(2 * B, 3, H, W, device=dev)
         self.K = torch.zeros(B, 3, 3, device=dev)
         self.loss = torch.zeros((), device=dev)
@@ -89,6 +90,7 @@ class GraphedTrainStep:
         """Warm up (kernel attribute setup, side streams, allocator pools) without side effects, then capture."""
         from . import _lib
         lib = _lib.load()
+        pg_path = self._process_group_path()        # (refuses a ProcessGroup.allreduce step the caller did not opt in for: before anything changes)
         nets = (self.depth_net, self.pose_net)
         for n in nets:
             n._grads_clean = False                  # whatever an earlier step left: the captured step starts with its clearing launch
@@ -119,10 +121,11 @@ class GraphedTrainStep:
         _lib.check(lib.colvo_set_capture_policy(self.capture_policy, self.capture_group), "colvo_set_capture_policy")
         _lib.check(lib.colvo_set_capture_carry(int(self.carry)), "colvo_set_capture_carry")
         _lib.check(lib.colvo_graph_stats_reset(), "colvo_graph_stats_reset")
-        if self._check_process_group_environment():
+        if pg_path:
             import time
-            torch.cuda.synchronize()            # every eager collective has finished on the GPU ...
-            time.sleep(0.25)                    # ... and the process group's watchdog (100 ms period) has taken it off its list
+            self.ddp.drain_eager_collectives()  # every work object of ours (the warm-up steps' too): waited for and completed
+            torch.cuda.synchronize()
+            time.sleep(2.5 * self._TORCH_WATCHDOG_PERIOD_S)
         g = torch.cuda.CUDAGraph()
         nspace = int(_lib.dev_env("COLVO_GRAPH_SPACER_STREAMS", "0"))       # (developer probe: streams created in front of the capture)
         self._spacers = [torch.cuda.Stream() for _ in range(nspace)]
@@ -156,27 +159,45 @@ class GraphedTrainStep:
         restore()          # capture itself does not execute, but keep the state exactly as the caller left it
         torch.cuda.synchronize()
 
-    def _check_process_group_environment(self) -> bool:
-        """True when the step carries RCCL collectives (an attached GradBuckets on an nccl group).
+    # torch's ProcessGroupNCCL watchdog wakes every kWatchdogThreadSleepMillis = 100 ms (a constant of ProcessGroupNCCL.hpp, not an option)
+    _TORCH_WATCHDOG_PERIOD_S = 0.1
 
-        torch's ProcessGroupNCCL keeps every EAGER collective on a list its watchdog thread walks every 100 ms, asking each one's end
-        event whether it has completed; captured collectives never enter that list.  This HIP runtime refuses hipEventQuery on an
-        event whose stream is being captured at that moment ('operation not permitted on an event last recorded in a capturing
-        stream'), the refusal is an exception on the watchdog thread, and torch ends the process.  So an eager collective that is
-        still on the list -- finished on the GPU milliseconds ago, not yet reaped -- when RCCL's stream joins a capture kills the
-        process if the watchdog wakes inside that window: round 5 saw it twice in about a dozen runs of tests/graph_rccl_worker.py
-        (eager data-parallel steps right in front of the capture; the 64-pair shape, whose capture takes ~0.1 s, more often), the
-        second time WITH the event cache off -- which retires the round's first hypothesis (a recycled event keeping its captured
-        mark; TORCH_NCCL_CUDA_EVENT_CACHE=0 is still what bench.py and the tests export: fresh events per collective cost nothing
-        measurable).  capture() therefore drains the device and sleeps two watchdog periods before it begins: the list is empty when
-        the capture starts, and nothing eager is issued until it ends."""
+    def _process_group_path(self) -> bool:
+        """The rule for a captured step that carries RCCL collectives (round 6).  -> True when the step's
+        collectives go through ProcessGroup.allreduce AND the caller opted in (capture() then runs the timing-based guard).
+
+        The hazard (two process aborts in round 5, gpurun_out/r5d/t_all.log and r5final/t_all.log:33-34): ProcessGroupNCCL keeps
+        every EAGER collective on a list its watchdog thread walks, asking each one's end event whether it has completed.  Those
+        events live on torch's internal RCCL stream, and this HIP runtime refuses hipEventQuery on an event of a stream that is
+        being captured ('operation not permitted on an event last recorded in a capturing stream'); the refusal is an exception on
+        the watchdog thread, and torch ends the process.  So the precondition of the abort is: torch's RCCL stream joins a capture
+        while an eager work object is still listed.
+
+        * Native path (GradBuckets(native_collectives=True), ddp._NativeRccl) -- the rule: the step's collectives, eager AND captured,
+          are ncclAllReduce calls on a stream of OURS.  They create no work objects, and torch's RCCL stream never joins the capture,
+          so whatever the caller left on the watchdog's list (a barrier at start-up, a logging reduction) is queried on a stream that
+          is not capturing.  Nothing to wait for: the precondition cannot arise.
+        * ProcessGroup.allreduce path: refused unless the caller opts in (allow_process_group_capture=True).  There is no API that says
+          "the watchdog's list is empty" (no _wait_for_pending_works in this torch), so the opt-in is the round-5 guard made as tight
+          as the API allows: every work object the library created is waited for and must report is_completed(), the device is
+          drained, and one watchdog period (the constant above, twice over) passes before the capture begins; the caller must not
+          issue a collective on the group until capture() returns.  Timing-based by nature -- hence not the default."""
         if self.ddp is None:
             return False
         try:
             import torch.distributed as dist
-            return bool(dist.is_initialized() and dist.get_backend(self.ddp.group) == "nccl")
+            nccl = bool(dist.is_initialized() and dist.get_backend(self.ddp.group) == "nccl")
         except Exception:           # noqa: BLE001
+            nccl = False
+        if not nccl or getattr(self.ddp, "native_collectives", False):
             return False
+        if not self.allow_process_group_capture:
+            raise RuntimeError(
+                "GraphedTrainStep: a captured step on an nccl process group needs the native RCCL path -- GradBuckets(..., "
+                "native_collectives=True) -- which creates no ProcessGroupNCCL work objects; through ProcessGroup.allreduce the watchdog "
+                "thread can query an eager collective's event while RCCL's stream is capturing, and torch then aborts the process "
+                "(coivo_amd/graph.py _process_group_path).  allow_process_group_capture=True accepts the timing-based guard.")
+        return True
 
     def close(self) -> None:
         """Destroy the captured graph NOW, at a defined point, and return the library to its pre-capture state.

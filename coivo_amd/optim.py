@@ -28,6 +28,10 @@ class FusedAdam:
                 raise TypeError("FusedAdam takes the HIP-backed networks (coivo_amd.nn.DepthNet / PoseNet)")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.grad_scale = 1.0
+        # A second gradient factor that only exists on the device, for ONE step: ddp.GradBuckets(defer_loss_normalisation=True) posts the
+        # 1-element tensor its two-float all-reduce ends in (world / max(3 n_valid of the whole batch, 1)); step() multiplies it into
+        # grad_scale inside the update kernel and forgets it.  None: no such factor.
+        self.grad_scale_dev = None
         self.zero_grad_in_step = bool(zero_grad_in_step)
         self._multi = _lib.dev_env("COLVO_NO_MULTI_ARENA") is None          # developer A/B switches (COLVO_DEV=1)
         self._fused_pack = _lib.dev_env("COLVO_NO_ADAM_PACK") is None
@@ -64,6 +68,9 @@ class FusedAdam:
         self._t += 1
         if self._fused_pack and self._pack_step():
             return
+        if self.grad_scale_dev is not None:
+            raise RuntimeError("FusedAdam: a device-side gradient scale needs the one-pass update (colvo_adam_pack_step_scaled: "
+                               "networks of one compute dtype, COLVO_NO_ADAM_PACK unset)")
         if self._multi and not self._device_steps and len(self.modules) <= _lib.MAX_ARENAS:
             # one launch for all networks (the step number comes from the host)
             for m in self.modules:
@@ -103,9 +110,15 @@ class FusedAdam:
             m.attach_grads()
         tab = self._pack_table()
         step_ptr = _lib.ptr(self.state[0]["step"]) if self._device_steps else 0
-        _lib.check(_lib.load().colvo_adam_pack_step(ops.dt_code(dt), _lib.ptr(tab[0]), tab[1], tab[2], self.lr, self.betas[0],
-                                                    self.betas[1], self.eps, self.grad_scale, step_ptr, self._t, _lib.stream_ptr()),
-                   "colvo_adam_pack_step")
+        gdev, self.grad_scale_dev = self.grad_scale_dev, None          # (one step only)
+        if gdev is None:
+            _lib.check(_lib.load().colvo_adam_pack_step(ops.dt_code(dt), _lib.ptr(tab[0]), tab[1], tab[2], self.lr, self.betas[0],
+                                                        self.betas[1], self.eps, self.grad_scale, step_ptr, self._t, _lib.stream_ptr()),
+                       "colvo_adam_pack_step")
+        else:
+            _lib.check(_lib.load().colvo_adam_pack_step_scaled(ops.dt_code(dt), _lib.ptr(tab[0]), tab[1], tab[2], self.lr, self.betas[0],
+                                                               self.betas[1], self.eps, self.grad_scale, _lib.ptr(gdev), step_ptr, self._t,
+                                                               _lib.stream_ptr()), "colvo_adam_pack_step_scaled")
         # (with device-side step numbers only the first network's counter is advanced here; _sync_step_state() brings the
         # others in line when the state is read)
         # (while the step is being CAPTURED nothing has run: the arenas are as dirty as they were -- a capture that fails, or one

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define COLVO_ABI_VERSION 9
+#define COLVO_ABI_VERSION 10
 
 typedef void* colvo_stream_t; /* hipStream_t */
 
@@ -89,6 +89,12 @@ int colvo_warp_loss_fused_bwd_params(const float* loss_state, const float* grad_
  * (1 / world) x the sum of the ranks' gradients is the gradient of that loss.  Every backward entry point above reads the scale
  * from loss_state[1].  world = 1 leaves the state bit for bit as the forward wrote it. */
 int colvo_warp_loss_rescale(float* loss_state, int world, colvo_stream_t stream);
+/* The same, for a caller that takes the exchange OFF the critical path (round 6): the backward pass has already run on the
+ * UNNORMALISED gradients (its consumers were handed a scale of 1 in place of loss_state[1]) while the two floats were being
+ * all-reduced; every parameter gradient is linear in the scale, so it is applied once, behind the gradient all-reduce, by the
+ * optimizer: *scale_out = world / max(3 n_global, 1) is what colvo_adam_pack_step_scaled multiplies into its grad_scale.
+ * loss_state[0] / [1] are rewritten as by colvo_warp_loss_rescale (the reported loss becomes the whole batch's). */
+int colvo_warp_loss_rescale_to(float* loss_state, int world, float* scale_out, colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * SURVEY.md §8f-1  geometric consistency (README.md:1 "Considering Geometric and Photometric   *
@@ -400,6 +406,13 @@ typedef struct ColvoAdamPackEntry {
 } ColvoAdamPackEntry;
 int colvo_adam_pack_step(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
                          float eps, float grad_scale, int32_t* step_count, int t, colvo_stream_t stream);
+/* ... with a second gradient factor read from the DEVICE at execution time (NULL: none): every gradient is multiplied by
+ * grad_scale * *grad_scale_dev first.  For data parallel with the loss normalisation taken off the critical path
+ * (colvo_warp_loss_rescale_to): grad_scale = 1 / world from the host, *grad_scale_dev = world / max(3 n_global, 1) from the
+ * two-float all-reduce that ran beside the backward pass. */
+int colvo_adam_pack_step_scaled(int dtype, const void* table, int nentries, int nblocks, float lr, float beta1, float beta2,
+                                float eps, float grad_scale, const float* grad_scale_dev, int32_t* step_count, int t,
+                                colvo_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------- *
  * SURVEY.md §8f-3  inference: dense depth maps stitched along the integrated trajectory into a  *
@@ -519,6 +532,13 @@ int colvo_capture_reset(colvo_stream_t stream);
 /* Dispatch thresholds (coivo_amd/csrc/tuning.h: ONE table, defaults measured on MI355X; production reads no environment
  * variable).  Developer / test hooks: set or read an entry by name ("quad_min_wgs", "wgrad_atomic_mb", ...); with COLVO_DEV=1 in
  * the environment at load time every entry can also be overridden by COLVO_<UPPER-CASE NAME>. */
+/* Which kernel form the dispatchers chose, counted per process since the last reset (developer / test hook: the forms that are
+ * selected by grid size -- k_conv_rt, the halved weight-gradient grids, the four-class / register-tiled weight gradients, the
+ * clean-arena stores -- are invisible in a result; a test that means to cover one asserts that it ran).  colvo_form_counts fills
+ * out[0..n) and returns the number of forms; colvo_form_name(id) names them (NULL beyond the last). */
+int colvo_form_counts(long long* out, int n);
+void colvo_form_counts_reset(void);
+const char* colvo_form_name(int id);
 int colvo_tune_set(const char* name, double value);
 int colvo_tune_get(const char* name, double* value);
 

@@ -46,8 +46,12 @@ def _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g
     # (the per-rank means differ from it: this batch would not pass with the round-4 normalisation)
     per_rank = [G.oracle_step(seed, {k: cpu[k][r * B:(r + 1) * B] for k in ("tgt", "ref", "K")}, torch.float32)["loss"] for r in range(world)]
     print(f"oracle: batch loss {acc[torch.float32][1]:.7f}, mean of the per-rank losses {sum(per_rank) / world:.7f}", flush=True)
-    hip = [("depth." + n, p.grad.detach().double() / world) for n, p in dn.named_parameters()] + \
-          [("pose." + n, p.grad.detach().double() / world) for n, p in pn.named_parameters()]
+    # (DDP_DEFER=1: the arena holds the sum of the ranks' UNNORMALISED gradients and the optimizer has been handed the device-side
+    #  factor world / max(3 n_global, 1); the gradient of the batch loss is their product / world)
+    gs = (float(opt.grad_scale_dev.item()) if opt.grad_scale_dev is not None else 1.0) / world
+    assert (opt.grad_scale_dev is not None) == (os.environ.get("DDP_DEFER") is not None)
+    hip = [("depth." + n, p.grad.detach().double() * gs) for n, p in dn.named_parameters()] + \
+          [("pose." + n, p.grad.detach().double() * gs) for n, p in pn.named_parameters()]
     rows = G.grad_parity_table(hip, acc[torch.float32][0], acc[torch.float64][0])
     bad = G.grad_parity_failures(rows)
     assert not bad, "data-parallel gradient vs the oracle's gradient of the whole batch's loss:\n" + "\n".join(bad)
@@ -63,6 +67,7 @@ def _check_against_oracle(rank, world, seed, B, full, dn, pn, loss, opt, g_dn, g
     from coivo_amd.optim import FusedAdam
     opt2 = FusedAdam([dn2, pn2], lr=opt.lr)
     opt2.grad_scale = opt.grad_scale
+    opt2.grad_scale_dev = opt.grad_scale_dev
     dn2.attach_grads(); pn2.attach_grads()
     dn2.flat_grad.copy_(dn.flat_grad); pn2.flat_grad.copy_(pn.flat_grad)
     opt2.step()
@@ -108,7 +113,10 @@ def main():
     sl = slice(rank * B, (rank + 1) * B)
     dn, pn = fresh()
     opt = FusedAdam([dn, pn], lr=1e-4)
-    ddp = GradBuckets([dn, pn], bucket_bytes=2 << 20)          # several buckets per arena
+    # DDP_DEFER=1: the loss normaliser's exchange overlaps the backward pass and the global scale goes into the optimizer (round 6)
+    defer = os.environ.get("DDP_DEFER") is not None and not obj
+    ddp = GradBuckets([dn, pn], bucket_bytes=2 << 20,          # several buckets per arena
+                      **(dict(defer_loss_normalisation=True, optimizer=opt) if defer else {}))
     opt.grad_scale = ddp.grad_scale
     opt.zero_grad()
     loss = hnn.dcdp_forward(dn, pn, full["tgt"][sl], full["ref"][sl], full["K"][sl], **obj)[0]
@@ -136,7 +144,7 @@ def main():
         slices = [slice(r * B, (r + 1) * B) for r in range(world)]
         if not obj:
             seen = []
-            Fh.set_batch_reducer(lambda st: seen.append(st.clone()))
+            Fh.set_batch_reducer(lambda st, can_defer=False: seen.append(st.clone()))
             for s2 in slices:
                 hnn.dcdp_forward(dn2, pn2, full["tgt"][s2], full["ref"][s2], full["K"][s2])
             assert len(seen) == world
@@ -144,9 +152,18 @@ def main():
             for st in seen[1:]:
                 glob += st[2:4]
 
-            def whole_batch(st):
+            one_ref, norm_ref = torch.ones(1, device=dev), torch.ones(1, device=dev)
+
+            def whole_batch(st, can_defer=False):
                 st[2:4].copy_(glob)
+                if defer and can_defer:     # what the ranks did: backward on the raw gradients, the global scale through the optimizer
+                    _lib.check(_lib.load().colvo_warp_loss_rescale_to(_lib.ptr(st), world, _lib.ptr(norm_ref), _lib.stream_ptr()),
+                               "colvo_warp_loss_rescale_to")
+                    opt2.grad_scale_dev = norm_ref
+                    return one_ref
+                assert not defer
                 _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(st), world, _lib.stream_ptr()), "colvo_warp_loss_rescale")
+                return None
             Fh.set_batch_reducer(whole_batch)
         opt2.zero_grad()
         for s2 in slices:
@@ -201,7 +218,7 @@ def main():
         if det:
             assert torch.equal(a, b), f"{name}: deterministic mode, yet the learned split points changed the gradient bits"
     if rank == 0:
-        print("DDP_OK" + (" DET" if det else "") + (" FULL" if obj else ""), f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
+        print("DDP_OK" + (" DET" if det else "") + (" FULL" if obj else "") + (" DEFER" if defer else ""), f"command-list calls: {n_learned} (learned) vs {n_full} (per layer)", flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -22,7 +22,6 @@ def main():
     from oracle import colvo_spec as S
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")      # (coivo_amd/graph.py _check_process_group_environment)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -49,7 +48,18 @@ def main():
     ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
     ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
     assert ddp1.native_collectives == native and ddp2.native_collectives == native
-    step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
+    if not native:
+        # the rule (coivo_amd/graph.py _process_group_path): a captured nccl step goes through the native RCCL path; through
+        # ProcessGroup.allreduce it is refused -- before anything is captured, and leaving the networks usable -- unless the caller opts in
+        refused = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2)
+        try:
+            refused.capture()
+            raise AssertionError("a captured step through ProcessGroup.allreduce was not refused")
+        except RuntimeError as e:
+            assert "native_collectives=True" in str(e), e
+        # (the refusal comes first in capture(): nothing ran, nothing in the library changed)
+        assert refused.graph is None and torch.equal(dn1.flat_param, dn2.flat_param) and torch.equal(pn1.flat_param, pn2.flat_param)
+    step = GraphedTrainStep(dn2, pn2, opt2, B, H, W, ddp=ddp2, allow_process_group_capture=not native)
     assert step.capture_group == (1 if B >= 32 else 2)
     eager, graphed = [], []
     for _ in range(3):

@@ -65,7 +65,7 @@ def test_per_rank_shape_step(pairs, config):
     l1 = 0.5 * ((d_t[sl].cpu() - do_t).abs().mean().item() + (d_r[sl].cpu() - do_r).abs().mean().item())
     rel = l1 / do_t.abs().mean().item()
     print(f"{config} per-rank shape ({pairs} pairs): depth L1 vs ref on pairs 0..7 {l1:.3e} (relative {rel:.3e})")
-    assert rel < 1e-2
+    assert rel < 3.5e-3            # (configs[1]'s bar for the same quantity, tests/test_config1_gpu.py; 1e-2 until round 5)
 
     # ---- batch-split consistency, with the normalisation data parallel uses ----
     # The slices stand for ranks: each slice's loss kernel is followed by what ddp.GradBuckets(exact_batch_loss=True) does behind it
@@ -81,7 +81,7 @@ def test_per_rank_shape_step(pairs, config):
         return hnn.dcdp_forward(dn, pn, d["tgt"][sl].contiguous(), d["ref"][sl].contiguous(), d["K"][sl].contiguous())[0]
 
     seen = []
-    Fh.set_batch_reducer(lambda st: seen.append(st.clone()))
+    Fh.set_batch_reducer(lambda st, can_defer=False: seen.append(st.clone()))
     try:
         first = run(slices[0]).item()               # (its own masked mean: the reducer above changes nothing)
         for sl in slices[1:]:
@@ -90,7 +90,7 @@ def test_per_rank_shape_step(pairs, config):
         glob = torch.stack([st[2:4] for st in seen]).sum(0)
         assert glob[0].item() > 0.5 * pairs * H * W              # the synthetic pairs overlap almost everywhere
 
-        def whole_batch(st):
+        def whole_batch(st, can_defer=False):
             st[2:4].copy_(glob)
             _lib.check(_lib.load().colvo_warp_loss_rescale(_lib.ptr(st), k, _lib.stream_ptr()), "colvo_warp_loss_rescale")
         Fh.set_batch_reducer(whole_batch)

@@ -50,6 +50,22 @@ def test_two_rank_dp_with_the_widened_objective_is_bitwise_too():
     assert "DDP_OK DET FULL" in r.stdout
 
 
+@pytest.mark.parametrize("mode", ["atomics", "deterministic", "oracle"])
+def test_two_rank_dp_with_the_loss_normalisation_off_the_critical_path(mode):
+    """GradBuckets(defer_loss_normalisation=True, optimizer=...) (round 6): the two-float exchange of the batch's
+    valid-pixel count and masked sum is only started behind the loss kernel; the backward pass runs on the unnormalised gradients,
+    the buckets sum those, finish() posts world / max(3 n_global, 1) to the optimizer as a device-side factor of its gradient scale.
+    Same three checks as the blocking form above: all-reduced gradient and parameters after Adam against one process accumulating
+    both ranks' batches with the same arithmetic (bitwise in deterministic mode), and gradient x scale / world, loss and Adam step
+    against the ORACLE's big-batch update at the bar of tests/gpu_util.grad_parity_failures."""
+    env = {"DDP_DEFER": "1", **({"DDP_DET": "1"} if mode == "deterministic" else {}), **({"DDP_ORACLE": "1"} if mode == "oracle" else {})}
+    r = _run([os.path.join(ROOT, "tests", "ddp_gpu_worker.py")], extra_env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert ("DDP_OK DET DEFER" if mode == "deterministic" else "DDP_OK DEFER") in r.stdout, r.stdout[-2000:]
+    if mode == "oracle":
+        assert "DDP_OK ORACLE" in r.stdout, r.stdout[-2000:]
+
+
 def test_bench_multiprocess_path():
     r = _run([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
               "--no-roofline-cfg2", "--batch-per-gpu", "2", "--height", "64", "--width", "96", "--rehearse-on-one-gpu"])
@@ -87,8 +103,12 @@ def test_rccl_path_with_one_rank():
     out = {}
     # rccl: RCCL called natively on the group's communicator (ddp._NativeRccl, the default since round 5); rccl_torch: the same step
     # through ProcessGroup.allreduce (COLVO_DDP_TORCH_COLLECTIVES=1), the fallback
-    for tag, extra, e in (("plain", [], {}), ("rccl", ["--rccl-single"], {}), ("rccl_bf16", ["--rccl-single", "--grad-transport", "bf16"], {}),
-                          ("rccl_torch", ["--rccl-single"], {"COLVO_DDP_TORCH_COLLECTIVES": "1"})):
+    # (--blocking-loss-exchange: the round-5 form, whose arithmetic is the plain run's -- the exactness checks; `rccl_defer`: the default
+    #  since round 6, the loss normaliser applied by the optimizer instead of the heads' backward kernels -- same mathematics, other
+    #  roundings)
+    blk = ["--rccl-single", "--blocking-loss-exchange"]
+    for tag, extra, e in (("plain", [], {}), ("rccl", blk, {}), ("rccl_bf16", blk + ["--grad-transport", "bf16"], {}),
+                          ("rccl_torch", blk, {"COLVO_DDP_TORCH_COLLECTIVES": "1"}), ("rccl_defer", ["--rccl-single"], {})):
         r = subprocess.run(common + extra, capture_output=True, text=True, env=dict(env, **e), timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = json.loads(r.stdout.strip().split("\n")[-1])
@@ -106,6 +126,10 @@ def test_rccl_path_with_one_rank():
     assert abs(out["rccl_bf16"]["final_loss"] - out["plain"]["final_loss"]) <= 0.1 * D, \
         (out["rccl_bf16"]["final_loss"], out["plain"]["final_loss"], D)
     assert out["rccl"]["config"]["grad_transport"] == "f32" and out["rccl_bf16"]["config"]["grad_transport"] == "bf16"
+    assert "overlaps the backward pass" in out["rccl_defer"]["config"]["batch_loss"] and "overlaps" not in out["rccl"]["config"]["batch_loss"]
+    assert out["rccl_defer"]["first_loss"] == out["plain"]["first_loss"]
+    assert abs(out["rccl_defer"]["final_loss"] - out["plain"]["final_loss"]) <= 0.02 * D, (out["rccl_defer"]["final_loss"], out["plain"]["final_loss"], D)
+    assert out["rccl_defer"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
     assert out["rccl"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
     assert out["rccl_torch"]["ms_per_step_hipevent_median"] < 1.6 * out["plain"]["ms_per_step_hipevent_median"]
 

@@ -658,3 +658,67 @@ def test_weight_gradients_stored_into_a_clean_arena_equal_the_added_ones():
     assert all(v == 0 for v in f2)                             # the second pass found the arena dirty
     for a, c in ((gd2, gd0), (gp2, gp0)):
         assert (a - 2 * c).abs().max().item() <= 2e-4 * c.abs().max().item()
+
+
+def test_a_torch_side_write_to_grad_behind_zero_grad_is_kept_by_every_layer():
+    """the "arena is zero" promise was a host flag nothing guarded -- an L2 term built through autograd on a parameter the
+    fused network also uses (its AccumulateGrad runs BEFORE the network's node) was overwritten by the single-split layers' stores and
+    kept by the multi-split layers' atomics.  The flag now carries the arena's version counter: any torch-side write to a .grad view
+    makes the backward pass add.  loss + sum(p^2) behind zero_grad() against the same gradients with the store switch off."""
+    from coivo_amd import _lib, nn as hnn
+    B, H, W, seed = 2, 64, 96, 43
+    b = to_dev(synth.make_batch(B, H, W, seed=seed))
+
+    def grads(store):
+        _lib.tune_set("wgrad_store_clean", 1 if store else 0)
+        try:
+            _, _, dn, pn = _models(seed, torch.bfloat16)
+            dn.zero_grad(); pn.zero_grad()
+            assert dn._grads_clean and pn._grads_clean
+            loss = hnn.dcdp_forward(dn, pn, b["tgt"], b["ref"], b["K"])[0]
+            reg = sum((p ** 2).sum() for p in list(dn.parameters()) + list(pn.parameters()))
+            (loss + 1e-3 * reg).backward()
+            dn.join_side(); pn.join_side()
+            torch.cuda.synchronize()
+            flagged = [pr._flag_value for inst in next(iter(dn._insts.values())) for pr, _ in inst.passes.values() if pr.flag_slots]
+            return dn.flat_grad.clone(), pn.flat_grad.clone(), flagged, dn, pn
+        finally:
+            _lib.tune_set("wgrad_store_clean", 1)
+
+    gd1, gp1, f1, dn, pn = grads(True)
+    gd0, gp0, _, _, _ = grads(False)
+    assert f1 and all(v == 0 for v in f1)                      # the version counter moved: the pass was NOT told "clean"
+    for a, c, net in ((gd1, gd0, dn), (gp1, gp0, pn)):
+        assert (a - c).abs().max().item() <= 1e-4 * c.abs().max().item()
+        # ... and the regulariser's own gradient 2e-3 p is in there, in the layers that would have stored (the deepest ones) too
+        reg_only = 2e-3 * net.flat_param
+        L = net.enc5b if hasattr(net, "enc5b") else net._layers()[-2]
+        sl = slice(L.span[0], L.span[0] + L.cout * 9 * L.cin_pad)
+        assert (a[sl] - reg_only[sl]).abs().max().item() > 0 and reg_only[sl].abs().max().item() > 0
+    # a manual write is seen as well; and the flag comes back with the next clearing
+    dn.zero_grad()
+    assert dn._grads_clean
+    dn.enc1a.weight.grad.add_(1.0)
+    assert not dn._grads_clean
+    dn.zero_grad()
+    assert dn._grads_clean
+
+
+@pytest.mark.parametrize("mode", ["inference_mode", "no_grad"])
+def test_depthnet_forward_of_an_even_batch_without_autograd(mode):
+    """for an even batch DepthNet.forward takes the pair form, whose tags read tensors' version counters -- which inference
+    tensors do not have ('Inference tensors do not track version counter').  Without autograd the plain node runs: same depth, no
+    PoseNet-input buffer kept alive, the spec's slices are ordinary views."""
+    _, _, dn, pn = _models(7, torch.bfloat16)
+    b = to_dev(synth.make_batch(2, 64, 96, seed=7))
+    frames = torch.cat([b["tgt"], b["ref"]])
+    ref = dn(frames).detach().clone()                          # (with autograd: the pair form)
+    ctx = torch.inference_mode() if mode == "inference_mode" else torch.no_grad()
+    with ctx:
+        d = dn(frames)
+        assert type(d) is torch.Tensor and not hasattr(d, "_colvo_halves")
+        d_t, d_r = d[:2], d[2:]
+        pose, a_, b_ = pn(b["tgt"], b["ref"], d_t, d_r)
+        odd = dn(frames[:3])
+    torch.cuda.synchronize()
+    assert torch.equal(d, ref) and odd.shape[0] == 3 and pose.shape == (2, 6)
