@@ -760,7 +760,12 @@ def main():
                "ms_per_step_pipeline_full": pipeline_full,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-               "config": {"workload": workload_name(args, B, H, W),
+               # (how the timed steps were launched belongs to the workload's name: configs[4] names the hipGraph-captured step, and on
+               #  these boxes the replay is the SLOWER form -- DESIGN.md section 7.6 -- so the line says which one it timed)
+               "config": {"workload": workload_name(args, B, H, W) + (
+                              "; launched as a replayed hipGraph" + (" (as BASELINE configs[4] names it; eager launches measure faster on one GPU)"
+                                                                   if args.config_id == "4" else "")
+                              if use_graph else "; eager launches"),
                           "baseline_config": args.config_id if not args.custom_shape else None,
                           "global_batch": world * B, "height": H, "width": W,
                           "parallelism": f"dp{world}" + (" (one rank through the RCCL path)" if args.rccl_single else ""),
