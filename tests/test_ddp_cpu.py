@@ -160,3 +160,44 @@ def test_gradbuckets_needs_process_group():
         pytest.skip("a process group is active in this process")
     with pytest.raises(RuntimeError):
         GradBuckets([FakeArena(8)])
+
+
+def _worker_rules(rank, world, port):
+    """Round 6 rules that need no GPU: the deferred loss normalisation needs its optimizer; a captured step on an nccl group is refused
+    through ProcessGroup.allreduce (the backend name is monkeypatched: the decision, not the capture, is what runs here)."""
+    from coivo_amd import graph
+    from coivo_amd.ddp import GradBuckets
+    _init(rank, world, port)
+    try:
+        a = FakeArena(1000)
+        with pytest.raises(ValueError, match="optimizer"):
+            GradBuckets([a], defer_loss_normalisation=True)
+        ddp = GradBuckets([a])
+        assert ddp.native_collectives is False and ddp.native_fallback is None and ddp._defer is False
+
+        class Step:             # the two attributes _process_group_path reads
+            allow_process_group_capture = False
+        st = Step()
+        st.ddp = ddp
+        assert graph.GraphedTrainStep._process_group_path(st) is False           # gloo: nothing to guard
+        real = dist.get_backend
+        dist.get_backend = lambda group=None: "nccl"
+        try:
+            with pytest.raises(RuntimeError, match="native_collectives=True"):
+                graph.GraphedTrainStep._process_group_path(st)
+            st.allow_process_group_capture = True
+            assert graph.GraphedTrainStep._process_group_path(st) is True        # opted in: capture() runs the timing-based guard
+            ddp._native = object()                                               # native path: no guard at all
+            st.allow_process_group_capture = False
+            assert graph.GraphedTrainStep._process_group_path(st) is False
+            ddp._native = None
+        finally:
+            dist.get_backend = real
+        ddp.drain_eager_collectives()                                            # nothing issued: a no-op
+        ddp.detach()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_round6_rules_for_deferred_normalisation_and_captured_nccl_steps():
+    mp.spawn(_worker_rules, args=(1, _free_port()), nprocs=1, join=True)
