@@ -484,6 +484,7 @@ class GradBuckets:
             st.module.grad_ready_hook = None
         self.attached = False
         self._install_reducer(False)
+        self._deferred = None                   # (an exchange started by a step that never reached finish())
         if getattr(self, "_shared_modules", None):
             from . import nn
             nn.unshare_side_stream(self._shared_modules)      # each network back on its own weight-gradient stream
