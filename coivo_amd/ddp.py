@@ -202,6 +202,9 @@ class GradBuckets:
         per step, taken through the hand-over path (nn.dcdp_forward, forward_pair_split, the spec's own call sequence) -- must be
         the only source of parameter gradients in the step (anything else would be scaled along), and finish() / optimizer.step()
         must follow every backward pass.  Calls that cannot defer (a loss without the hand-over mailboxes) exchange at once, as before.
+        photometric_loss's reducer is ONE process-wide hook (functional.set_batch_reducer), installed by the last GradBuckets built or
+        resumed: a process that keeps several GradBuckets attached at once (tests/graph_rccl_worker.py does) must re-install the right
+        one before each step (_install_reducer(True)) -- with this option the reducer carries state.
         native_collectives=True: RCCL called through its own C ABI on the group's communicator (_NativeRccl: half the host cost per
         collective) instead of through ProcessGroup.allreduce -- for an nccl group with GPU arenas, unless COLVO_DDP_TORCH_COLLECTIVES=1
         is exported.  An opt-in because it binds the CALLER: no torch collective may run on this group from before the attach to the

@@ -36,7 +36,7 @@ def main():
 
     # default: B=2 64x96; `... f32 64 256 320` = the per-GPU shape of BASELINE configs[4] (64 pairs of 320x256): from 32 pairs on
     # GraphedTrainStep cuts the weight-gradient chain into one-command segments (graph.py), a branch the small shape never reaches
-    B, H, W = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 else (2, 64, 96)
+    B, H, W = (int(v) for v in sys.argv[2:5]) if len(sys.argv) >= 5 and sys.argv[2].isdigit() else (2, 64, 96)
     seed = 63
     b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in synth.make_batch(B, H, W, seed=seed).items()}
     frames = torch.cat([b["tgt"], b["ref"]])
@@ -45,8 +45,15 @@ def main():
     # (RCCL called natively on the group's communicator, ddp._NativeRccl: this worker runs no torch collective on the group; `... torch`
     #  as the last argument keeps ProcessGroup.allreduce)
     native = sys.argv[-1] != "torch"
-    ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
-    ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native)
+    # `... defer` as the last argument: the loss normaliser's exchange off the critical path (GradBuckets(defer_loss_normalisation=True):
+    # what bench.py runs data parallel since round 6) -- the two-float all-reduce, colvo_warp_loss_rescale_to in finish() and the
+    # optimizer's device-side scale are then all INSIDE the captured step
+    defer = sys.argv[-1] == "defer"
+    ddp1 = GradBuckets([dn1, pn1], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native,
+                       **(dict(defer_loss_normalisation=True, optimizer=opt1) if defer else {}))
+    ddp2 = GradBuckets([dn2, pn2], bucket_bytes=4 << 20, transport_dtype=transport, native_collectives=native,
+                       **(dict(defer_loss_normalisation=True, optimizer=opt2) if defer else {}))
+    assert ddp1._defer == defer and ddp2._defer == defer
     assert ddp1.native_collectives == native and ddp2.native_collectives == native
     if not native:
         # the rule (coivo_amd/graph.py _process_group_path): a captured nccl step goes through the native RCCL path; through
@@ -63,12 +70,16 @@ def main():
     assert step.capture_group == (1 if B >= 32 else 2)
     eager, graphed = [], []
     for _ in range(3):
+        # (photometric_loss's batch reducer is ONE process-wide hook, the last GradBuckets' -- a process has one set of networks; this
+        #  worker has two, and with the deferred normalisation the reducer carries state: each step gets its own object's)
+        ddp1._install_reducer(True)
         opt1.zero_grad()
         loss = hnn.dcdp_forward(dn1, pn1, b["tgt"], b["ref"], b["K"])[0]
         loss.backward()
         ddp1.finish()
         opt1.step()
         eager.append(loss.item())
+        ddp2._install_reducer(True)
         graphed.append(step(frames, b["K"]).item())
     torch.cuda.synchronize()
     assert eager == graphed, (sys.argv[1], eager, graphed)
@@ -76,8 +87,9 @@ def main():
     assert graphed[-1] < graphed[0]
     st = step.stats
     assert st["pending_commands"] == 0 and st["side_commands"] == 29, st      # (deterministic nets: no fused iconv1 kernel; the head's MFMA form is 2)
-    if transport is None:
-        # ... and the fp32-transport run is bitwise the run WITHOUT any process group (a one-rank all-reduce is the identity)
+    if transport is None and not defer:
+        # ... and the fp32-transport run is bitwise the run WITHOUT any process group (a one-rank all-reduce is the identity; not with
+        # the deferred normalisation, which applies the scale in the optimizer instead of the heads' backward kernels: other roundings)
         dn3, pn3, opt3 = setup(seed)
         for _ in range(3):
             opt3.zero_grad()
@@ -88,7 +100,7 @@ def main():
     ddp1.detach()
     ddp2.detach()
     torch.cuda.synchronize()
-    print(f"GRAPH_RCCL_OK {sys.argv[1]} losses {graphed}", flush=True)
+    print(f"GRAPH_RCCL_OK {sys.argv[1]}{' DEFER' if defer else ''} losses {graphed}", flush=True)
     sys.stdout.flush()
     # leave without tearing the communicator / the graph down piece by piece: the process is done
     os._exit(0)

@@ -55,7 +55,7 @@ def test_graph_is_built_with_explicit_dependencies(policy):
     _run_case("explicit_dependencies", policy)
 
 
-@pytest.mark.parametrize("transport", ["f32", "bf16", "f32-torch"])
+@pytest.mark.parametrize("transport", ["f32", "bf16", "f32-torch", "f32-defer", "bf16-defer"])
 def test_graphed_step_with_rccl_single_rank(transport):
     """configs[4]'s structure on one GPU: the graph contains the bucketed all-reduces of ddp.GradBuckets (RCCL, one rank) beside the
     native two-chain backward.  Deterministic weight gradients + fp32 transport: a one-rank all-reduce is the identity, so the
@@ -68,13 +68,15 @@ def test_graphed_step_with_rccl_single_rank(transport):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # f32 / bf16: RCCL called natively on the group's communicator (ddp._NativeRccl); f32-torch: through ProcessGroup.allreduce
+    # f32 / bf16: RCCL called natively on the group's communicator (ddp._NativeRccl); f32-torch: through ProcessGroup.allreduce (refused
+    # first, then with the opt-in); *-defer (round 6): the loss normaliser's exchange started behind the loss kernel, waited for in
+    # finish(), the scale applied by the optimizer -- all of it inside the captured step, as `bench.py --config 4` runs data parallel
     transport, path = (transport.split("-") + ["native"])[:2]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0",
-               MASTER_PORT={"f32native": "29541", "bf16native": "29542", "f32torch": "29544"}[transport + path])
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "graph_rccl_worker.py"), transport] + (["torch"] if path == "torch" else []),
+               MASTER_PORT={"f32native": "29541", "bf16native": "29542", "f32torch": "29544", "f32defer": "29545", "bf16defer": "29546"}[transport + path])
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "graph_rccl_worker.py"), transport] + ([path] if path != "native" else []),
                        capture_output=True, text=True, env=env, timeout=600, cwd=root)
-    assert r.returncode == 0 and f"GRAPH_RCCL_OK {transport}" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    assert r.returncode == 0 and f"GRAPH_RCCL_OK {transport}{' DEFER' if path == 'defer' else ''}" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
 def test_graphed_step_with_rccl_at_the_configs4_per_gpu_shape():
